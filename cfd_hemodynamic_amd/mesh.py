@@ -1,0 +1,363 @@
+"""Minimal simplicial mesh layer + deterministic synthetic mesh generators.
+
+The reference takes its meshes from DOLFINx (`create_unit_square`,
+`gmshio.model_to_mesh`; /root/reference/src/scenarios/lid_driven2D.py:29,
+/root/reference/src/scenarios/dfg_1.py:97-171).  Neither DOLFINx nor gmsh exist
+on the GPU box, so this module supplies the small attribute surface the
+reference's Scenario/Solver code touches (`mesh.topology.dim`,
+`mesh.geometry.dim`, `mesh.geometry.x`, `mesh.comm`, `mesh.h`,
+`locate_entities_boundary`, `meshtags(...).find`) on top of plain NumPy arrays,
+plus own generators for the BASELINE configs.
+
+2-D affine P1 triangles only (the BASELINE configs C1-C4 are 2-D).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class _SerialComm:
+    """Stand-in for `mesh.comm` (mpi4py communicator in the reference).
+
+    One process per GPU: rank/size come from torch.distributed when it is
+    initialised, else 0/1.  Only what the reference's Scenario loop calls."""
+
+    def __init__(self, rank=0, size=1):
+        self.rank = rank
+        self.size = size
+
+    def barrier(self):
+        return None
+
+    def allreduce(self, v, op=None):  # serial: identity
+        return v
+
+    def gather(self, v, root=0):
+        return [v]
+
+
+class _Topology:
+    def __init__(self, mesh):
+        self._mesh = mesh
+        self.dim = 2
+
+    def cell_name(self):
+        return "triangle"
+
+    def create_connectivity(self, d0, d1):  # connectivity is always available
+        return None
+
+
+class _Geometry:
+    def __init__(self, mesh):
+        self._mesh = mesh
+        self.dim = 2
+
+    @property
+    def x(self):
+        """[nv,3] coordinates (z=0), as DOLFINx exposes them."""
+        m = self._mesh
+        out = np.zeros((m.num_vertices, 3))
+        out[:, :2] = m.x
+        return out
+
+
+class Mesh:
+    """Affine triangle mesh.
+
+    cells : int32 [nc,3] vertex ids; x : float64 [nv,2].
+    Exterior facets (edges with exactly one adjacent cell) are enumerated once:
+    facet_cells[f] = owning cell, facet_local[f] = local index of the vertex
+    OPPOSITE to the facet (UFC/Basix numbering of triangle facets),
+    facet_vertices[f] = its two vertex ids.
+    """
+
+    def __init__(self, cells, x, comm=None, name="mesh"):
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        x = np.ascontiguousarray(x, dtype=np.float64)[:, :2].copy()
+        assert cells.ndim == 2 and cells.shape[1] == 3
+        # positive orientation
+        a = x[cells[:, 0]]
+        b = x[cells[:, 1]]
+        c = x[cells[:, 2]]
+        det = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])
+        if np.any(det == 0.0):
+            raise ValueError("degenerate cell in mesh")
+        flip = det < 0
+        if flip.any():
+            cells = cells.copy()
+            cells[flip, 1], cells[flip, 2] = cells[flip, 2].copy(), cells[flip, 1].copy()
+        self.cells = cells
+        self.x = x
+        self.name = name
+        self.comm = comm or _SerialComm()
+        self.topology = _Topology(self)
+        self.geometry = _Geometry(self)
+        self._build_facets()
+
+    @property
+    def num_vertices(self):
+        return self.x.shape[0]
+
+    @property
+    def num_cells(self):
+        return self.cells.shape[0]
+
+    def _build_facets(self):
+        c = self.cells
+        nc = c.shape[0]
+        # local facet i is opposite local vertex i: vertices (i+1, i+2)
+        e = np.stack([c[:, [1, 2]], c[:, [2, 0]], c[:, [0, 1]]], axis=1).reshape(-1, 2)
+        es = np.sort(e, axis=1).astype(np.int64)
+        key = es[:, 0] * (self.num_vertices + 1) + es[:, 1]
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        first = np.ones(len(ks), bool)
+        first[1:] = ks[1:] != ks[:-1]
+        last = np.ones(len(ks), bool)
+        last[:-1] = ks[1:] != ks[:-1]
+        single = order[first & last]
+        single.sort()
+        self.facet_cells = (single // 3).astype(np.int32)
+        self.facet_local = (single % 3).astype(np.int32)
+        self.facet_vertices = e[single].astype(np.int32)
+        self.facet_marker = np.zeros(len(single), dtype=np.int32)
+        assert nc > 0
+
+    @property
+    def num_facets(self):
+        return len(self.facet_cells)
+
+    def facet_midpoints(self):
+        fv = self.facet_vertices
+        return 0.5 * (self.x[fv[:, 0]] + self.x[fv[:, 1]])
+
+    def h(self, dim=2, entities=None):
+        """Greatest vertex-vertex distance per cell (DOLFINx `mesh.h`;
+        used at /root/reference/src/solvers/stabilized_schur.py:85-88)."""
+        c = self.cells if entities is None else self.cells[np.asarray(entities)]
+        p = self.x[c]
+        d01 = np.linalg.norm(p[:, 0] - p[:, 1], axis=1)
+        d12 = np.linalg.norm(p[:, 1] - p[:, 2], axis=1)
+        d20 = np.linalg.norm(p[:, 2] - p[:, 0], axis=1)
+        return np.maximum(d01, np.maximum(d12, d20))
+
+    def cell_areas(self):
+        p = self.x[self.cells]
+        return 0.5 * np.abs(
+            (p[:, 1, 0] - p[:, 0, 0]) * (p[:, 2, 1] - p[:, 0, 1])
+            - (p[:, 1, 1] - p[:, 0, 1]) * (p[:, 2, 0] - p[:, 0, 0])
+        )
+
+    def set_facet_markers(self, facets, values):
+        self.facet_marker[np.asarray(facets, dtype=np.int64)] = np.asarray(values, dtype=np.int32)
+
+
+class MeshTags:
+    """Facet tags with the `find(marker)` the scenarios use
+    (/root/reference/src/scenarios/dfg_1.py:61)."""
+
+    def __init__(self, mesh, dim, indices, values, name="Facet markers"):
+        self.mesh = mesh
+        self.dim = dim
+        self.indices = np.asarray(indices, dtype=np.int32)
+        self.values = np.asarray(values, dtype=np.int32)
+        self.name = name
+        mesh.set_facet_markers(self.indices, self.values)
+
+    def find(self, value):
+        return self.indices[self.values == value]
+
+
+def meshtags(mesh, dim, indices, values):
+    return MeshTags(mesh, dim, indices, values)
+
+
+def locate_entities_boundary(mesh, dim, marker):
+    """Exterior facets ALL of whose vertices satisfy `marker(x[3,n])`
+    (DOLFINx rule)."""
+    assert dim == mesh.topology.dim - 1
+    X = mesh.geometry.x.T  # [3,nv]
+    ok = np.asarray(marker(X), dtype=bool)
+    fv = mesh.facet_vertices
+    sel = ok[fv[:, 0]] & ok[fv[:, 1]]
+    return np.nonzero(sel)[0].astype(np.int32)
+
+
+# --------------------------------------------------------------------------
+# generators
+# --------------------------------------------------------------------------
+
+def _split_quads(x, quads):
+    """Split quads (v00,v10,v11,v01) along the shorter diagonal (ties: 00-11)."""
+    q = np.asarray(quads, dtype=np.int64)
+    d0 = np.linalg.norm(x[q[:, 0]] - x[q[:, 2]], axis=1)
+    d1 = np.linalg.norm(x[q[:, 1]] - x[q[:, 3]], axis=1)
+    use0 = d0 <= d1 * (1.0 + 1e-12)
+    t = np.empty((len(q), 2, 3), dtype=np.int64)
+    # diagonal 00-11
+    t[use0, 0] = q[use0][:, [0, 1, 2]]
+    t[use0, 1] = q[use0][:, [0, 2, 3]]
+    # diagonal 10-01
+    n0 = ~use0
+    t[n0, 0] = q[n0][:, [0, 1, 3]]
+    t[n0, 1] = q[n0][:, [1, 2, 3]]
+    return t.reshape(-1, 3)
+
+
+def create_unit_square(nx, ny=None, comm=None):
+    """Unit square, nx*ny squares each split along (i,j)-(i+1,j+1)
+    (DOLFINx `create_unit_square` default diagonal "right";
+    /root/reference/src/scenarios/lid_driven2D.py:29)."""
+    ny = nx if ny is None else ny
+    xs = np.linspace(0.0, 1.0, nx + 1)
+    ys = np.linspace(0.0, 1.0, ny + 1)
+    X, Y = np.meshgrid(xs, ys, indexing="xy")  # row-major in y
+    x = np.stack([X.ravel(), Y.ravel()], axis=1)
+    j, i = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    v0 = (j * (nx + 1) + i).ravel()
+    v1 = v0 + 1
+    v2 = v0 + (nx + 1)
+    v3 = v2 + 1
+    cells = np.empty((2 * nx * ny, 3), dtype=np.int64)
+    cells[0::2] = np.stack([v0, v1, v3], axis=1)
+    cells[1::2] = np.stack([v0, v2, v3], axis=1)
+    return Mesh(cells, x, comm=comm, name="unit_square")
+
+
+DFG_L = 2.2
+DFG_H = 0.41
+DFG_C = (0.2, 0.2)
+DFG_R = 0.05
+
+
+def create_dfg_channel(m, comm=None):
+    """DFG 2D-1 domain [0,2.2]x[0,0.41] minus the disk c=(0.2,0.2), r=0.05
+    (geometry of /root/reference/src/scenarios/dfg_1.py:97-110), meshed by an
+    own deterministic block generator (gmsh is not available):
+
+      * an O-grid of 4m x m quads between the cylinder and the box
+        [0,0.41]^2, radially graded (ratio ~5.2 between outer and inner
+        spacing, mirroring the reference's LcMin=r/6 ... LcMax=H/13 grading,
+        dfg_1.py:146-155), and
+      * a uniform block of nx x m quads for x in [0.41, 2.2],
+
+    every quad split along its shorter diagonal.  Nv ~ 8.4 m^2:
+    m=18 -> ~2.7k vertices (C1, ~8k DOF); m=200 -> ~336k vertices (C3, ~1M DOF).
+
+    Returns (mesh, facet_tags) with the reference's markers
+    inlet=2, outlet=3, wall=4, obstacle=5 (dfg_1.py:18-22).
+    """
+    m = int(m)
+    assert m >= 4
+    L, H, r = DFG_L, DFG_H, DFG_R
+    cx, cy = DFG_C
+    xb = H  # box [0,xb]x[0,H] around the cylinder
+    t = np.arange(m) / m
+    zeros = np.zeros(m)
+    # box boundary, counter-clockwise from (0,0): bottom, right, top, left
+    S = np.concatenate(
+        [
+            np.stack([xb * t, zeros], 1),
+            np.stack([xb + zeros, H * t], 1),
+            np.stack([xb * (1 - t), H + zeros], 1),
+            np.stack([zeros, H * (1 - t)], 1),
+        ]
+    )
+    d = S - np.array([cx, cy])
+    C = np.array([cx, cy]) + r * d / np.linalg.norm(d, axis=1)[:, None]
+    nr = m
+    q = 5.2 ** (1.0 / (nr - 1))
+    s = (q ** np.arange(nr + 1) - 1.0) / (q**nr - 1.0)
+    s[-1] = 1.0
+    nk = 4 * m
+    # O-grid vertices: id = k*(nr+1)+j
+    P = C[:, None, :] + s[None, :, None] * (S - C)[:, None, :]
+    # snap the outer ring exactly onto the box
+    P[:, nr, :] = S
+    xo = P.reshape(-1, 2)
+    k = np.arange(nk)
+    kp = (k + 1) % nk
+    jj = np.arange(nr)
+    K, J = np.meshgrid(k, jj, indexing="ij")
+    KP = np.meshgrid(kp, jj, indexing="ij")[0]
+    q_o = np.stack(
+        [
+            (K * (nr + 1) + J).ravel(),
+            (K * (nr + 1) + J + 1).ravel(),
+            (KP * (nr + 1) + J + 1).ravel(),
+            (KP * (nr + 1) + J).ravel(),
+        ],
+        axis=1,
+    )
+    # channel block
+    nx = int(round((L - xb) / (H / m)))
+    n_o = xo.shape[0]
+    xi = xb + (L - xb) * np.arange(1, nx + 1) / nx
+    yj = H * np.arange(m + 1) / m
+    XI, YJ = np.meshgrid(xi, yj, indexing="ij")
+    xc = np.stack([XI.ravel(), YJ.ravel()], axis=1)  # id = n_o + (i-1)*(m+1)+j
+
+    def col0(j):
+        # vertex on x=xb at y=H*j/m: O-grid outer ring, side 1 (k=m+j), j=m -> k=2m
+        return (m + j) * (nr + 1) + nr
+
+    def cid(i, j):
+        if i == 0:
+            return col0(j)
+        return n_o + (i - 1) * (m + 1) + j
+
+    ii, jj2 = np.meshgrid(np.arange(nx), np.arange(m), indexing="ij")
+    ii = ii.ravel()
+    jj2 = jj2.ravel()
+    cidv = np.vectorize(cid)
+    q_c = np.stack([cidv(ii, jj2), cidv(ii + 1, jj2), cidv(ii + 1, jj2 + 1), cidv(ii, jj2 + 1)], axis=1)
+    x = np.concatenate([xo, xc])
+    cells = _split_quads(x, np.concatenate([q_o, q_c]))
+    mesh = Mesh(cells, x, comm=comm, name="Grid")
+    mid = mesh.facet_midpoints()
+    tol = 1e-9
+    marker = np.full(mesh.num_facets, 5, dtype=np.int32)  # obstacle by default
+    marker[np.abs(mid[:, 0]) < tol] = 2
+    marker[np.abs(mid[:, 0] - L) < tol] = 3
+    marker[(np.abs(mid[:, 1]) < tol) | (np.abs(mid[:, 1] - H) < tol)] = 4
+    ft = MeshTags(mesh, 1, np.arange(mesh.num_facets, dtype=np.int32), marker)
+    return mesh, ft
+
+
+def create_stenosis_channel(ny, L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, severity=0.5,
+                            half_len=None, comm=None):
+    """2-D stenosed channel 0<=x<=L, walls y = R_in +- R(x): a symmetric
+    cosine-shaped narrowing of relative depth `severity` centred at x_sten and
+    a linear taper from R_in to R_out over the whole length (a y-profile
+    reduction of the Bezier walls of /root/reference/src/scenarios/stenosis.py:27-69;
+    the exact CAD outline is out of scope).
+
+    Structured ny cells across, uniform aspect ~1 in x, shorter-diagonal split.
+    Markers: inlet=1 (x=0), outlet=2 (x=L), wall=3.
+    """
+    ny = int(ny)
+    if half_len is None:
+        half_len = 2.0 * R_in / 0.3 * severity  # slope parameter ~0.3 of the reference
+    hx = 2.0 * R_in / ny
+    nx = int(round(L / hx))
+    xs = np.linspace(0.0, L, nx + 1)
+    Rx = R_in + (R_out - R_in) * xs / L
+    bump = np.where(np.abs(xs - x_sten) < half_len,
+                    0.5 * severity * (1.0 + np.cos(np.pi * (xs - x_sten) / half_len)), 0.0)
+    Rx = Rx * (1.0 - bump)
+    eta = np.linspace(-1.0, 1.0, ny + 1)
+    X = np.repeat(xs[:, None], ny + 1, axis=1)
+    Y = R_in + Rx[:, None] * eta[None, :]
+    x = np.stack([X.ravel(), Y.ravel()], axis=1)
+    i, j = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    v0 = (i * (ny + 1) + j).ravel()
+    quads = np.stack([v0, v0 + (ny + 1), v0 + (ny + 1) + 1, v0 + 1], axis=1)
+    cells = _split_quads(x, quads)
+    mesh = Mesh(cells, x, comm=comm, name="stenosis")
+    mid = mesh.facet_midpoints()
+    marker = np.full(mesh.num_facets, 3, dtype=np.int32)
+    marker[np.abs(mid[:, 0]) < 1e-9] = 1
+    marker[np.abs(mid[:, 0] - L) < 1e-9] = 2
+    ft = MeshTags(mesh, 1, np.arange(mesh.num_facets, dtype=np.int32), marker)
+    return mesh, ft

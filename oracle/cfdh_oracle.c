@@ -1,0 +1,954 @@
+/*
+ * cfdh_oracle.c -- CPU restatement of the reference's per-time-step path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may build, load or call this file.  The
+ * product (libcfdh.so, HIP) never links or calls it.
+ *
+ * PARITY UNPINNED.  The reference's arithmetic lives in un-vendored third-party
+ * code (fenics-dolfinx 0.9.0 / UFL 2024.2 / Basix 0.9 / FFCx 0.9 and the
+ * PETSc+MPICH of the image dolfinx/dolfinx:v0.9.0, /root/reference/singularity.def:2)
+ * which can neither be built nor imported in this container, and the reference
+ * holds no test, fixture or recorded output for this path.
+ * This file restates the published algorithm of those call sites and is
+ * pinned only by the substitutes listed in DESIGN.md ("Oracle"): the NumPy
+ * twin with a direct solver (oracle/np_twin.py), Jacobian = d(residual) finite
+ * differences, a brute-force quadrature of the weak form, patch tests,
+ * Poiseuille flow and the Ghia / DFG literature values.
+ *
+ * What is restated (2-D affine P1/P1 triangles, IEEE double, int32 indices):
+ *   element residual   /root/reference/src/solvers/stabilized_schur.py:67-123
+ *   element Jacobian   stabilized_schur.py:185-189 (exact Gateaux derivative)
+ *   block assembly, Dirichlet rows/cols, lifting (x0=x, alpha=-1)
+ *                      stabilized_schur.py:144-175
+ *   Newton (SNES newtonls, bt line search) + FGMRES(200) + PCFIELDSPLIT Schur
+ *   FULL / SELFP with GMRES(30)+ILU(0) on A00 and preonly+ILU(0) on
+ *   Sp = A11 - A10 diag(A00)^-1 A01       stabilized_schur.py:201-275
+ *   (single rank: PCASM with one subdomain per rank == ILU(0) of the block)
+ *   constant-pressure null space           stabilized_schur.py:282-293,314-319
+ *   functionals                            /root/reference/src/scenarios/dfg_1.py:183-202,
+ *                                          /root/reference/src/scenario.py:315-324
+ * Algebra of the closed-form element integrals: SURVEY.md Appendix A.
+ *
+ * Monolithic ordering (stabilized_schur.py:194-196): all velocity dofs
+ * (vertex-major, component-minor), then all pressure dofs.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "quad_tri.h"
+
+#define EPS_VNORM 1e-15 /* np.finfo(float64).resolution, stabilized_schur.py:100 */
+
+typedef struct {
+  int n;
+  int *rowptr, *col;
+  double *val;
+  int *diag;
+} csr_t;
+
+typedef struct orc_ctx {
+  int nv, nc, nf, ndof;
+  int *cells;   /* [nc][3] */
+  double *x;    /* [nv][2] */
+  uint8_t *fflag; /* [nc] bit f: facet opposite local vertex f is exterior */
+  int *fcell, *flocal;
+  double dt, rho, mu, muf, f[2];
+  uint8_t *isbc;
+  double *bcval, *bcmult;
+  int any_pbc;
+  /* vertex graph */
+  int *vptr, *vadj;       /* neighbours incl. self, sorted */
+  int *vcptr, *vcell;     /* vertex -> incident cells (cell*3+local) */
+  /* monolithic CSR */
+  int *rowptr, *col;
+  double *val;
+  int nnz;
+  int *cellpos;           /* [nc][9]: index of neighbour b in row of vertex a */
+  /* per-step data */
+  double *un;             /* [nv][2] */
+  double *Mom;            /* [nc][7]: M00 M01 M02 M11 M12 M22 L */
+  double *Fe, *Je;        /* [nc][9], [nc][81] scratch */
+  /* solver workspace (lazily allocated) */
+  csr_t A00f, Sp;         /* ILU factors */
+  int *sp_rowptr, *sp_col;
+  int nthreads;
+  char err[256];
+} orc_ctx;
+
+typedef struct {
+  double snes_rtol, snes_atol, snes_stol;
+  int snes_max_it;
+  double ksp_rtol, ksp_atol;
+  int ksp_max_it, ksp_restart;
+  double sub_rtol; /* inner GMRES(30) on A00 */
+  int sub_max_it, sub_restart;
+  int remove_p_mean; /* nullsp.remove(x_n), stabilized_schur.py:319 */
+  int verbose;
+} orc_opts;
+
+typedef struct {
+  int newton_its, krylov_its, reason, sub_its;
+  double fnorm0, fnorm;
+  double ms_assemble, ms_solve;
+} orc_stats;
+
+static double now_ms(void) {
+#ifdef _OPENMP
+  return omp_get_wtime() * 1e3;
+#else
+  return 0.0;
+#endif
+}
+
+/* ------------------------------------------------------------------ element */
+
+static void geom(const double xe[3][2], double g[3][2], double *area, double *h) {
+  double x0 = xe[0][0], y0 = xe[0][1], x1 = xe[1][0], y1 = xe[1][1], x2 = xe[2][0], y2 = xe[2][1];
+  double det = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0);
+  g[0][0] = (y1 - y2) / det; g[0][1] = (x2 - x1) / det;
+  g[1][0] = (y2 - y0) / det; g[1][1] = (x0 - x2) / det;
+  g[2][0] = (y0 - y1) / det; g[2][1] = (x1 - x0) / det;
+  *area = 0.5 * fabs(det);
+  double d01 = hypot(x0 - x1, y0 - y1), d12 = hypot(x1 - x2, y1 - y2), d20 = hypot(x2 - x0, y2 - y0);
+  *h = fmax(d01, fmax(d12, d20));
+}
+
+/* M_ab = int tau l_a l_b (6 packed), L = int tau_L; stabilized_schur.py:100-118 */
+static void moments(const double une[3][2], double area, double h, double dt, double nu, double mom[7]) {
+  double t2 = 4.0 / (dt * dt), t3 = 16.0 * nu * nu / (h * h * h * h), ih2 = 1.0 / (h * h);
+  double m[6] = {0, 0, 0, 0, 0, 0}, L = 0;
+  for (int q = 0; q < CFDH_NQ; q++) {
+    const double *l = CFDH_QL[q];
+    double ux = l[0] * une[0][0] + l[1] * une[1][0] + l[2] * une[2][0];
+    double uy = l[0] * une[0][1] + l[1] * une[1][1] + l[2] * une[2][1];
+    double s = ux * ux + uy * uy;
+    double t1 = fmax(4.0 * s, EPS_VNORM * EPS_VNORM) * ih2;
+    double tau = 1.0 / sqrt(t1 + t2 + t3);
+    double vn = sqrt(s);
+    double Re = vn * h / (2.0 * nu);
+    double z = (Re <= 3.0) ? Re / 3.0 : 1.0;
+    double tl = vn * h * z * 0.5;
+    double w = CFDH_QW[q] * tau;
+    m[0] += w * l[0] * l[0]; m[1] += w * l[0] * l[1]; m[2] += w * l[0] * l[2];
+    m[3] += w * l[1] * l[1]; m[4] += w * l[1] * l[2]; m[5] += w * l[2] * l[2];
+    L += CFDH_QW[q] * tl;
+  }
+  for (int k = 0; k < 6; k++) mom[k] = area * m[k];
+  mom[6] = area * L;
+}
+
+/* Element residual Fe[9] / Jacobian Je[9][9]; local order (a,i)->2a+i, p_a->6+a. */
+static void element(const orc_ctx *c, const double xe[3][2], const double ue[3][2], const double une[3][2],
+                    const double pe[3], const double mom[7], int fflag, double Fe[9], double *Je /*81 or NULL*/) {
+  const double rho = c->rho, mu = c->mu, dt = c->dt, muf = c->muf;
+  double g[3][2], area, h;
+  geom(xe, g, &area, &h);
+  double M[3][3] = {{mom[0], mom[1], mom[2]}, {mom[1], mom[3], mom[4]}, {mom[2], mom[4], mom[5]}};
+  double Lm = mom[6];
+  double ub[3][2], w[3][2], G[2][2] = {{0, 0}, {0, 0}}, gp[2] = {0, 0};
+  for (int a = 0; a < 3; a++)
+    for (int i = 0; i < 2; i++) {
+      ub[a][i] = 0.5 * (ue[a][i] + une[a][i]);
+      w[a][i] = (ue[a][i] - une[a][i]) / dt;
+    }
+  for (int a = 0; a < 3; a++)
+    for (int i = 0; i < 2; i++) {
+      gp[i] += pe[a] * g[a][i];
+      for (int j = 0; j < 2; j++) G[i][j] += g[a][i] * ub[a][j];
+    }
+  double divu = G[0][0] + G[1][1];
+  double Cn[3][2], R[3][2], beta[3][3], mab[3][3], mt[3], T = 0, Q[3][2];
+  for (int a = 0; a < 3; a++)
+    for (int j = 0; j < 2; j++) {
+      Cn[a][j] = ub[a][0] * G[0][j] + ub[a][1] * G[1][j];
+      R[a][j] = rho * (w[a][j] + Cn[a][j]) + gp[j] - rho * c->f[j];
+    }
+  for (int d = 0; d < 3; d++)
+    for (int a = 0; a < 3; a++) {
+      beta[d][a] = ub[d][0] * g[a][0] + ub[d][1] * g[a][1];
+      mab[d][a] = area * (d == a ? 2.0 : 1.0) / 12.0;
+    }
+  for (int b = 0; b < 3; b++) { mt[b] = M[b][0] + M[b][1] + M[b][2]; T += mt[b]; }
+  for (int d = 0; d < 3; d++)
+    for (int i = 0; i < 2; i++) Q[d][i] = M[0][d] * R[0][i] + M[1][d] * R[1][i] + M[2][d] * R[2][i];
+  double E[2][2] = {{G[0][0], 0.5 * (G[0][1] + G[1][0])}, {0.5 * (G[0][1] + G[1][0]), G[1][1]}};
+  double pbar = (pe[0] + pe[1] + pe[2]) / 3.0;
+  for (int a = 0; a < 3; a++) {
+    for (int i = 0; i < 2; i++) {
+      double v = 0;
+      for (int b = 0; b < 3; b++) v += rho * mab[a][b] * (w[b][i] + Cn[b][i]);
+      v -= rho * c->f[i] * area / 3.0;
+      v += area * (2.0 * mu * (E[i][0] * g[a][0] + E[i][1] * g[a][1]) - pbar * g[a][i]);
+      for (int d = 0; d < 3; d++) v += beta[d][a] * Q[d][i];
+      v += rho * Lm * divu * g[a][i];
+      Fe[2 * a + i] = v;
+    }
+    double v = area / 3.0 * divu;
+    for (int b = 0; b < 3; b++) v += mt[b] * (R[b][0] * g[a][0] + R[b][1] * g[a][1]) / rho;
+    Fe[6 + a] = v;
+  }
+  if (Je) {
+    double MB[3][3], BMB[3][3], mB[3][3], mtB[3], gg[3][3];
+    for (int b = 0; b < 3; b++)
+      for (int a = 0; a < 3; a++) {
+        MB[b][a] = M[b][0] * beta[0][a] + M[b][1] * beta[1][a] + M[b][2] * beta[2][a];
+        mB[a][b] = mab[a][0] * beta[0][b] + mab[a][1] * beta[1][b] + mab[a][2] * beta[2][b];
+        gg[a][b] = g[a][0] * g[b][0] + g[a][1] * g[b][1];
+      }
+    for (int b = 0; b < 3; b++)
+      for (int a = 0; a < 3; a++) BMB[b][a] = beta[0][b] * MB[0][a] + beta[1][b] * MB[1][a] + beta[2][b] * MB[2][a];
+    for (int a = 0; a < 3; a++) mtB[a] = mt[0] * beta[0][a] + mt[1] * beta[1][a] + mt[2] * beta[2][a];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        for (int i = 0; i < 2; i++) {
+          for (int j = 0; j < 2; j++) {
+            double dij = (i == j) ? 1.0 : 0.0;
+            double v = rho * mab[a][b] * dij / dt;
+            v += rho * 0.5 * (mab[a][b] * G[j][i] + dij * mB[a][b]);
+            v += area * mu * 0.5 * (g[b][i] * g[a][j] + gg[a][b] * dij);
+            v += rho * ((dij / dt + 0.5 * G[j][i]) * MB[b][a] + 0.5 * dij * BMB[b][a]);
+            v += 0.5 * g[a][j] * Q[b][i];
+            v += rho * Lm * 0.5 * g[b][j] * g[a][i];
+            Je[(2 * a + i) * 9 + 2 * b + j] = v;
+          }
+          Je[(2 * a + i) * 9 + 6 + b] = -area / 3.0 * g[a][i] + g[b][i] * mtB[a];
+        }
+        for (int j = 0; j < 2; j++) {
+          double Gg = G[j][0] * g[a][0] + G[j][1] * g[a][1];
+          double v = area / 3.0 * 0.5 * g[b][j];
+          v += mt[b] * (g[a][j] / dt + 0.5 * Gg);
+          v += 0.5 * g[a][j] * mtB[b];
+          Je[(6 + a) * 9 + 2 * b + j] = v;
+        }
+        Je[(6 + a) * 9 + 6 + b] = T * gg[a][b] / rho;
+      }
+  }
+  /* exterior facets: + oint p n.v - oint mu_f (nabla_grad(ubar) n).v   (stabilized_schur.py:79) */
+  for (int f = 0; f < 3; f++) {
+    if (!((fflag >> f) & 1)) continue;
+    double gl = hypot(g[f][0], g[f][1]);
+    double n[2] = {-g[f][0] / gl, -g[f][1] / gl};
+    double elen = 2.0 * area * gl;
+    double Gn[2] = {G[0][0] * n[0] + G[0][1] * n[1], G[1][0] * n[0] + G[1][1] * n[1]};
+    int ev[2] = {(f + 1) % 3, (f + 2) % 3};
+    for (int ka = 0; ka < 2; ka++) {
+      int a = ev[ka];
+      double pint = 0;
+      for (int kb = 0; kb < 2; kb++) pint += pe[ev[kb]] * (ev[kb] == a ? 2.0 : 1.0) / 6.0;
+      for (int i = 0; i < 2; i++) {
+        Fe[2 * a + i] += n[i] * elen * pint - muf * Gn[i] * elen * 0.5;
+        if (Je) {
+          for (int kb = 0; kb < 2; kb++) {
+            int b = ev[kb];
+            Je[(2 * a + i) * 9 + 6 + b] += n[i] * elen * (a == b ? 2.0 : 1.0) / 6.0;
+          }
+          for (int b = 0; b < 3; b++)
+            for (int j = 0; j < 2; j++) Je[(2 * a + i) * 9 + 2 * b + j] -= muf * 0.5 * g[b][i] * n[j] * elen * 0.5;
+        }
+      }
+    }
+  }
+}
+
+/* exported for unit tests: one element, moments computed here */
+void orc_element(double dt, double rho, double mu, double muf, const double *f, const double *xe, const double *ue,
+                 const double *une, const double *pe, int fflag, double *Fe, double *Je) {
+  orc_ctx c;
+  memset(&c, 0, sizeof c);
+  c.dt = dt; c.rho = rho; c.mu = mu; c.muf = muf; c.f[0] = f[0]; c.f[1] = f[1];
+  double g[3][2], area, h, mom[7];
+  geom((const double(*)[2])xe, g, &area, &h);
+  moments((const double(*)[2])une, area, h, dt, mu / rho, mom);
+  element(&c, (const double(*)[2])xe, (const double(*)[2])ue, (const double(*)[2])une, pe, mom, fflag, Fe, Je);
+}
+
+/* ------------------------------------------------------------------ setup */
+
+static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b); }
+
+orc_ctx *orc_create(int nv, int nc, const int *cells, const double *x, int nf, const int *fcell, const int *flocal) {
+  orc_ctx *c = (orc_ctx *)calloc(1, sizeof *c);
+  c->nv = nv; c->nc = nc; c->nf = nf; c->ndof = 3 * nv;
+  c->cells = (int *)malloc(sizeof(int) * 3 * nc); memcpy(c->cells, cells, sizeof(int) * 3 * nc);
+  c->x = (double *)malloc(sizeof(double) * 2 * nv); memcpy(c->x, x, sizeof(double) * 2 * nv);
+  c->fflag = (uint8_t *)calloc(nc, 1);
+  c->fcell = (int *)malloc(sizeof(int) * (nf + 1)); c->flocal = (int *)malloc(sizeof(int) * (nf + 1));
+  for (int k = 0; k < nf; k++) { c->fcell[k] = fcell[k]; c->flocal[k] = flocal[k]; c->fflag[fcell[k]] |= (uint8_t)(1u << flocal[k]); }
+  c->isbc = (uint8_t *)calloc(c->ndof, 1);
+  c->bcval = (double *)calloc(c->ndof, sizeof(double));
+  c->bcmult = (double *)calloc(c->ndof, sizeof(double));
+  c->un = (double *)calloc(2 * nv, sizeof(double));
+  c->Mom = (double *)calloc((size_t)7 * nc, sizeof(double));
+  c->Fe = (double *)malloc(sizeof(double) * 9 * (size_t)nc);
+  c->Je = (double *)malloc(sizeof(double) * 81 * (size_t)nc);
+  c->rho = 1; c->mu = 1; c->muf = 1; c->dt = 1;
+#ifdef _OPENMP
+  c->nthreads = omp_get_max_threads();
+#else
+  c->nthreads = 1;
+#endif
+  /* vertex -> cells */
+  c->vcptr = (int *)calloc(nv + 1, sizeof(int));
+  for (int k = 0; k < 3 * nc; k++) c->vcptr[c->cells[k] + 1]++;
+  for (int v = 0; v < nv; v++) c->vcptr[v + 1] += c->vcptr[v];
+  c->vcell = (int *)malloc(sizeof(int) * 3 * nc);
+  int *fill = (int *)calloc(nv, sizeof(int));
+  for (int k = 0; k < 3 * nc; k++) { int v = c->cells[k]; c->vcell[c->vcptr[v] + fill[v]++] = k; }
+  free(fill);
+  /* vertex graph (neighbours incl. self, sorted) */
+  c->vptr = (int *)calloc(nv + 1, sizeof(int));
+  int *tmp = (int *)malloc(sizeof(int) * (3 * 64 + 8));
+  int cap = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    for (int v = 0; v < nv; v++) {
+      int n = 0;
+      int deg = c->vcptr[v + 1] - c->vcptr[v];
+      if (3 * deg + 1 > cap) { cap = 3 * deg + 64; tmp = (int *)realloc(tmp, sizeof(int) * cap); }
+      tmp[n++] = v;
+      for (int k = c->vcptr[v]; k < c->vcptr[v + 1]; k++) {
+        int cell = c->vcell[k] / 3;
+        for (int a = 0; a < 3; a++) tmp[n++] = c->cells[3 * cell + a];
+      }
+      qsort(tmp, n, sizeof(int), cmp_int);
+      int m = 0;
+      for (int k = 0; k < n; k++) if (k == 0 || tmp[k] != tmp[k - 1]) tmp[m++] = tmp[k];
+      if (pass == 0) c->vptr[v + 1] = c->vptr[v] + m;
+      else memcpy(c->vadj + c->vptr[v], tmp, sizeof(int) * m);
+    }
+    if (pass == 0) c->vadj = (int *)malloc(sizeof(int) * c->vptr[nv]);
+  }
+  free(tmp);
+  /* monolithic CSR: row of dof has [2*w+j for w in N(v)] then [2nv+w] */
+  int nu = 2 * nv;
+  c->rowptr = (int *)malloc(sizeof(int) * (c->ndof + 1));
+  c->rowptr[0] = 0;
+  for (int r = 0; r < c->ndof; r++) {
+    int v = r < nu ? r / 2 : r - nu;
+    c->rowptr[r + 1] = c->rowptr[r] + 3 * (c->vptr[v + 1] - c->vptr[v]);
+  }
+  c->nnz = c->rowptr[c->ndof];
+  c->col = (int *)malloc(sizeof(int) * c->nnz);
+  c->val = (double *)calloc(c->nnz, sizeof(double));
+  for (int r = 0; r < c->ndof; r++) {
+    int v = r < nu ? r / 2 : r - nu;
+    int deg = c->vptr[v + 1] - c->vptr[v];
+    int *cc = c->col + c->rowptr[r];
+    for (int k = 0; k < deg; k++) {
+      int w = c->vadj[c->vptr[v] + k];
+      cc[2 * k] = 2 * w; cc[2 * k + 1] = 2 * w + 1; cc[2 * deg + k] = nu + w;
+    }
+  }
+  c->cellpos = (int *)malloc(sizeof(int) * 9 * (size_t)nc);
+  for (int e = 0; e < nc; e++)
+    for (int a = 0; a < 3; a++) {
+      int va = c->cells[3 * e + a];
+      for (int b = 0; b < 3; b++) {
+        int vb = c->cells[3 * e + b];
+        int *base = c->vadj + c->vptr[va];
+        int deg = c->vptr[va + 1] - c->vptr[va];
+        int *p = (int *)bsearch(&vb, base, deg, sizeof(int), cmp_int);
+        c->cellpos[9 * e + 3 * a + b] = (int)(p - base);
+      }
+    }
+  return c;
+}
+
+static void free_csr(csr_t *m) { free(m->rowptr); free(m->col); free(m->val); free(m->diag); memset(m, 0, sizeof *m); }
+
+void orc_destroy(orc_ctx *c) {
+  if (!c) return;
+  free(c->cells); free(c->x); free(c->fflag); free(c->fcell); free(c->flocal); free(c->isbc); free(c->bcval);
+  free(c->bcmult); free(c->un); free(c->Mom); free(c->Fe); free(c->Je); free(c->vcptr); free(c->vcell);
+  free(c->vptr); free(c->vadj); free(c->rowptr); free(c->col); free(c->val); free(c->cellpos);
+  free_csr(&c->A00f); free_csr(&c->Sp); free(c->sp_rowptr); free(c->sp_col);
+  free(c);
+}
+
+void orc_set_params(orc_ctx *c, double dt, double rho, double mu, double muf, const double *f) {
+  c->dt = dt; c->rho = rho; c->mu = mu; c->muf = muf; c->f[0] = f[0]; c->f[1] = f[1];
+}
+void orc_set_threads(orc_ctx *c, int n) {
+#ifdef _OPENMP
+  if (n > 0) { omp_set_num_threads(n); c->nthreads = n; }
+#else
+  (void)c; (void)n;
+#endif
+}
+int orc_get_threads(orc_ctx *c) { return c->nthreads; }
+
+void orc_clear_bcs(orc_ctx *c) {
+  memset(c->isbc, 0, c->ndof); memset(c->bcval, 0, sizeof(double) * c->ndof); memset(c->bcmult, 0, sizeof(double) * c->ndof);
+  c->any_pbc = 0;
+}
+/* one DirichletBC object; field 0: velocity (values [n][2]), 1: pressure (values [n]).
+ * Later objects overwrite the value; the diagonal counts the objects. */
+void orc_add_bc(orc_ctx *c, int field, int n, const int *nodes, const double *vals) {
+  for (int k = 0; k < n; k++) {
+    if (field == 0) {
+      for (int i = 0; i < 2; i++) { int d = 2 * nodes[k] + i; c->isbc[d] = 1; c->bcval[d] = vals[2 * k + i]; c->bcmult[d] += 1.0; }
+    } else {
+      int d = 2 * c->nv + nodes[k]; c->isbc[d] = 1; c->bcval[d] = vals[k]; c->bcmult[d] += 1.0; c->any_pbc = 1;
+    }
+  }
+}
+
+/* u_prev for the step; refreshes the tau moments (they depend on u_prev only) */
+void orc_set_un(orc_ctx *c, const double *un) {
+  memcpy(c->un, un, sizeof(double) * 2 * c->nv);
+  double nu = c->mu / c->rho;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < c->nc; e++) {
+    double xe[3][2], une[3][2], g[3][2], area, h;
+    for (int a = 0; a < 3; a++) {
+      int v = c->cells[3 * e + a];
+      xe[a][0] = c->x[2 * v]; xe[a][1] = c->x[2 * v + 1];
+      une[a][0] = c->un[2 * v]; une[a][1] = c->un[2 * v + 1];
+    }
+    geom(xe, g, &area, &h);
+    moments(une, area, h, c->dt, nu, c->Mom + 7 * (size_t)e);
+  }
+}
+
+/* ------------------------------------------------------------------ assembly */
+
+/* F (always) and the CSR values (want_jac) at monolithic state xv.
+ * Dirichlet semantics of assemble_vector_block(F, F_form, J_form, bcs, x0=x, alpha=-1)
+ * and assemble_matrix_block(J, J_form, bcs): stabilized_schur.py:144-175. */
+void orc_assemble(orc_ctx *c, const double *xv, int want_jac, double *F) {
+  const int nv = c->nv, nu = 2 * nv, nc = c->nc;
+  int any_lift = 0;
+  for (int d = 0; d < c->ndof && !any_lift; d++)
+    if (c->isbc[d] && c->bcval[d] != xv[d]) any_lift = 1;
+  const int need_j = want_jac || any_lift;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < nc; e++) {
+    double xe[3][2], ue[3][2], une[3][2], pe[3];
+    int ld[9];
+    for (int a = 0; a < 3; a++) {
+      int v = c->cells[3 * e + a];
+      xe[a][0] = c->x[2 * v]; xe[a][1] = c->x[2 * v + 1];
+      ue[a][0] = xv[2 * v]; ue[a][1] = xv[2 * v + 1];
+      une[a][0] = c->un[2 * v]; une[a][1] = c->un[2 * v + 1];
+      pe[a] = xv[nu + v];
+      ld[2 * a] = 2 * v; ld[2 * a + 1] = 2 * v + 1; ld[6 + a] = nu + v;
+    }
+    double *Fe = c->Fe + 9 * (size_t)e, *Je = c->Je + 81 * (size_t)e;
+    element(c, xe, ue, une, pe, c->Mom + 7 * (size_t)e, c->fflag[e], Fe, need_j ? Je : NULL);
+    int anybc = 0;
+    for (int k = 0; k < 9; k++) anybc |= c->isbc[ld[k]];
+    if (anybc) {
+      if (any_lift)
+        for (int k = 0; k < 9; k++)
+          if (c->isbc[ld[k]]) {
+            double gx = c->bcval[ld[k]] - xv[ld[k]];
+            if (gx != 0.0)
+              for (int r = 0; r < 9; r++) Fe[r] += Je[r * 9 + k] * gx;
+          }
+      for (int k = 0; k < 9; k++)
+        if (c->isbc[ld[k]]) {
+          Fe[k] = 0.0;
+          if (need_j)
+            for (int r = 0; r < 9; r++) { Je[k * 9 + r] = 0.0; Je[r * 9 + k] = 0.0; }
+        }
+    }
+  }
+  /* row gather: deterministic, race free */
+#pragma omp parallel for schedule(static)
+  for (int v = 0; v < nv; v++) {
+    int deg = c->vptr[v + 1] - c->vptr[v];
+    double f0 = 0, f1 = 0, f2 = 0;
+    double *r0 = c->val + c->rowptr[2 * v], *r1 = c->val + c->rowptr[2 * v + 1], *r2 = c->val + c->rowptr[nu + v];
+    if (want_jac) { memset(r0, 0, sizeof(double) * 3 * deg); memset(r1, 0, sizeof(double) * 3 * deg); memset(r2, 0, sizeof(double) * 3 * deg); }
+    for (int k = c->vcptr[v]; k < c->vcptr[v + 1]; k++) {
+      int e = c->vcell[k] / 3, a = c->vcell[k] % 3;
+      const double *Fe = c->Fe + 9 * (size_t)e, *Je = c->Je + 81 * (size_t)e;
+      f0 += Fe[2 * a]; f1 += Fe[2 * a + 1]; f2 += Fe[6 + a];
+      if (want_jac)
+        for (int b = 0; b < 3; b++) {
+          int kb = c->cellpos[9 * e + 3 * a + b];
+          for (int j = 0; j < 2; j++) {
+            r0[2 * kb + j] += Je[(2 * a) * 9 + 2 * b + j];
+            r1[2 * kb + j] += Je[(2 * a + 1) * 9 + 2 * b + j];
+            r2[2 * kb + j] += Je[(6 + a) * 9 + 2 * b + j];
+          }
+          r0[2 * deg + kb] += Je[(2 * a) * 9 + 6 + b];
+          r1[2 * deg + kb] += Je[(2 * a + 1) * 9 + 6 + b];
+          r2[2 * deg + kb] += Je[(6 + a) * 9 + 6 + b];
+        }
+    }
+    int rows[3] = {2 * v, 2 * v + 1, nu + v};
+    double fv[3] = {f0, f1, f2};
+    double *rr[3] = {r0, r1, r2};
+    /* position of the diagonal inside the row */
+    int kd = 0;
+    while (c->vadj[c->vptr[v] + kd] != v) kd++;
+    for (int t = 0; t < 3; t++) {
+      int d = rows[t];
+      if (c->isbc[d]) {
+        fv[t] = xv[d] - c->bcval[d];
+        if (want_jac) rr[t][t < 2 ? 2 * kd + t : 2 * deg + kd] = c->bcmult[d];
+      }
+      F[d] = fv[t];
+    }
+  }
+}
+
+void orc_get_csr(orc_ctx *c, int *nnz, int **rowptr, int **col, double **val) {
+  *nnz = c->nnz; *rowptr = c->rowptr; *col = c->col; *val = c->val;
+}
+
+/* ------------------------------------------------------------------ linear algebra */
+
+static double vdot(int n, const double *a, const double *b) {
+  double s = 0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+  for (int i = 0; i < n; i++) s += a[i] * b[i];
+  return s;
+}
+static double vnorm(int n, const double *a) { return sqrt(vdot(n, a, a)); }
+static void vaxpy(int n, double al, const double *x, double *y) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) y[i] += al * x[i];
+}
+static void vcopy(int n, const double *x, double *y) { memcpy(y, x, sizeof(double) * n); }
+static void vscale(int n, double al, double *x) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) x[i] *= al;
+}
+
+/* y = A[rows r0..r1, cols c0..c1) x : sub-block of the monolithic CSR.
+ * columns of a row are sorted with all velocity columns first, so a block is a
+ * contiguous slice of the row. */
+typedef struct { const orc_ctx *c; int blk; } blk_t; /* blk: 0=full,1=A00,2=A01,3=A10,4=A11 */
+
+static void blk_range(const orc_ctx *c, int blk, int *r0, int *r1) {
+  int nu = 2 * c->nv;
+  if (blk == 0) { *r0 = 0; *r1 = c->ndof; }
+  else if (blk == 1 || blk == 2) { *r0 = 0; *r1 = nu; }
+  else { *r0 = nu; *r1 = c->ndof; }
+}
+static void blk_mult(const orc_ctx *c, int blk, const double *x, double *y) {
+  int nu = 2 * c->nv, r0, r1;
+  blk_range(c, blk, &r0, &r1);
+#pragma omp parallel for schedule(static)
+  for (int r = r0; r < r1; r++) {
+    int v = r < nu ? r / 2 : r - nu;
+    int deg = c->vptr[v + 1] - c->vptr[v];
+    int s = c->rowptr[r], k0 = s, k1 = s + 3 * deg, off = 0;
+    if (blk == 1 || blk == 3) k1 = s + 2 * deg;
+    if (blk == 2 || blk == 4) { k0 = s + 2 * deg; off = nu; }
+    double acc = 0;
+    for (int k = k0; k < k1; k++) acc += c->val[k] * x[c->col[k] - off];
+    y[r - r0] = acc;
+  }
+}
+
+/* ILU(0) of a CSR matrix with sorted columns */
+static int ilu0(csr_t *m) {
+  int n = m->n;
+  if (!m->diag) m->diag = (int *)malloc(sizeof(int) * n);
+  int *pos = (int *)malloc(sizeof(int) * n);
+  for (int i = 0; i < n; i++) pos[i] = -1;
+  for (int i = 0; i < n; i++) {
+    int s = m->rowptr[i], e = m->rowptr[i + 1];
+    for (int k = s; k < e; k++) pos[m->col[k]] = k;
+    m->diag[i] = -1;
+    for (int k = s; k < e; k++) {
+      int j = m->col[k];
+      if (j >= i) { if (j == i) m->diag[i] = k; break; }
+      double piv = m->val[m->diag[j]];
+      double l = m->val[k] / piv;
+      m->val[k] = l;
+      for (int kk = m->diag[j] + 1; kk < m->rowptr[j + 1]; kk++) {
+        int p = pos[m->col[kk]];
+        if (p >= 0) m->val[p] -= l * m->val[kk];
+      }
+    }
+    if (m->diag[i] < 0) { for (int k = s; k < e; k++) if (m->col[k] == i) m->diag[i] = k; }
+    if (m->diag[i] < 0 || m->val[m->diag[i]] == 0.0) { free(pos); return -1; }
+    for (int k = s; k < e; k++) pos[m->col[k]] = -1;
+  }
+  free(pos);
+  return 0;
+}
+static void ilu_solve(const csr_t *m, const double *b, double *x) {
+  int n = m->n;
+  for (int i = 0; i < n; i++) {
+    double s = b[i];
+    for (int k = m->rowptr[i]; k < m->diag[i]; k++) s -= m->val[k] * x[m->col[k]];
+    x[i] = s;
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = m->diag[i] + 1; k < m->rowptr[i + 1]; k++) s -= m->val[k] * x[m->col[k]];
+    x[i] = s / m->val[m->diag[i]];
+  }
+}
+
+/* PC setup for the current Jacobian: ILU(0) of A00 and of Sp = A11 - A10 D^-1 A01 */
+static int pc_setup(orc_ctx *c) {
+  const int nv = c->nv, nu = 2 * nv;
+  /* A00 copy */
+  csr_t *A = &c->A00f;
+  if (!A->rowptr) {
+    A->n = nu;
+    A->rowptr = (int *)malloc(sizeof(int) * (nu + 1));
+    A->rowptr[0] = 0;
+    for (int r = 0; r < nu; r++) { int v = r / 2; A->rowptr[r + 1] = A->rowptr[r] + 2 * (c->vptr[v + 1] - c->vptr[v]); }
+    A->col = (int *)malloc(sizeof(int) * A->rowptr[nu]);
+    A->val = (double *)malloc(sizeof(double) * A->rowptr[nu]);
+    for (int r = 0; r < nu; r++) memcpy(A->col + A->rowptr[r], c->col + c->rowptr[r], sizeof(int) * (A->rowptr[r + 1] - A->rowptr[r]));
+  }
+  for (int r = 0; r < nu; r++) memcpy(A->val + A->rowptr[r], c->val + c->rowptr[r], sizeof(double) * (A->rowptr[r + 1] - A->rowptr[r]));
+  double *Dinv = (double *)malloc(sizeof(double) * nu);
+  for (int r = 0; r < nu; r++) {
+    double d = 0;
+    for (int k = A->rowptr[r]; k < A->rowptr[r + 1]; k++) if (A->col[k] == r) d = A->val[k];
+    Dinv[r] = 1.0 / d;
+  }
+  /* Sp pattern (once): union over u-columns k of row i of the p-columns of row k */
+  csr_t *S = &c->Sp;
+  if (!S->rowptr) {
+    S->n = nv;
+    S->rowptr = (int *)calloc(nv + 1, sizeof(int));
+    int *mark = (int *)malloc(sizeof(int) * nv);
+    for (int i = 0; i < nv; i++) mark[i] = -1;
+    int cap = 32 * nv, n = 0;
+    S->col = (int *)malloc(sizeof(int) * cap);
+    for (int i = 0; i < nv; i++) {
+      int start = n;
+      for (int kk = c->vptr[i]; kk < c->vptr[i + 1]; kk++) {
+        int w = c->vadj[kk];
+        for (int k2 = c->vptr[w]; k2 < c->vptr[w + 1]; k2++) {
+          int j = c->vadj[k2];
+          if (mark[j] != i) {
+            mark[j] = i;
+            if (n == cap) { cap *= 2; S->col = (int *)realloc(S->col, sizeof(int) * cap); }
+            S->col[n++] = j;
+          }
+        }
+      }
+      qsort(S->col + start, n - start, sizeof(int), cmp_int);
+      S->rowptr[i + 1] = n;
+    }
+    free(mark);
+    S->val = (double *)malloc(sizeof(double) * n);
+  }
+  {
+    int *pos = (int *)malloc(sizeof(int) * nv);
+    for (int i = 0; i < nv; i++) pos[i] = -1;
+    for (int i = 0; i < nv; i++) {
+      int s = S->rowptr[i], e = S->rowptr[i + 1];
+      for (int k = s; k < e; k++) { pos[S->col[k]] = k; S->val[k] = 0.0; }
+      int r = nu + i, deg = c->vptr[i + 1] - c->vptr[i];
+      int rs = c->rowptr[r];
+      for (int k = 0; k < deg; k++) S->val[pos[c->col[rs + 2 * deg + k] - nu]] += c->val[rs + 2 * deg + k];
+      for (int k = 0; k < 2 * deg; k++) {
+        int ucol = c->col[rs + k];
+        double a = c->val[rs + k] * Dinv[ucol];
+        if (a == 0.0) continue;
+        int w = ucol / 2, dw = c->vptr[w + 1] - c->vptr[w], us = c->rowptr[ucol];
+        for (int k2 = 0; k2 < dw; k2++) S->val[pos[c->col[us + 2 * dw + k2] - nu]] -= a * c->val[us + 2 * dw + k2];
+      }
+      for (int k = s; k < e; k++) pos[S->col[k]] = -1;
+    }
+    free(pos);
+  }
+  free(Dinv);
+  if (ilu0(A)) { snprintf(c->err, sizeof c->err, "zero pivot in ILU(A00)"); return -1; }
+  if (ilu0(S)) { snprintf(c->err, sizeof c->err, "zero pivot in ILU(Sp)"); return -1; }
+  return 0;
+}
+
+/* inner KSP on A00: GMRES(restart) left-preconditioned with ILU(0), rtol on the
+ * preconditioned residual (PETSc defaults for ksp_u, stabilized_schur.py:261) */
+typedef struct {
+  int n, m;
+  double *V, *H, *w, *t, *cs, *sn, *g, *y;
+} gm_ws;
+static void gm_alloc(gm_ws *ws, int n, int m) {
+  ws->n = n; ws->m = m;
+  ws->V = (double *)malloc(sizeof(double) * (size_t)n * (m + 1));
+  ws->H = (double *)malloc(sizeof(double) * (m + 1) * m);
+  ws->w = (double *)malloc(sizeof(double) * n); ws->t = (double *)malloc(sizeof(double) * n);
+  ws->cs = (double *)malloc(sizeof(double) * m); ws->sn = (double *)malloc(sizeof(double) * m);
+  ws->g = (double *)malloc(sizeof(double) * (m + 1)); ws->y = (double *)malloc(sizeof(double) * m);
+}
+static void gm_free(gm_ws *ws) { free(ws->V); free(ws->H); free(ws->w); free(ws->t); free(ws->cs); free(ws->sn); free(ws->g); free(ws->y); }
+
+static int a00_solve(orc_ctx *c, gm_ws *ws, const double *b, double *x, double rtol, int max_it, int *its_out) {
+  const int n = ws->n, m = ws->m;
+  memset(x, 0, sizeof(double) * n);
+  int its = 0;
+  double r0n = -1;
+  for (;;) {
+    /* r = M^-1 (b - A x) */
+    blk_mult(c, 1, x, ws->t);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) ws->t[i] = b[i] - ws->t[i];
+    ilu_solve(&c->A00f, ws->t, ws->w);
+    double beta = vnorm(n, ws->w);
+    if (r0n < 0) r0n = beta;
+    if (beta <= rtol * r0n || beta == 0.0 || its >= max_it) break;
+    double *V = ws->V;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) V[i] = ws->w[i] / beta;
+    memset(ws->g, 0, sizeof(double) * (m + 1));
+    ws->g[0] = beta;
+    int j;
+    for (j = 0; j < m && its < max_it; j++) {
+      blk_mult(c, 1, V + (size_t)j * n, ws->t);
+      ilu_solve(&c->A00f, ws->t, ws->w);
+      double *Hj = ws->H + (size_t)j * (m + 1);
+      for (int i = 0; i <= j; i++) { Hj[i] = vdot(n, ws->w, V + (size_t)i * n); vaxpy(n, -Hj[i], V + (size_t)i * n, ws->w); }
+      Hj[j + 1] = vnorm(n, ws->w);
+      double *vn = V + (size_t)(j + 1) * n;
+      double inv = Hj[j + 1] != 0.0 ? 1.0 / Hj[j + 1] : 0.0;
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < n; i++) vn[i] = ws->w[i] * inv;
+      for (int i = 0; i < j; i++) {
+        double t = ws->cs[i] * Hj[i] + ws->sn[i] * Hj[i + 1];
+        Hj[i + 1] = -ws->sn[i] * Hj[i] + ws->cs[i] * Hj[i + 1];
+        Hj[i] = t;
+      }
+      double d = hypot(Hj[j], Hj[j + 1]);
+      ws->cs[j] = Hj[j] / d; ws->sn[j] = Hj[j + 1] / d;
+      Hj[j] = d; Hj[j + 1] = 0;
+      ws->g[j + 1] = -ws->sn[j] * ws->g[j]; ws->g[j] = ws->cs[j] * ws->g[j];
+      its++;
+      if (fabs(ws->g[j + 1]) <= rtol * r0n) { j++; break; }
+    }
+    for (int i = j - 1; i >= 0; i--) {
+      double s = ws->g[i];
+      for (int k = i + 1; k < j; k++) s -= ws->H[(size_t)k * (m + 1) + i] * ws->y[k];
+      ws->y[i] = s / ws->H[(size_t)i * (m + 1) + i];
+    }
+    for (int k = 0; k < j; k++) vaxpy(n, ws->y[k], V + (size_t)k * n, x);
+  }
+  *its_out += its;
+  return 0;
+}
+
+/* z = P^-1 r: PCFIELDSPLIT Schur FULL (stabilized_schur.py:231-235,256-264) */
+typedef struct {
+  gm_ws sub;
+  double *yu, *yp, *tu, *tp;
+  double sub_rtol;
+  int sub_max_it, sub_its;
+} pc_ws;
+
+static void pc_apply(orc_ctx *c, pc_ws *p, const double *r, double *z) {
+  const int nv = c->nv, nu = 2 * nv;
+  a00_solve(c, &p->sub, r, p->yu, p->sub_rtol, p->sub_max_it, &p->sub_its); /* y_u = A00^-1 r_u */
+  blk_mult(c, 3, p->yu, p->tp);                                            /* A10 y_u */
+  for (int i = 0; i < nv; i++) p->tp[i] = r[nu + i] - p->tp[i];
+  ilu_solve(&c->Sp, p->tp, z + nu);                                          /* y_p = ILU(Sp)^-1 (...) */
+  blk_mult(c, 2, z + nu, p->tu);                                             /* A01 y_p */
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < nu; i++) p->tu[i] = r[i] - p->tu[i];
+  a00_solve(c, &p->sub, p->tu, z, p->sub_rtol, p->sub_max_it, &p->sub_its);  /* y_u = A00^-1 (r_u - A01 y_p) */
+}
+
+static void remove_pmean(const orc_ctx *c, double *v) {
+  double s = 0;
+  const int nv = c->nv, nu = 2 * nv;
+  for (int i = 0; i < nv; i++) s += v[nu + i];
+  s /= nv;
+  for (int i = 0; i < nv; i++) v[nu + i] -= s;
+}
+
+/* outer FGMRES (right preconditioned, true-residual norm test against |b|, x0 = 0) */
+static int fgmres(orc_ctx *c, const orc_opts *o, pc_ws *pc, const double *b, double *x, int singular, int *its_out) {
+  const int n = c->ndof, m = o->ksp_restart;
+  double *V = (double *)malloc(sizeof(double) * (size_t)n * (m + 1));
+  double *Z = (double *)malloc(sizeof(double) * (size_t)n * m);
+  double *H = (double *)malloc(sizeof(double) * (m + 1) * m);
+  double *w = (double *)malloc(sizeof(double) * n);
+  double *cs = (double *)malloc(sizeof(double) * m), *sn = (double *)malloc(sizeof(double) * m);
+  double *g = (double *)malloc(sizeof(double) * (m + 1)), *y = (double *)malloc(sizeof(double) * m);
+  memset(x, 0, sizeof(double) * n);
+  double bn = vnorm(n, b);
+  int its = 0, reason = 0;
+  if (bn == 0.0) { reason = 1; goto done; }
+  for (;;) {
+    blk_mult(c, 0, x, w);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) w[i] = b[i] - w[i];
+    double beta = vnorm(n, w);
+    if (beta <= fmax(o->ksp_rtol * bn, o->ksp_atol)) { reason = 2; break; }
+    if (its >= o->ksp_max_it) { reason = -3; break; }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) V[i] = w[i] / beta;
+    memset(g, 0, sizeof(double) * (m + 1));
+    g[0] = beta;
+    int j;
+    for (j = 0; j < m && its < o->ksp_max_it; j++) {
+      double *zj = Z + (size_t)j * n;
+      pc_apply(c, pc, V + (size_t)j * n, zj);
+      if (singular) remove_pmean(c, zj);
+      blk_mult(c, 0, zj, w);
+      double *Hj = H + (size_t)j * (m + 1);
+      for (int i = 0; i <= j; i++) { Hj[i] = vdot(n, w, V + (size_t)i * n); vaxpy(n, -Hj[i], V + (size_t)i * n, w); }
+      Hj[j + 1] = vnorm(n, w);
+      double inv = Hj[j + 1] != 0.0 ? 1.0 / Hj[j + 1] : 0.0;
+      double *vn = V + (size_t)(j + 1) * n;
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < n; i++) vn[i] = w[i] * inv;
+      for (int i = 0; i < j; i++) {
+        double t = cs[i] * Hj[i] + sn[i] * Hj[i + 1];
+        Hj[i + 1] = -sn[i] * Hj[i] + cs[i] * Hj[i + 1];
+        Hj[i] = t;
+      }
+      double d = hypot(Hj[j], Hj[j + 1]);
+      cs[j] = Hj[j] / d; sn[j] = Hj[j + 1] / d;
+      Hj[j] = d; Hj[j + 1] = 0;
+      g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
+      its++;
+      if (o->verbose > 1) printf("      oracle fgmres %3d  |r|/|b| = %.3e\n", its, fabs(g[j + 1]) / bn);
+      if (fabs(g[j + 1]) <= fmax(o->ksp_rtol * bn, o->ksp_atol)) { j++; break; }
+    }
+    for (int i = j - 1; i >= 0; i--) {
+      double s = g[i];
+      for (int k = i + 1; k < j; k++) s -= H[(size_t)k * (m + 1) + i] * y[k];
+      y[i] = s / H[(size_t)i * (m + 1) + i];
+    }
+    for (int k = 0; k < j; k++) vaxpy(n, y[k], Z + (size_t)k * n, x);
+  }
+done:
+  free(V); free(Z); free(H); free(w); free(cs); free(sn); free(g); free(y);
+  *its_out += its;
+  return reason;
+}
+
+void orc_default_opts(orc_opts *o) {
+  /* PETSc defaults + the caps of stabilized_schur.py:269-274 */
+  o->snes_rtol = 1e-8; o->snes_atol = 1e-50; o->snes_stol = 1e-8; o->snes_max_it = 100;
+  o->ksp_rtol = 1e-5; o->ksp_atol = 1e-50; o->ksp_max_it = 1000; o->ksp_restart = 200;
+  o->sub_rtol = 1e-5; o->sub_max_it = 10000; o->sub_restart = 30;
+  o->remove_p_mean = 1; o->verbose = 0;
+}
+
+/* One time step: Newton on the monolithic vector xv (in: initial guess = previous
+ * converged vector, out: solution).  stabilized_schur.py:313-334. */
+int orc_solve_step(orc_ctx *c, double *xv, const orc_opts *o, orc_stats *st) {
+  const int n = c->ndof, nv = c->nv, nu = 2 * nv;
+  memset(st, 0, sizeof *st);
+  double *F = (double *)malloc(sizeof(double) * n), *d = (double *)malloc(sizeof(double) * n);
+  double *xt = (double *)malloc(sizeof(double) * n), *Ft = (double *)malloc(sizeof(double) * n);
+  pc_ws pc;
+  memset(&pc, 0, sizeof pc);
+  gm_alloc(&pc.sub, nu, o->sub_restart);
+  pc.yu = (double *)malloc(sizeof(double) * nu); pc.tu = (double *)malloc(sizeof(double) * nu);
+  pc.yp = (double *)malloc(sizeof(double) * nv); pc.tp = (double *)malloc(sizeof(double) * nv);
+  pc.sub_rtol = o->sub_rtol; pc.sub_max_it = o->sub_max_it;
+  int singular = !c->any_pbc;
+  if (o->remove_p_mean) remove_pmean(c, xv);
+  double t0 = now_ms();
+  orc_assemble(c, xv, 1, F);
+  st->ms_assemble += now_ms() - t0;
+  double fn = vnorm(n, F);
+  st->fnorm0 = fn;
+  int reason = 0;
+  for (int it = 0;; it++) {
+    if (o->verbose) printf("  oracle newton %d |F| = %.6e\n", it, fn);
+    if (fn < o->snes_atol) { reason = 2; break; }
+    if (it > 0 && fn <= o->snes_rtol * st->fnorm0) { reason = 3; break; }
+    if (it >= o->snes_max_it) { reason = -5; break; }
+    t0 = now_ms();
+    if (pc_setup(c)) { reason = -3; break; }
+    int kr = fgmres(c, o, &pc, F, d, singular, &st->krylov_its);
+    st->ms_solve += now_ms() - t0;
+    if (kr < 0) { reason = -3; snprintf(c->err, sizeof c->err, "linear solve failed (%d)", kr); break; }
+    /* bt line search on 1/2|F|^2 (Dennis-Schnabel backtracking, alpha = 1e-4) */
+    double lam = 1.0, fnew = 0;
+    t0 = now_ms();
+    int ok = 0;
+    for (int ls = 0; ls < 40; ls++) {
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < n; i++) xt[i] = xv[i] - lam * d[i];
+      orc_assemble(c, xt, 0, Ft);
+      fnew = vnorm(n, Ft);
+      if (fnew * fnew <= fn * fn * (1.0 - 2.0 * 1e-4 * lam) || fnew < o->snes_atol) { ok = 1; break; }
+      /* quadratic model through phi(0)=fn^2/2, phi'(0)=-fn^2, phi(lam) */
+      double l2 = fn * fn * lam * lam / (2.0 * (0.5 * fnew * fnew - 0.5 * fn * fn + fn * fn * lam));
+      if (!(l2 > 0.1 * lam)) l2 = 0.1 * lam;
+      if (l2 > 0.5 * lam) l2 = 0.5 * lam;
+      lam = l2;
+    }
+    if (!ok) { reason = -6; st->ms_assemble += now_ms() - t0; break; }
+    double dxn = lam * vnorm(n, d), xn = vnorm(n, xt);
+    vcopy(n, xt, xv);
+    st->newton_its = it + 1;
+    /* Jacobian + residual at the new iterate */
+    orc_assemble(c, xv, 1, F);
+    st->ms_assemble += now_ms() - t0;
+    fn = vnorm(n, F);
+    if (dxn < o->snes_stol * xn && fn > o->snes_rtol * st->fnorm0 && fn >= o->snes_atol) {
+      if (o->verbose) printf("  oracle newton %d |F| = %.6e (stol)\n", it + 1, fn);
+      reason = 4; break;
+    }
+  }
+  st->fnorm = fn;
+  st->reason = reason;
+  st->sub_its = pc.sub_its;
+  gm_free(&pc.sub);
+  free(pc.yu); free(pc.tu); free(pc.yp); free(pc.tp);
+  free(F); free(d); free(xt); free(Ft);
+  return reason;
+}
+
+const char *orc_last_error(orc_ctx *c) { return c->err; }
+
+/* y = J x with the currently assembled values (tests) */
+void orc_spmv(orc_ctx *c, const double *x, double *y) { blk_mult(c, 0, x, y); }
+
+/* kind 0: F_D, 1: F_L over facets of `marker` list (dfg_1.py:183-202; caller scales by 500)
+ *      2: ||u||_L2, 3: ||p||_L2 (scenario.py:315-324) */
+double orc_functional(orc_ctx *c, const double *xv, int kind, int nfac, const int *facets, double mu) {
+  const int nu = 2 * c->nv;
+  if (kind >= 2) {
+    double s = 0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+    for (int e = 0; e < c->nc; e++) {
+      double xe[3][2], g[3][2], area, h;
+      int vs[3];
+      for (int a = 0; a < 3; a++) { vs[a] = c->cells[3 * e + a]; xe[a][0] = c->x[2 * vs[a]]; xe[a][1] = c->x[2 * vs[a] + 1]; }
+      geom(xe, g, &area, &h);
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+          double m = area * (a == b ? 2.0 : 1.0) / 12.0;
+          if (kind == 2) s += m * (xv[2 * vs[a]] * xv[2 * vs[b]] + xv[2 * vs[a] + 1] * xv[2 * vs[b] + 1]);
+          else s += m * xv[nu + vs[a]] * xv[nu + vs[b]];
+        }
+    }
+    return sqrt(s);
+  }
+  double FD = 0, FL = 0;
+  for (int k = 0; k < nfac; k++) {
+    int e = c->fcell[facets[k]], fl = c->flocal[facets[k]];
+    double xe[3][2], g[3][2], area, h;
+    int vs[3];
+    for (int a = 0; a < 3; a++) { vs[a] = c->cells[3 * e + a]; xe[a][0] = c->x[2 * vs[a]]; xe[a][1] = c->x[2 * vs[a] + 1]; }
+    geom(xe, g, &area, &h);
+    double gl = hypot(g[fl][0], g[fl][1]);
+    double n[2] = {g[fl][0] / gl, g[fl][1] / gl}; /* n = -FacetNormal */
+    double elen = 2.0 * area * gl;
+    double t[2] = {n[1], -n[0]};
+    double gut[2] = {0, 0};
+    for (int a = 0; a < 3; a++) {
+      double ut = xv[2 * vs[a]] * t[0] + xv[2 * vs[a] + 1] * t[1];
+      gut[0] += ut * g[a][0]; gut[1] += ut * g[a][1];
+    }
+    double dn = gut[0] * n[0] + gut[1] * n[1];
+    double pm = 0.5 * (xv[nu + vs[(fl + 1) % 3]] + xv[nu + vs[(fl + 2) % 3]]);
+    FD += elen * (mu * dn * n[1] - pm * n[0]);
+    FL -= elen * (mu * dn * n[0] + pm * n[1]);
+  }
+  return kind == 0 ? FD : FL;
+}

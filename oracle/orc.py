@@ -1,0 +1,166 @@
+"""ctypes binding of the C oracle  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+(see oracle/cfdh_oracle.c header: parity unpinned; only tests/, smoke() and
+bench.py's cpu_baseline leg may import this.)"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libcfdh_oracle.so")
+    src = os.path.join(_HERE, "cfdh_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+class Opts(C.Structure):
+    _fields_ = [("snes_rtol", C.c_double), ("snes_atol", C.c_double), ("snes_stol", C.c_double),
+                ("snes_max_it", C.c_int), ("ksp_rtol", C.c_double), ("ksp_atol", C.c_double),
+                ("ksp_max_it", C.c_int), ("ksp_restart", C.c_int), ("sub_rtol", C.c_double),
+                ("sub_max_it", C.c_int), ("sub_restart", C.c_int), ("remove_p_mean", C.c_int),
+                ("verbose", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("newton_its", C.c_int), ("krylov_its", C.c_int), ("reason", C.c_int), ("sub_its", C.c_int),
+                ("fnorm0", C.c_double), ("fnorm", C.c_double), ("ms_assemble", C.c_double),
+                ("ms_solve", C.c_double)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_int, ip, dp, C.c_int, ip, ip]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_params.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, dp]
+        L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc_get_threads.argtypes = [C.c_void_p]
+        L.orc_get_threads.restype = C.c_int
+        L.orc_clear_bcs.argtypes = [C.c_void_p]
+        L.orc_add_bc.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, dp]
+        L.orc_set_un.argtypes = [C.c_void_p, dp]
+        L.orc_assemble.argtypes = [C.c_void_p, dp, C.c_int, dp]
+        L.orc_get_csr.argtypes = [C.c_void_p, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp)]
+        L.orc_default_opts.argtypes = [C.POINTER(Opts)]
+        L.orc_solve_step.argtypes = [C.c_void_p, dp, C.POINTER(Opts), C.POINTER(Stats)]
+        L.orc_solve_step.restype = C.c_int
+        L.orc_last_error.argtypes = [C.c_void_p]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_spmv.argtypes = [C.c_void_p, dp, dp]
+        L.orc_functional.argtypes = [C.c_void_p, dp, C.c_int, C.c_int, ip, C.c_double]
+        L.orc_functional.restype = C.c_double
+        L.orc_element.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp, C.c_int, dp, dp]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def default_opts(**kw):
+    o = Opts()
+    lib().orc_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class Oracle:
+    """Plain-array problem: x [nv,2], cells [nc,3], exterior facets (cell, local)."""
+
+    def __init__(self, x, cells, facet_cells, facet_local, dt, rho, mu, f=(0.0, 0.0), mu_facet=None):
+        L = lib()
+        self.x = np.ascontiguousarray(x, dtype=np.float64)
+        self.cells = np.ascontiguousarray(cells, dtype=np.int32)
+        self.fc = np.ascontiguousarray(facet_cells, dtype=np.int32)
+        self.fl = np.ascontiguousarray(facet_local, dtype=np.int32)
+        self.nv, self.nc = len(self.x), len(self.cells)
+        self.ndof = 3 * self.nv
+        self.h = L.orc_create(self.nv, self.nc, _ip(self.cells), _dp(self.x), len(self.fc), _ip(self.fc), _ip(self.fl))
+        ff = np.asarray(f, dtype=np.float64)
+        L.orc_set_params(self.h, dt, rho, mu, mu if mu_facet is None else mu_facet, _dp(ff))
+        self.mu = mu
+
+    def __del__(self):
+        try:
+            lib().orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_threads(self, n):
+        lib().orc_set_threads(self.h, int(n))
+
+    def threads(self):
+        return lib().orc_get_threads(self.h)
+
+    def clear_bcs(self):
+        lib().orc_clear_bcs(self.h)
+
+    def add_bc_u(self, nodes, values):
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float64).reshape(-1, 2)
+        lib().orc_add_bc(self.h, 0, len(nodes), _ip(nodes), _dp(values))
+
+    def add_bc_p(self, nodes, values):
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        lib().orc_add_bc(self.h, 1, len(nodes), _ip(nodes), _dp(values))
+
+    def set_un(self, un):
+        un = np.ascontiguousarray(un, dtype=np.float64).reshape(-1)
+        lib().orc_set_un(self.h, _dp(un))
+
+    def assemble(self, xv, want_jac=True):
+        xv = np.ascontiguousarray(xv, dtype=np.float64)
+        F = np.empty(self.ndof)
+        lib().orc_assemble(self.h, _dp(xv), int(want_jac), _dp(F))
+        return F
+
+    def csr(self):
+        import scipy.sparse as sp
+        nnz = C.c_int()
+        rp, cl, vl = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_double)()
+        lib().orc_get_csr(self.h, C.byref(nnz), C.byref(rp), C.byref(cl), C.byref(vl))
+        rowptr = np.ctypeslib.as_array(rp, (self.ndof + 1,)).copy()
+        col = np.ctypeslib.as_array(cl, (nnz.value,)).copy()
+        val = np.ctypeslib.as_array(vl, (nnz.value,)).copy()
+        return sp.csr_matrix((val, col, rowptr), shape=(self.ndof, self.ndof))
+
+    def solve_step(self, xv, opts=None):
+        opts = opts or default_opts()
+        st = Stats()
+        xv = np.ascontiguousarray(xv, dtype=np.float64)
+        r = lib().orc_solve_step(self.h, _dp(xv), C.byref(opts), C.byref(st))
+        if r < 0:
+            raise RuntimeError("Did not converge, reason: %d. %s" % (r, lib().orc_last_error(self.h).decode()))
+        return xv, st
+
+    def functional(self, xv, kind, facets=None):
+        xv = np.ascontiguousarray(xv, dtype=np.float64)
+        fa = np.ascontiguousarray(facets if facets is not None else [], dtype=np.int32)
+        return lib().orc_functional(self.h, _dp(xv), int(kind), len(fa), _ip(fa), float(self.mu))
+
+
+def element(dt, rho, mu, muf, f, xe, ue, une, pe, fflag):
+    Fe = np.empty(9)
+    Je = np.empty((9, 9))
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (f, xe, ue, une, pe)]
+    lib().orc_element(dt, rho, mu, muf, _dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(a[3]), _dp(a[4]), int(fflag), _dp(Fe), _dp(Je))
+    return Fe, Je
