@@ -1,0 +1,329 @@
+// extern "C" entry points of libcfdh.so (see include/cfdh.h).
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "cfdh_internal.hpp"
+
+std::string g_cfdh_last_error;
+
+int cfdh_prepare_assembly(cfdh_ctx *c);
+
+extern "C" {
+
+int cfdh_abi_version(void) { return CFDH_ABI_VERSION; }
+
+const char *cfdh_last_error(const cfdh_ctx *c) { return c ? c->err.c_str() : g_cfdh_last_error.c_str(); }
+
+int cfdh_default_options(cfdh_options *o) {
+  if (!o) return CFDH_E_ARG;
+  // PETSc defaults + the caps the reference sets (stabilized_schur.py:269-274)
+  o->snes_rtol = 1e-8; o->snes_atol = 1e-50; o->snes_stol = 1e-8; o->snes_max_it = 100;
+  o->ksp_rtol = 1e-5; o->ksp_atol = 1e-50; o->ksp_max_it = 1000; o->ksp_restart = 200;
+  o->cheb_degree = 3; o->cheb_ratio = 10.0; o->schur_full = 1;
+  o->amg_smooth_degree = 2; o->amg_smooth_ratio = 8.0; o->amg_theta = 0.08; o->amg_max_coarse = 300;
+  o->pc_refresh = 0; o->remove_p_mean = 1; o->verbose = 0;
+  return 0;
+}
+
+int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_owned, int64_t nc, const int32_t *cells,
+                const double *coords, int64_t nfacets, const int32_t *facet_cells, const int32_t *facet_local,
+                const int32_t *facet_marker) {
+  if (!out) return cfdh_fail(nullptr, CFDH_E_ARG, "null output pointer");
+  *out = nullptr;
+  if (gdim != 2) return cfdh_fail(nullptr, CFDH_E_ARG, "only gdim == 2 (P1 triangles) is implemented");
+  if (!cells || !coords || (nfacets > 0 && (!facet_cells || !facet_local)))
+    return cfdh_fail(nullptr, CFDH_E_ARG, "null mesh array");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return cfdh_fail(nullptr, CFDH_E_HIP, "no HIP device available: libcfdh has no CPU fallback");
+  if (device < 0 || device >= ndev) return cfdh_fail(nullptr, CFDH_E_ARG, "device %d out of range (%d devices)", device, ndev);
+  cfdh_ctx *c = new (std::nothrow) cfdh_ctx();
+  if (!c) return cfdh_fail(nullptr, CFDH_E_NOMEM, "out of host memory");
+  c->device = device;
+  cfdh_default_options(&c->opt);
+  memset(&c->last_stats, 0, sizeof c->last_stats);
+  int rc = 0;
+  do {
+    if (hipSetDevice(device) != hipSuccess) { rc = cfdh_fail(nullptr, CFDH_E_HIP, "hipSetDevice(%d) failed", device); break; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = cfdh_fail(nullptr, CFDH_E_HIP, "hipStreamCreate failed"); break; }
+    rc = k_upload_quadrature(c);
+    if (rc) break;
+    rc = cfdh_build_mesh(c, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker);
+  } while (0);
+  if (rc) {
+    g_cfdh_last_error = c->err.empty() ? g_cfdh_last_error : c->err;
+    cfdh_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return 0;
+}
+
+void cfdh_destroy(cfdh_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  comm_finalize(c);
+  for (AmgLevel *l : c->amg) delete l;
+  c->amg.clear();
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  hipStream_t s = c->stream;
+  delete c;
+  if (s) (void)hipStreamDestroy(s);
+}
+
+int cfdh_set_params(cfdh_ctx *c, double dt, double rho, double mu, double mu_facet, const double f[3]) {
+  if (!c) return CFDH_E_ARG;
+  if (!(dt > 0) || !(rho > 0) || !(mu > 0)) return cfdh_fail(c, CFDH_E_ARG, "dt, rho, mu must be positive");
+  const bool changed = !c->params_set || dt != c->dt || rho != c->rho || mu != c->mu;
+  c->dt = dt; c->rho = rho; c->mu = mu; c->muf = mu_facet;
+  c->f[0] = f ? f[0] : 0.0; c->f[1] = f ? f[1] : 0.0;
+  c->params_set = true;
+  if (changed) { c->mom_valid = false; c->pc_valid = false; }
+  return 0;
+}
+
+int cfdh_set_options(cfdh_ctx *c, const cfdh_options *o) {
+  if (!c || !o) return CFDH_E_ARG;
+  if (o->ksp_restart < 1 || o->ksp_restart > 1000 || o->cheb_degree < 1 || !(o->cheb_ratio > 1) || o->amg_smooth_degree < 1 ||
+      !(o->amg_smooth_ratio > 1) || o->amg_max_coarse < 8 || o->amg_max_coarse > 2000)
+    return cfdh_fail(c, CFDH_E_ARG, "option out of range");
+  const bool pc_changed = o->amg_theta != c->opt.amg_theta || o->amg_max_coarse != c->opt.amg_max_coarse ||
+                          o->amg_smooth_ratio != c->opt.amg_smooth_ratio;
+  c->opt = *o;
+  if (pc_changed) c->pc_valid = false;
+  return 0;
+}
+
+int cfdh_clear_dirichlet(cfdh_ctx *c) {
+  if (!c) return CFDH_E_ARG;
+  std::fill(c->h_bcflag.begin(), c->h_bcflag.end(), 0);
+  std::fill(c->h_bcval.begin(), c->h_bcval.end(), 0.0);
+  std::fill(c->h_bcmult.begin(), c->h_bcmult.end(), 0.0);
+  c->n_pbc = 0;
+  c->bc_dirty = true;
+  return 0;
+}
+
+int cfdh_add_dirichlet(cfdh_ctx *c, int field, int64_t n, const int32_t *nodes, const double *values) {
+  if (!c || (field != 0 && field != 1) || n < 0 || (n > 0 && (!nodes || !values))) return cfdh_fail(c, CFDH_E_ARG, "bad Dirichlet arguments");
+  for (int64_t k = 0; k < n; k++)
+    if (nodes[k] < 0 || nodes[k] >= c->nv) return cfdh_fail(c, CFDH_E_ARG, "Dirichlet node %d out of range", (int)nodes[k]);
+  for (int64_t k = 0; k < n; k++) {
+    const int v = c->perm[nodes[k]];
+    if (field == 0) {
+      for (int i = 0; i < 2; i++) {
+        c->h_bcflag[v] |= (unsigned char)(1u << i);
+        c->h_bcval[3 * (size_t)v + i] = values[2 * k + i];
+        c->h_bcmult[3 * (size_t)v + i] += 1.0;
+      }
+    } else {
+      c->h_bcflag[v] |= 4u;
+      c->h_bcval[3 * (size_t)v + 2] = values[k];
+      c->h_bcmult[3 * (size_t)v + 2] += 1.0;
+      c->n_pbc++;
+    }
+  }
+  c->bc_dirty = true;
+  return 0;
+}
+
+// user arrays (u [nv][2], p [nv], user numbering) -> internal vector layout
+static void pack_vec(const cfdh_ctx *c, const double *u, const double *p, std::vector<double> &out, const std::vector<double> *keep) {
+  const int nvo = c->nvo, nv = c->nv;
+  out.resize((size_t)c->NL);
+  if (keep) out = *keep;
+  for (int k = 0; k < nv; k++) {
+    const int v = c->iperm[k];
+    const size_t uo = k < nvo ? 2 * (size_t)k : 3 * (size_t)k, po = k < nvo ? 2 * (size_t)nvo + k : 3 * (size_t)k + 2;
+    if (u) { out[uo] = u[2 * (size_t)v]; out[uo + 1] = u[2 * (size_t)v + 1]; }
+    if (p) out[po] = p[v];
+  }
+}
+static void unpack_vec(const cfdh_ctx *c, const std::vector<double> &in, double *u, double *p) {
+  const int nvo = c->nvo, nv = c->nv;
+  for (int k = 0; k < nv; k++) {
+    const int v = c->iperm[k];
+    const size_t uo = k < nvo ? 2 * (size_t)k : 3 * (size_t)k, po = k < nvo ? 2 * (size_t)nvo + k : 3 * (size_t)k + 2;
+    if (u) { u[2 * (size_t)v] = in[uo]; u[2 * (size_t)v + 1] = in[uo + 1]; }
+    if (p) p[v] = in[po];
+  }
+}
+static int download_vec(cfdh_ctx *c, const double *dev, std::vector<double> &h) {
+  h.resize((size_t)c->NL);
+  HIPCHK(c, hipMemcpyAsync(h.data(), dev, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+static int upload_vec(cfdh_ctx *c, const std::vector<double> &h, double *dev) {
+  HIPCHK(c, hipMemcpyAsync(dev, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int cfdh_set_state(cfdh_ctx *c, const double *u_prev, const double *p_prev, const double *u, const double *p) {
+  if (!c) return CFDH_E_ARG;
+  std::vector<double> h, cur;
+  if (u_prev || p_prev) {
+    const std::vector<double> *keep = nullptr;
+    if (!(u_prev && p_prev)) { CHK(download_vec(c, c->xprev.p, cur)); keep = &cur; }
+    pack_vec(c, u_prev, p_prev, h, keep);
+    CHK(upload_vec(c, h, c->xprev.p));
+    if (u_prev) c->mom_valid = false;
+  }
+  if (u || p) {
+    const std::vector<double> *keep = nullptr;
+    if (!(u && p)) { CHK(download_vec(c, c->x.p, cur)); keep = &cur; }
+    pack_vec(c, u, p, h, keep);
+    CHK(upload_vec(c, h, c->x.p));
+  }
+  c->state_set = true;
+  return 0;
+}
+
+int cfdh_get_solution(cfdh_ctx *c, double *u, double *p) {
+  if (!c) return CFDH_E_ARG;
+  std::vector<double> h;
+  CHK(download_vec(c, c->x.p, h));
+  unpack_vec(c, h, u, p);
+  return 0;
+}
+
+int cfdh_get_residual(cfdh_ctx *c, double *ru, double *rp) {
+  if (!c) return CFDH_E_ARG;
+  std::vector<double> h;
+  CHK(download_vec(c, c->F.p, h));
+  // ghost entries of F are not defined: report zeros there
+  for (size_t k = 3 * (size_t)c->nvo; k < h.size(); k++) h[k] = 0.0;
+  unpack_vec(c, h, ru, rp);
+  return 0;
+}
+
+int cfdh_advance(cfdh_ctx *c) {
+  if (!c) return CFDH_E_ARG;
+  CHK(v_copy(c, c->NL, c->x.p, c->xprev.p));
+  c->mom_valid = false;
+  return 0;
+}
+
+int cfdh_assemble(cfdh_ctx *c, int want_jacobian) {
+  if (!c) return CFDH_E_ARG;
+  if (!c->params_set) return cfdh_fail(c, CFDH_E_STATE, "cfdh_set_params was not called");
+  CHK(cfdh_prepare_assembly(c));
+  CHK(comm_halo(c, c->x.p));
+  CHK(k_assemble(c, c->x.p, want_jacobian ? 1 : 2));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int cfdh_get_csr(cfdh_ctx *c, int64_t *nnz, int32_t *rowptr, int32_t *col, double *vals) {
+  if (!c || !nnz) return CFDH_E_ARG;
+  *nnz = 9ll * c->nnzv;
+  if (!rowptr && !col && !vals) return 0;
+  if (!rowptr || !col || !vals) return cfdh_fail(c, CFDH_E_ARG, "pass all of rowptr/col/vals or none");
+  if (!c->jac_valid) return cfdh_fail(c, CFDH_E_STATE, "no Jacobian assembled yet");
+  std::vector<double> a00, a01, a10, a11;
+  CHK(cfdh_download_blocks(c, a00, a01, a10, a11));
+  const int nvo = c->nvo, nv = c->nv;
+  // rows in user numbering: u rows 2*v+i (v < nvo), then p rows 2*nvo+v
+  int64_t pos = 0;
+  std::vector<std::pair<int, int>> ord;  // (user column vertex, slot k)
+  auto emit_rows = [&](int kind) {
+    for (int vu = 0; vu < nvo; vu++) {
+      const int r = c->perm[vu];
+      ord.clear();
+      for (int k = c->h_vptr[r]; k < c->h_vptr[r + 1]; k++) ord.push_back({c->iperm[c->h_vcol[k]], k});
+      std::sort(ord.begin(), ord.end());
+      const int nrow = kind == 0 ? 2 : 1;
+      for (int i = 0; i < nrow; i++) {
+        const int row = kind == 0 ? 2 * vu + i : 2 * nvo + vu;
+        rowptr[row] = (int32_t)pos;
+        for (auto &e : ord)
+          for (int j = 0; j < 2; j++) {
+            col[pos] = 2 * e.first + j;
+            vals[pos] = kind == 0 ? a00[4 * (size_t)e.second + 2 * i + j] : a10[2 * (size_t)e.second + j];
+            pos++;
+          }
+        for (auto &e : ord) {
+          col[pos] = 2 * nv + e.first;
+          vals[pos] = kind == 0 ? a01[2 * (size_t)e.second + i] : a11[e.second];
+          pos++;
+        }
+      }
+    }
+  };
+  emit_rows(0);
+  emit_rows(1);
+  rowptr[3 * nvo] = (int32_t)pos;
+  return 0;
+}
+
+int cfdh_spmv(cfdh_ctx *c, const double *x, double *y) {
+  if (!c || !x || !y) return CFDH_E_ARG;
+  if (!c->jac_valid) return cfdh_fail(c, CFDH_E_STATE, "no Jacobian assembled yet");
+  std::vector<double> h;
+  pack_vec(c, x, x + 2 * (size_t)c->nv, h, nullptr);
+  CHK(upload_vec(c, h, c->xt.p));
+  CHK(k_spmv_full(c, c->xt.p, c->dvec.p));
+  std::vector<double> o;
+  CHK(download_vec(c, c->dvec.p, o));
+  for (int k = 0; k < c->nvo; k++) {
+    const int v = c->iperm[k];
+    y[2 * (size_t)v] = o[2 * (size_t)k]; y[2 * (size_t)v + 1] = o[2 * (size_t)k + 1];
+    y[2 * (size_t)c->nvo + v] = o[2 * (size_t)c->nvo + k];
+  }
+  return 0;
+}
+
+int cfdh_solve_step(cfdh_ctx *c, cfdh_stats *stats) {
+  if (!c) return CFDH_E_ARG;
+  cfdh_stats st;
+  c->err.clear();
+  int rc = cfdh_newton_step(c, &st);
+  if (stats) *stats = st;
+  return rc;
+}
+
+int cfdh_functional(cfdh_ctx *c, int kind, int marker, double *out) {
+  if (!c || !out) return CFDH_E_ARG;
+  return k_functional(c, kind, marker, out);
+}
+
+int cfdh_profile_enable(cfdh_ctx *c, int on) {
+  if (!c) return CFDH_E_ARG;
+  prof_flush(c);
+  c->prof_on = on != 0;
+  return 0;
+}
+int cfdh_profile_get(cfdh_ctx *c, int kind, double *total_ms, int64_t *launches) {
+  if (!c || kind < 0 || kind >= 8) return CFDH_E_ARG;
+  prof_flush(c);
+  if (total_ms) *total_ms = c->prof[kind].total_ms;
+  if (launches) *launches = c->prof[kind].launches;
+  return 0;
+}
+int cfdh_profile_reset(cfdh_ctx *c) {
+  if (!c) return CFDH_E_ARG;
+  prof_flush(c);
+  for (auto &p : c->prof) { p.total_ms = 0; p.launches = 0; }
+  return 0;
+}
+
+int64_t cfdh_info(const cfdh_ctx *c, int what) {
+  if (!c) return -1;
+  switch (what) {
+    case 0: return c->nvo;
+    case 1: return c->nv;
+    case 2: return c->nc;
+    case 3: return c->nnzv;
+    case 4: return c->sp_nnz;
+    case 5: return c->ninc;
+    case 6: return (int64_t)c->amg.size();
+    case 7: return c->nblk;
+    default: return -1;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+// Internal declarations of libcfdh.so (gfx950).  See include/cfdh.h for the ABI
+// and DESIGN.md for the data layout.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cfdh.h"
+
+#define CFDH_MAX_INC 256   // incidences (= threads) per assembly workgroup
+#define CFDH_MAX_SLOTS 448 // vertex-graph slots per assembly workgroup (LDS 72 B each)
+#define CFDH_MAX_ROWS 128  // rows per assembly workgroup
+
+template <class T>
+struct dbuf {
+  T *p = nullptr;
+  size_t n = 0;
+  dbuf() = default;
+  dbuf(const dbuf &) = delete;
+  dbuf &operator=(const dbuf &) = delete;
+  ~dbuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    if (count == n && p) return hipSuccess;
+    release();
+    if (count == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  hipError_t upload(const std::vector<T> &h, hipStream_t s) {
+    hipError_t e = alloc(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+  }
+  hipError_t zero(hipStream_t s) { return n ? hipMemsetAsync(p, 0, n * sizeof(T), s) : hipSuccess; }
+};
+
+struct CsrHost {
+  int n = 0, m = 0;
+  std::vector<int> rowptr, col;
+  std::vector<double> val;
+  int nnz() const { return (int)col.size(); }
+};
+
+struct CsrDev {
+  int n = 0, m = 0, nnz = 0;
+  dbuf<int> rowptr, col;
+  dbuf<double> val;
+};
+
+struct AmgLevel {
+  int n = 0;
+  CsrDev A, P, R;
+  dbuf<double> dinv, x, b, r, d0, d1;
+  double lmax = 0, lmin = 0;
+};
+
+struct ProfSlot {
+  double total_ms = 0;
+  long long launches = 0;
+};
+
+struct cfdh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // sizes (local part): nv = nvo owned + ng ghosts
+  int nv = 0, nvo = 0, ng = 0, nc = 0, nfac = 0;
+  int NL = 0;   // vector length incl. ghost tail = 3*nvo + 3*ng
+  int NO = 0;   // owned compact length 3*nvo
+
+  // user <-> internal vertex numbering
+  std::vector<int> perm;   // user -> internal
+  std::vector<int> iperm;  // internal -> user
+  std::vector<int> h_cells;       // internal ids, [nc][3]
+  std::vector<int> cell_user;     // internal cell -> user cell
+  std::vector<double> h_coords;   // internal order [nv][2]
+  std::vector<int> fac_cell, fac_local, fac_marker;  // internal cell ids
+
+  bool params_set = false;
+  double dt = 0, rho = 0, mu = 0, muf = 0, f[2] = {0, 0};
+  cfdh_options opt;
+
+  // device mesh
+  dbuf<double> coords;          // [nv][2]
+  dbuf<int> cells;              // [nc][3]
+  dbuf<unsigned char> cflag;    // [nc] exterior-facet bits
+  dbuf<double> mom;             // [nc][8]: M00 M01 M02 M11 M12 M22 L pad
+  dbuf<unsigned char> cell_owned;  // [nc] 1 when this rank integrates the cell in global functionals
+  bool mom_valid = false;
+
+  // vertex graph of owned rows (columns may be ghosts), block values
+  std::vector<int> h_vptr, h_vcol, h_vdiag;
+  int nnzv = 0;
+  dbuf<int> vptr, vcol, vdiag;
+  dbuf<double> A00, A01, A10, A11;  // [nnzv][4], [nnzv][2], [nnzv][2], [nnzv]
+  bool jac_valid = false;
+
+  // incidences (row vertex, cell), grouped in workgroup blocks of whole rows
+  int ninc = 0, nblk = 0;
+  dbuf<int> inc_cell;        // cell*4 + local index of the row vertex
+  dbuf<int> inc_row;         // row (internal owned vertex)
+  dbuf<unsigned> inc_slot;   // 3 x 8 bit: slot of column b' within the row (rotated order)
+  dbuf<unsigned> inc_rank;   // 3 x 8 bit: accumulation round of block b'
+  dbuf<int> blk_row;         // [nblk+1]
+  dbuf<int> blk_inc;         // [nblk+1] first incidence of the block
+  dbuf<int> blk_maxrank;     // [nblk]
+
+  // Dirichlet data (host master copies in internal numbering)
+  std::vector<unsigned char> h_bcflag;  // bit0 ux, bit1 uy, bit2 p
+  std::vector<double> h_bcval;          // [nv][3]
+  std::vector<double> h_bcmult;         // [nv][3]
+  bool bc_dirty = true;
+  int n_pbc = 0;
+  dbuf<unsigned char> bcflag;
+  dbuf<double> bcval, bcmult;
+
+  // exterior facets on device (functionals)
+  dbuf<int> d_fac_cell, d_fac_local, d_fac_marker;
+
+  // state: layout [u owned 2*nvo | p owned nvo | ghosts 3*ng (ux,uy,p)]
+  dbuf<double> x, xt, xprev, F, dvec;
+  bool state_set = false;
+
+  // reductions
+  dbuf<double> red_partial, red_out;
+  double *h_pinned = nullptr;  // pinned host scratch for scalar read-back
+  int red_blocks = 0;
+
+  // Krylov workspace
+  int kry_m = 0;
+  dbuf<double> kV, kZ, kw, kh;  // V[(m+1)*NL], Z[m*NL], w[NL], h[2*(m+1)+2]
+  dbuf<double> ky;
+
+  // preconditioner
+  dbuf<double> dinvA;          // 1/diag(A00), [2*nvo]
+  double lmaxA = 0;
+  dbuf<double> pu0, pu1, pu2, pr, pp0, pp1;  // PC work vectors
+  dbuf<double> prand;                        // fixed start vector of the power iteration
+  std::vector<AmgLevel *> amg;
+  dbuf<double> coarse_inv;  // dense inverse of the coarsest operator
+  int coarse_n = 0;
+  bool pc_valid = false;
+  int pc_its_ref = 0;       // FGMRES iterations right after the last refresh
+  int steps_since_refresh = 0;
+  int singular = 0;         // constant pressure in the null space (tested per step)
+  long long sp_nnz = 0;
+
+  // halo / comm
+  int nnbr = 0;
+  std::vector<int> nbr_rank;
+  std::vector<long long> send_ptr, recv_ptr;
+  dbuf<int> send_idx;        // internal owned vertex ids, concatenated per neighbour
+  dbuf<double> send_buf;     // 3 doubles per send vertex
+  std::vector<double> h_send, h_recv;
+  int rank = 0, nranks = 1;
+  double nvo_global = 0;     // number of pressure dofs over all ranks
+  void *nccl_comm = nullptr;
+  cfdh_allreduce_fn cb_ar = nullptr;
+  cfdh_exchange_fn cb_ex = nullptr;
+  void *cb_user = nullptr;
+
+  // profiling
+  bool prof_on = false;
+  ProfSlot prof[8];
+  std::vector<hipEvent_t> ev_pool;
+  struct EvRec { int kind; hipEvent_t a, b; };
+  std::vector<EvRec> ev_pending;
+  size_t ev_next = 0;
+
+  cfdh_stats last_stats;
+};
+
+// ---- error helpers -----------------------------------------------------------
+int cfdh_fail(cfdh_ctx *c, int code, const char *fmt, ...);
+#define HIPCHK(c, call)                                                                           \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) return cfdh_fail((c), CFDH_E_HIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                           __FILE__, __LINE__);                                   \
+  } while (0)
+#define CHK(call)            \
+  do {                       \
+    int r_ = (call);         \
+    if (r_ != 0) return r_;  \
+  } while (0)
+
+// ---- setup (cfdh_setup.cpp) ------------------------------------------------------
+int cfdh_build_mesh(cfdh_ctx *c, int64_t nv, int64_t nvo, int64_t nc, const int32_t *cells, const double *coords,
+                    int64_t nfac, const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker);
+int cfdh_amg_setup(cfdh_ctx *c, const CsrHost &Sp);  // builds c->amg from the host Schur matrix
+
+// ---- kernels (cfdh_kernels.hip) ----------------------------------------------------
+void prof_begin(cfdh_ctx *c, int kind);
+void prof_end(cfdh_ctx *c, int kind);
+void prof_flush(cfdh_ctx *c);
+
+int k_upload_quadrature(cfdh_ctx *c);
+int k_halo_pack(cfdh_ctx *c, const double *vec);
+int v_pointwise_mult(cfdh_ctx *c, int n, const double *a, const double *b, double *out);
+int k_moments(cfdh_ctx *c);
+int k_assemble(cfdh_ctx *c, const double *xstate, int mode);  // mode 0: F only, 1: F+J, 2: F with lifting (no J write)
+int k_spmv_full(cfdh_ctx *c, const double *x, double *y);
+int k_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b, double alpha);  // y = b*? see .hip
+int k_extract_diag(cfdh_ctx *c);
+int k_cheb_a00(cfdh_ctx *c, const double *b, double *x);  // x = Cheb_k(A00) b, zero initial guess
+int k_csr_spmv(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mode, const double *b);  // mode 0: y=Ax, 1: y=b-Ax, 2: y+=Ax
+int k_amg_vcycle(cfdh_ctx *c, const double *b, double *x);
+int k_nullspace_test(cfdh_ctx *c, double *nrm);
+
+// vector ops on [0,n)
+int v_copy(cfdh_ctx *c, int n, const double *x, double *y);
+int v_zero(cfdh_ctx *c, int n, double *y);
+int v_axpy(cfdh_ctx *c, int n, double a, const double *x, double *y);
+int v_waxpy(cfdh_ctx *c, int n, double a, const double *x, const double *y, double *w);  // w = y + a x
+int v_scale(cfdh_ctx *c, int n, double a, double *x);
+int v_dot(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host);   // with comm reduction
+int v_norm2(cfdh_ctx *c, int n, const double *x, double *out_host);
+int v_norminf_diff(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host);  // y may be null
+int v_sub_mean(cfdh_ctx *c, int n, double *p);  // remove the (global) mean of p[0..n)
+int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev);
+int v_multiaxpy(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, double *w);  // w -= sum h_i V_i
+int v_norm_to_dev(cfdh_ctx *c, int n, const double *w, double *out_dev);  // ||w|| (global) into device scalar
+int v_scale_inv_dev(cfdh_ctx *c, int n, const double *w, const double *nrm_dev, double *v);  // v = w / *nrm
+int v_lincomb(cfdh_ctx *c, int n, const double *Z, int ld, int nvec, const double *y_dev, double *x);  // x += sum y_k Z_k
+int v_pack_state(cfdh_ctx *c, const double *u_user, const double *p_user, double *dst);  // host staging helpers
+int k_functional(cfdh_ctx *c, int kind, int marker, double *out);
+
+// ---- comm (cfdh_comm.cpp) ----------------------------------------------------------
+int comm_allreduce_dev(cfdh_ctx *c, double *dev, int n, int op);  // in-stream
+int comm_halo(cfdh_ctx *c, double *vec);                          // fill the ghost tail of vec
+int comm_finalize(cfdh_ctx *c);
+
+// ---- solver (cfdh_solver.cpp) ------------------------------------------------------
+int cfdh_pc_update(cfdh_ctx *c, bool force_refresh);
+int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z);
+int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its, int *reason);
+int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st);
+int cfdh_download_blocks(cfdh_ctx *c, std::vector<double> &a00, std::vector<double> &a01, std::vector<double> &a10,
+                         std::vector<double> &a11);

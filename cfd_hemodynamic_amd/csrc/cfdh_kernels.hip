@@ -1,0 +1,1134 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the stabilized_schur hot path.
+//
+//  * k_moments    : tau / tau_LSIC moments per cell (stabilized_schur.py:100-118)
+//  * asm_kernel   : fused element residual + Jacobian, one lane per
+//                   (row vertex, cell) incidence, accumulation in LDS in fixed
+//                   rounds (bitwise reproducible, no global atomics), coalesced
+//                   write-out of whole CSR row segments (stabilized_schur.py:67-123,
+//                   144-175,185-189)
+//  * spmv kernels : 8 lanes per vertex row over the block CSR, DPP reductions
+//  * Chebyshev / AMG / vector kernels for the Krylov solver
+//
+// Everything is HBM-bound fp64 stream/gather work; MFMA is not used (nothing
+// here is a dense contraction).  Algebra: SURVEY.md Appendix A / DESIGN.md.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "cfdh_internal.hpp"
+#include "quad_tri.h"
+
+#define TPB 256
+
+__constant__ double d_qw[CFDH_NQ];
+__constant__ double d_ql[CFDH_NQ][3];
+
+int k_upload_quadrature(cfdh_ctx *c) {
+  HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(d_qw), CFDH_QW, sizeof(CFDH_QW)));
+  HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(d_ql), CFDH_QL, sizeof(CFDH_QL)));
+  return 0;
+}
+
+// ---------------------------------------------------------------- profiling
+void prof_begin(cfdh_ctx *c, int kind) {
+  if (!c->prof_on) return;
+  if (c->ev_next + 2 > c->ev_pool.size()) {
+    for (int i = 0; i < 64; i++) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->ev_pool.push_back(e); }
+  }
+  cfdh_ctx::EvRec r;
+  r.kind = kind; r.a = c->ev_pool[c->ev_next++]; r.b = c->ev_pool[c->ev_next++];
+  (void)hipEventRecord(r.a, c->stream);
+  c->ev_pending.push_back(r);
+}
+void prof_end(cfdh_ctx *c, int kind) {
+  if (!c->prof_on || c->ev_pending.empty()) return;
+  (void)kind;
+  (void)hipEventRecord(c->ev_pending.back().b, c->stream);
+  if (c->ev_pending.size() >= 4096) prof_flush(c);
+}
+void prof_flush(cfdh_ctx *c) {
+  if (c->ev_pending.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &r : c->ev_pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof[r.kind].total_ms += ms; c->prof[r.kind].launches++; }
+  }
+  c->ev_pending.clear();
+  c->ev_next = 0;
+}
+
+// ---------------------------------------------------------------- wave-level helpers
+template <int CTRL>
+__device__ __forceinline__ double dpp_shuffle(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over aligned groups of 8 lanes (result in every lane of the group)
+__device__ __forceinline__ double group8_sum(double v) {
+  v += dpp_shuffle<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_shuffle<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_shuffle<0x141>(v);  // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes of the wave (result in every lane)
+__device__ __forceinline__ double wave_sum(double v) {
+  v = group8_sum(v);
+  v += dpp_shuffle<0x140>(v);  // row_mirror -> sums of 16
+  return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+__device__ __forceinline__ double wave_max(double v) {
+  v = fmax(v, dpp_shuffle<0xB1>(v));
+  v = fmax(v, dpp_shuffle<0x4E>(v));
+  v = fmax(v, dpp_shuffle<0x141>(v));
+  v = fmax(v, dpp_shuffle<0x140>(v));
+  return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
+}
+// block (256 threads) sum; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double *sh /*[4]*/) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ double block_max(double v, double *sh) {
+  v = wave_max(v);
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double r = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+  __syncthreads();
+  return r;
+}
+
+// vector layout: [u owned 2*nvo | p owned nvo | ghosts (ux,uy,p) x ng]
+__device__ __forceinline__ int uoff(int w, int nvo) { return w < nvo ? 2 * w : 3 * w; }
+__device__ __forceinline__ int poff(int w, int nvo) { return w < nvo ? 2 * nvo + w : 3 * w + 2; }
+
+// ---------------------------------------------------------------- tau moments
+// M_ab = int_K tau l_a l_b, L = int_K tau_L on the 49-point rule; tau, tau_L
+// depend on u_prev only (stabilized_schur.py:91-93,100-108,116-118) so this
+// runs once per time step.  One lane per cell, coalesced 64-B records out.
+__global__ __launch_bounds__(TPB) void moments_kernel(int nc, int nvo, const int *__restrict__ cells,
+                                                      const double *__restrict__ coords,
+                                                      const double *__restrict__ un, double *__restrict__ mom,
+                                                      double dt, double nu) {
+  int e = blockIdx.x * TPB + threadIdx.x;
+  if (e >= nc) return;
+  int v0 = cells[3 * e], v1 = cells[3 * e + 1], v2 = cells[3 * e + 2];
+  double2 X0 = *(const double2 *)(coords + 2 * v0), X1 = *(const double2 *)(coords + 2 * v1), X2 = *(const double2 *)(coords + 2 * v2);
+  double u0x = un[uoff(v0, nvo)], u0y = un[uoff(v0, nvo) + 1];
+  double u1x = un[uoff(v1, nvo)], u1y = un[uoff(v1, nvo) + 1];
+  double u2x = un[uoff(v2, nvo)], u2y = un[uoff(v2, nvo) + 1];
+  double det = (X1.x - X0.x) * (X2.y - X0.y) - (X1.y - X0.y) * (X2.x - X0.x);
+  double area = 0.5 * fabs(det);
+  double d01 = hypot(X0.x - X1.x, X0.y - X1.y), d12 = hypot(X1.x - X2.x, X1.y - X2.y), d20 = hypot(X2.x - X0.x, X2.y - X0.y);
+  double h = fmax(d01, fmax(d12, d20));
+  double ih2 = 1.0 / (h * h);
+  double t2 = 4.0 / (dt * dt), t3 = 16.0 * nu * nu * ih2 * ih2;
+  double hr = h / (2.0 * nu);
+  double m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0, L = 0;
+#pragma unroll 7
+  for (int q = 0; q < CFDH_NQ; q++) {
+    double l0 = d_ql[q][0], l1 = d_ql[q][1], l2 = d_ql[q][2], wq = d_qw[q];
+    double ux = l0 * u0x + l1 * u1x + l2 * u2x;
+    double uy = l0 * u0y + l1 * u1y + l2 * u2y;
+    double s = ux * ux + uy * uy;
+    double t1 = fmax(4.0 * s, 1e-30) * ih2;  // (max(2|u|, eps))^2 / h^2, eps = 1e-15
+    double tau = 1.0 / sqrt(t1 + t2 + t3);
+    double vn = sqrt(s);
+    double Re = vn * hr;
+    double z = (Re <= 3.0) ? Re * (1.0 / 3.0) : 1.0;
+    double tl = vn * h * z * 0.5;
+    double w = wq * tau;
+    m00 += w * l0 * l0; m01 += w * l0 * l1; m02 += w * l0 * l2;
+    m11 += w * l1 * l1; m12 += w * l1 * l2; m22 += w * l2 * l2;
+    L += wq * tl;
+  }
+  double4 *o = (double4 *)(mom + 8 * (size_t)e);
+  o[0] = make_double4(area * m00, area * m01, area * m02, area * m11);
+  o[1] = make_double4(area * m12, area * m22, area * L, 0.0);
+}
+
+int k_moments(cfdh_ctx *c) {
+  prof_begin(c, 2);
+  hipLaunchKernelGGL(moments_kernel, dim3((c->nc + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nc, c->nvo, c->cells.p,
+                     c->coords.p, c->xprev.p, c->mom.p, c->dt, c->mu / c->rho);
+  prof_end(c, 2);
+  HIPCHK(c, hipGetLastError());
+  c->mom_valid = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------- fused assembly
+struct AsmArgs {
+  const double *coords, *mom, *x, *un, *bcval, *bcmult;
+  const int *cells, *vptr, *vdiag, *inc_cell, *inc_row, *blk_row, *blk_inc, *blk_maxrank;
+  const unsigned *inc_slot, *inc_rank;
+  const unsigned char *cflag, *bcflag;
+  double *A00, *A01, *A10, *A11, *F;
+  int nvo;
+  double dt, rho, mu, muf, fx, fy;
+};
+
+// MODE 0: residual only; 1: residual + Jacobian; 2: residual with lifting (Jacobian in registers only)
+template <int MODE>
+__global__ __launch_bounds__(CFDH_MAX_INC) void asm_kernel(AsmArgs p) {
+  constexpr bool JAC = (MODE != 0);
+  constexpr bool WJ = (MODE == 1);
+  __shared__ double sA00[WJ ? CFDH_MAX_SLOTS * 4 : 1];
+  __shared__ double sA01[WJ ? CFDH_MAX_SLOTS * 2 : 1];
+  __shared__ double sA10[WJ ? CFDH_MAX_SLOTS * 2 : 1];
+  __shared__ double sA11[WJ ? CFDH_MAX_SLOTS : 1];
+  __shared__ double sF[CFDH_MAX_ROWS * 3];
+  const int t = threadIdx.x, blk = blockIdx.x;
+  const int row0 = p.blk_row[blk], row1 = p.blk_row[blk + 1];
+  const int inc0 = p.blk_inc[blk], ninc = p.blk_inc[blk + 1] - inc0;
+  const int s0 = p.vptr[row0], nslots = p.vptr[row1] - s0;
+  const int nrows = row1 - row0;
+  const int maxr = p.blk_maxrank[blk];
+  const int nvo = p.nvo;
+  if (WJ) {
+    for (int i = t; i < nslots * 4; i += CFDH_MAX_INC) sA00[i] = 0.0;
+    for (int i = t; i < nslots * 2; i += CFDH_MAX_INC) { sA01[i] = 0.0; sA10[i] = 0.0; }
+    for (int i = t; i < nslots; i += CFDH_MAX_INC) sA11[i] = 0.0;
+  }
+  for (int i = t; i < nrows * 3; i += CFDH_MAX_INC) sF[i] = 0.0;
+
+  const bool active = t < ninc;
+  double Fr[3] = {0, 0, 0};
+  double J00[3][2][2], J01[3][2], J10[3][2], J11[3];
+  int sl[3] = {0, 0, 0}, rk[3] = {0, 0, 0}, rloc = 0;
+  if (active) {
+    const int k = inc0 + t;
+    const int ce = p.inc_cell[k];
+    const int e = ce >> 2, a = ce & 3;
+    const int row = p.inc_row[k];
+    const unsigned slots = p.inc_slot[k], ranks = p.inc_rank[k];
+    rloc = row - row0;
+    const int sbase = p.vptr[row] - s0;
+    sl[0] = sbase + (slots & 255); sl[1] = sbase + ((slots >> 8) & 255); sl[2] = sbase + ((slots >> 16) & 255);
+    rk[0] = ranks & 255; rk[1] = (ranks >> 8) & 255; rk[2] = (ranks >> 16) & 255;
+    const int c0 = p.cells[3 * e], c1 = p.cells[3 * e + 1], c2 = p.cells[3 * e + 2];
+    const int v0 = a == 0 ? c0 : (a == 1 ? c1 : c2);
+    const int v1 = a == 0 ? c1 : (a == 1 ? c2 : c0);
+    const int v2 = a == 0 ? c2 : (a == 1 ? c0 : c1);
+    const int vv[3] = {v0, v1, v2};
+    unsigned cf = p.cflag[e];
+    cf = ((cf >> a) | (cf << (3 - a))) & 7u;
+    // moments, rotated
+    const double4 q0 = *(const double4 *)(p.mom + 8 * (size_t)e);
+    const double4 q1 = *(const double4 *)(p.mom + 8 * (size_t)e + 4);
+    const double o00 = q0.x, o01 = q0.y, o02 = q0.z, o11 = q0.w, o12 = q1.x, o22 = q1.y, Lm = q1.z;
+    double M[3][3];
+    M[0][0] = a == 0 ? o00 : (a == 1 ? o11 : o22);
+    M[1][1] = a == 0 ? o11 : (a == 1 ? o22 : o00);
+    M[2][2] = a == 0 ? o22 : (a == 1 ? o00 : o11);
+    M[0][1] = M[1][0] = a == 0 ? o01 : (a == 1 ? o12 : o02);
+    M[0][2] = M[2][0] = a == 0 ? o02 : (a == 1 ? o01 : o12);
+    M[1][2] = M[2][1] = a == 0 ? o12 : (a == 1 ? o02 : o01);
+    // geometry
+    double X[3][2], ue[3][2], une[3][2], pe[3];
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      const double2 xx = *(const double2 *)(p.coords + 2 * vv[b]);
+      X[b][0] = xx.x; X[b][1] = xx.y;
+      const int uo = uoff(vv[b], nvo), po = poff(vv[b], nvo);
+      ue[b][0] = p.x[uo]; ue[b][1] = p.x[uo + 1]; pe[b] = p.x[po];
+      une[b][0] = p.un[uo]; une[b][1] = p.un[uo + 1];
+    }
+    const double det = (X[1][0] - X[0][0]) * (X[2][1] - X[0][1]) - (X[1][1] - X[0][1]) * (X[2][0] - X[0][0]);
+    const double idet = 1.0 / det;
+    double g[3][2];
+    g[0][0] = (X[1][1] - X[2][1]) * idet; g[0][1] = (X[2][0] - X[1][0]) * idet;
+    g[1][0] = (X[2][1] - X[0][1]) * idet; g[1][1] = (X[0][0] - X[2][0]) * idet;
+    g[2][0] = (X[0][1] - X[1][1]) * idet; g[2][1] = (X[1][0] - X[0][0]) * idet;
+    const double area = 0.5 * fabs(det);
+    const double rho = p.rho, mu = p.mu, idt = 1.0 / p.dt;
+    double ub[3][2], w[3][2], G[2][2] = {{0, 0}, {0, 0}}, gp[2] = {0, 0};
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        ub[b][i] = 0.5 * (ue[b][i] + une[b][i]);
+        w[b][i] = (ue[b][i] - une[b][i]) * idt;
+      }
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        gp[i] += pe[b] * g[b][i];
+#pragma unroll
+        for (int j = 0; j < 2; j++) G[i][j] += g[b][i] * ub[b][j];
+      }
+    const double divu = G[0][0] + G[1][1];
+    double Cn[3][2], R[3][2], beta[3][3], mt[3], Q[3][2];
+    const double ff[2] = {p.fx, p.fy};
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        Cn[b][j] = ub[b][0] * G[0][j] + ub[b][1] * G[1][j];
+        R[b][j] = rho * (w[b][j] + Cn[b][j]) + gp[j] - rho * ff[j];
+      }
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) beta[d][b] = ub[d][0] * g[b][0] + ub[d][1] * g[b][1];
+    double T = 0;
+#pragma unroll
+    for (int b = 0; b < 3; b++) { mt[b] = M[b][0] + M[b][1] + M[b][2]; T += mt[b]; }
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int i = 0; i < 2; i++) Q[d][i] = M[0][d] * R[0][i] + M[1][d] * R[1][i] + M[2][d] * R[2][i];
+    const double E01 = 0.5 * (G[0][1] + G[1][0]);
+    const double E[2][2] = {{G[0][0], E01}, {E01, G[1][1]}};
+    const double pbar = (pe[0] + pe[1] + pe[2]) * (1.0 / 3.0);
+    const double mab0[3] = {area * (2.0 / 12.0), area * (1.0 / 12.0), area * (1.0 / 12.0)};
+    // ---- residual rows of local vertex 0
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      double v = 0;
+#pragma unroll
+      for (int b = 0; b < 3; b++) v += rho * mab0[b] * (w[b][i] + Cn[b][i]);
+      v -= rho * ff[i] * area * (1.0 / 3.0);
+      v += area * (2.0 * mu * (E[i][0] * g[0][0] + E[i][1] * g[0][1]) - pbar * g[0][i]);
+#pragma unroll
+      for (int d = 0; d < 3; d++) v += beta[d][0] * Q[d][i];
+      v += rho * Lm * divu * g[0][i];
+      Fr[i] = v;
+    }
+    {
+      double v = area * (1.0 / 3.0) * divu;
+#pragma unroll
+      for (int b = 0; b < 3; b++) v += mt[b] * (R[b][0] * g[0][0] + R[b][1] * g[0][1]) / rho;
+      Fr[2] = v;
+    }
+    // ---- Jacobian row block of local vertex 0
+    if (JAC) {
+      double MBa[3], mtB[3];
+#pragma unroll
+      for (int cidx = 0; cidx < 3; cidx++) MBa[cidx] = M[cidx][0] * beta[0][0] + M[cidx][1] * beta[1][0] + M[cidx][2] * beta[2][0];
+#pragma unroll
+      for (int b = 0; b < 3; b++) mtB[b] = mt[0] * beta[0][b] + mt[1] * beta[1][b] + mt[2] * beta[2][b];
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const double mBa = mab0[0] * beta[0][b] + mab0[1] * beta[1][b] + mab0[2] * beta[2][b];
+        const double BMBa = beta[0][b] * MBa[0] + beta[1][b] * MBa[1] + beta[2][b] * MBa[2];
+        const double gg0b = g[0][0] * g[b][0] + g[0][1] * g[b][1];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            const double dij = (i == j) ? 1.0 : 0.0;
+            double v = rho * mab0[b] * dij * idt;
+            v += rho * 0.5 * (mab0[b] * G[j][i] + dij * mBa);
+            v += area * mu * 0.5 * (g[b][i] * g[0][j] + gg0b * dij);
+            v += rho * ((dij * idt + 0.5 * G[j][i]) * MBa[b] + 0.5 * dij * BMBa);
+            v += 0.5 * g[0][j] * Q[b][i];
+            v += rho * Lm * 0.5 * g[b][j] * g[0][i];
+            J00[b][i][j] = v;
+          }
+          J01[b][i] = -area * (1.0 / 3.0) * g[0][i] + g[b][i] * mtB[0];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const double Gg = G[j][0] * g[0][0] + G[j][1] * g[0][1];
+          J10[b][j] = area * (1.0 / 6.0) * g[b][j] + mt[b] * (g[0][j] * idt + 0.5 * Gg) + 0.5 * g[0][j] * mtB[b];
+        }
+        J11[b] = T * gg0b / rho;
+      }
+    }
+    // ---- exterior facets that contain local vertex 0 (facets 1 and 2)
+    if (cf & 6u) {
+#pragma unroll
+      for (int f = 1; f < 3; f++) {
+        if (!((cf >> f) & 1u)) continue;
+        const int other = (f == 1) ? 2 : 1;
+        const double gl = hypot(g[f][0], g[f][1]);
+        const double n[2] = {-g[f][0] / gl, -g[f][1] / gl};
+        const double elen = 2.0 * area * gl;
+        const double pint = (2.0 * pe[0] + pe[other]) * (1.0 / 6.0);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          const double Gn = G[i][0] * n[0] + G[i][1] * n[1];
+          Fr[i] += n[i] * elen * pint - p.muf * Gn * elen * 0.5;
+          if (JAC) {
+            J01[0][i] += n[i] * elen * (2.0 / 6.0);
+            J01[other][i] += n[i] * elen * (1.0 / 6.0);
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+              for (int j = 0; j < 2; j++) J00[b][i][j] -= p.muf * 0.25 * g[b][i] * n[j] * elen;
+          }
+        }
+      }
+    }
+    // ---- Dirichlet: lifting F += J[:,bc](g - x), zero bc columns and rows
+    const unsigned fl0 = p.bcflag[v0], fl1 = p.bcflag[v1], fl2 = p.bcflag[v2];
+    if (fl0 | fl1 | fl2) {
+      const unsigned flb[3] = {fl0, fl1, fl2};
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        if (!flb[b]) continue;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          if ((flb[b] >> j) & 1u) {
+            if (JAC) {
+              const double gx = p.bcval[3 * vv[b] + j] - ue[b][j];
+              if (MODE == 2 || gx != 0.0) { Fr[0] += J00[b][0][j] * gx; Fr[1] += J00[b][1][j] * gx; Fr[2] += J10[b][j] * gx; }
+              J00[b][0][j] = 0.0; J00[b][1][j] = 0.0; J10[b][j] = 0.0;
+            }
+          }
+        if (flb[b] & 4u) {
+          if (JAC) {
+            const double gx = p.bcval[3 * vv[b] + 2] - pe[b];
+            if (MODE == 2 || gx != 0.0) { Fr[0] += J01[b][0] * gx; Fr[1] += J01[b][1] * gx; Fr[2] += J11[b] * gx; }
+            J01[b][0] = 0.0; J01[b][1] = 0.0; J11[b] = 0.0;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+        if ((fl0 >> i) & 1u) {
+          Fr[i] = 0.0;
+          if (JAC) {
+#pragma unroll
+            for (int b = 0; b < 3; b++) { J00[b][i][0] = 0.0; J00[b][i][1] = 0.0; J01[b][i] = 0.0; }
+          }
+        }
+      if (fl0 & 4u) {
+        Fr[2] = 0.0;
+        if (JAC) {
+#pragma unroll
+          for (int b = 0; b < 3; b++) { J10[b][0] = 0.0; J10[b][1] = 0.0; J11[b] = 0.0; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- deterministic accumulation: in round r only the r-th contribution of a slot adds
+  for (int r = 0; r < maxr; r++) {
+    if (active) {
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        if (rk[b] == r) {
+          if (WJ) {
+            const int s = sl[b];
+            sA00[4 * s + 0] += J00[b][0][0]; sA00[4 * s + 1] += J00[b][0][1];
+            sA00[4 * s + 2] += J00[b][1][0]; sA00[4 * s + 3] += J00[b][1][1];
+            sA01[2 * s + 0] += J01[b][0]; sA01[2 * s + 1] += J01[b][1];
+            sA10[2 * s + 0] += J10[b][0]; sA10[2 * s + 1] += J10[b][1];
+            sA11[s] += J11[b];
+          }
+          if (b == 0) { sF[3 * rloc] += Fr[0]; sF[3 * rloc + 1] += Fr[1]; sF[3 * rloc + 2] += Fr[2]; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- Dirichlet rows: diagonal = number of bc objects, F = x - g
+  if (t < nrows) {
+    const int row = row0 + t;
+    const unsigned fl = p.bcflag[row];
+    if (fl) {
+      const int dsl = p.vdiag[row] - s0;
+      if (fl & 1u) { if (WJ) sA00[4 * dsl + 0] = p.bcmult[3 * row]; sF[3 * t] = p.x[2 * row] - p.bcval[3 * row]; }
+      if (fl & 2u) { if (WJ) sA00[4 * dsl + 3] = p.bcmult[3 * row + 1]; sF[3 * t + 1] = p.x[2 * row + 1] - p.bcval[3 * row + 1]; }
+      if (fl & 4u) { if (WJ) sA11[dsl] = p.bcmult[3 * row + 2]; sF[3 * t + 2] = p.x[2 * nvo + row] - p.bcval[3 * row + 2]; }
+    }
+  }
+  __syncthreads();
+  // ---- coalesced write-out of the block's contiguous CSR segment
+  if (WJ) {
+    double *o00 = p.A00 + 4 * (size_t)s0, *o01 = p.A01 + 2 * (size_t)s0, *o10 = p.A10 + 2 * (size_t)s0, *o11 = p.A11 + (size_t)s0;
+    for (int i = t; i < nslots * 2; i += CFDH_MAX_INC) {
+      ((double2 *)o00)[i] = make_double2(sA00[2 * i], sA00[2 * i + 1]);
+    }
+    for (int i = t; i < nslots; i += CFDH_MAX_INC) {
+      ((double2 *)o01)[i] = make_double2(sA01[2 * i], sA01[2 * i + 1]);
+      ((double2 *)o10)[i] = make_double2(sA10[2 * i], sA10[2 * i + 1]);
+      o11[i] = sA11[i];
+    }
+  }
+  for (int i = t; i < nrows; i += CFDH_MAX_INC) {
+    ((double2 *)(p.F + 2 * (size_t)row0))[i] = make_double2(sF[3 * i], sF[3 * i + 1]);
+    p.F[2 * (size_t)nvo + row0 + i] = sF[3 * i + 2];
+  }
+}
+
+int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
+  AsmArgs a;
+  a.coords = c->coords.p; a.mom = c->mom.p; a.x = xstate; a.un = c->xprev.p; a.bcval = c->bcval.p; a.bcmult = c->bcmult.p;
+  a.cells = c->cells.p; a.vptr = c->vptr.p; a.vdiag = c->vdiag.p; a.inc_cell = c->inc_cell.p; a.inc_row = c->inc_row.p;
+  a.blk_row = c->blk_row.p; a.blk_inc = c->blk_inc.p; a.blk_maxrank = c->blk_maxrank.p;
+  a.inc_slot = c->inc_slot.p; a.inc_rank = c->inc_rank.p; a.cflag = c->cflag.p; a.bcflag = c->bcflag.p;
+  a.A00 = c->A00.p; a.A01 = c->A01.p; a.A10 = c->A10.p; a.A11 = c->A11.p; a.F = c->F.p;
+  a.nvo = c->nvo; a.dt = c->dt; a.rho = c->rho; a.mu = c->mu; a.muf = c->muf; a.fx = c->f[0]; a.fy = c->f[1];
+  prof_begin(c, 0);
+  if (mode == 1) hipLaunchKernelGGL(asm_kernel<1>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
+  else if (mode == 2) hipLaunchKernelGGL(asm_kernel<2>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
+  else hipLaunchKernelGGL(asm_kernel<0>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
+  prof_end(c, 0);
+  HIPCHK(c, hipGetLastError());
+  if (mode == 1) c->jac_valid = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------- block SpMV
+// 8 lanes per vertex row: lane l of a group takes block k = rowstart + l (+8,...),
+// so the value arrays are streamed fully coalesced across the wave; partial
+// sums are combined with DPP shuffles.  y = J x over the monolithic vector.
+__global__ __launch_bounds__(TPB) void spmv_full_kernel(int nvo, const int *__restrict__ vptr,
+                                                        const int *__restrict__ vcol, const double *__restrict__ A00,
+                                                        const double *__restrict__ A01, const double *__restrict__ A10,
+                                                        const double *__restrict__ A11, const double *__restrict__ x,
+                                                        double *__restrict__ y) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  double a0 = 0, a1 = 0, a2 = 0;
+  if (row < nvo) {
+    const int ks = vptr[row], ke = vptr[row + 1];
+    for (int k = ks + l; k < ke; k += 8) {
+      const int w = vcol[k];
+      const int uo = uoff(w, nvo), po = poff(w, nvo);
+      const double xu0 = x[uo], xu1 = x[uo + 1], xp = x[po];
+      const double2 b0 = *(const double2 *)(A00 + 4 * (size_t)k), b1 = *(const double2 *)(A00 + 4 * (size_t)k + 2);
+      const double2 c01 = *(const double2 *)(A01 + 2 * (size_t)k), c10 = *(const double2 *)(A10 + 2 * (size_t)k);
+      const double c11 = A11[k];
+      a0 += b0.x * xu0 + b0.y * xu1 + c01.x * xp;
+      a1 += b1.x * xu0 + b1.y * xu1 + c01.y * xp;
+      a2 += c10.x * xu0 + c10.y * xu1 + c11 * xp;
+    }
+  }
+  a0 = group8_sum(a0); a1 = group8_sum(a1); a2 = group8_sum(a2);
+  if (row < nvo && l == 0) {
+    *(double2 *)(y + 2 * (size_t)row) = make_double2(a0, a1);
+    y[2 * (size_t)nvo + row] = a2;
+  }
+}
+
+int k_spmv_full(cfdh_ctx *c, const double *x, double *y) {
+  const long long nthreads = 8ll * c->nvo;
+  prof_begin(c, 1);
+  hipLaunchKernelGGL(spmv_full_kernel, dim3((unsigned)((nthreads + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, c->nvo,
+                     c->vptr.p, c->vcol.p, c->A00.p, c->A01.p, c->A10.p, c->A11.p, x, y);
+  prof_end(c, 1);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// sub-block products on owned columns only (the preconditioner is rank-local):
+// BLK 1: y_u = A00 x_u, 2: y_u = A01 x_p, 3: y_p = A10 x_u, 4: y_p = A11 x_p;  MODE 1: y = b - A x
+template <int BLK, int MODE>
+__global__ __launch_bounds__(TPB) void spmv_blk_kernel(int nvo, const int *__restrict__ vptr, const int *__restrict__ vcol,
+                                                       const double *__restrict__ A, const double *__restrict__ x,
+                                                       double *__restrict__ y, const double *__restrict__ bvec) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  double a0 = 0, a1 = 0;
+  if (row < nvo) {
+    const int ks = vptr[row], ke = vptr[row + 1];
+    for (int k = ks + l; k < ke; k += 8) {
+      const int w = vcol[k];
+      if (w >= nvo) continue;
+      if (BLK == 1) {
+        const double2 xx = *(const double2 *)(x + 2 * (size_t)w);
+        const double2 b0 = *(const double2 *)(A + 4 * (size_t)k), b1 = *(const double2 *)(A + 4 * (size_t)k + 2);
+        a0 += b0.x * xx.x + b0.y * xx.y; a1 += b1.x * xx.x + b1.y * xx.y;
+      } else if (BLK == 2) {
+        const double xp = x[w];
+        const double2 cc = *(const double2 *)(A + 2 * (size_t)k);
+        a0 += cc.x * xp; a1 += cc.y * xp;
+      } else if (BLK == 3) {
+        const double2 xx = *(const double2 *)(x + 2 * (size_t)w);
+        const double2 cc = *(const double2 *)(A + 2 * (size_t)k);
+        a0 += cc.x * xx.x + cc.y * xx.y;
+      } else {
+        a0 += A[k] * x[w];
+      }
+    }
+  }
+  a0 = group8_sum(a0);
+  if (BLK <= 2) a1 = group8_sum(a1);
+  if (row < nvo && l == 0) {
+    if (BLK <= 2) {
+      double2 o = make_double2(a0, a1);
+      if (MODE == 1) { const double2 bb = *(const double2 *)(bvec + 2 * (size_t)row); o.x = bb.x - o.x; o.y = bb.y - o.y; }
+      *(double2 *)(y + 2 * (size_t)row) = o;
+    } else {
+      y[row] = (MODE == 1) ? bvec[row] - a0 : a0;
+    }
+  }
+}
+
+int k_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b, double /*alpha*/) {
+  const long long nthreads = 8ll * c->nvo;
+  dim3 grid((unsigned)((nthreads + TPB - 1) / TPB)), block(TPB);
+  const int mode = b ? 1 : 0;
+#define LAUNCH_BLK(B, M, AP) hipLaunchKernelGGL((spmv_blk_kernel<B, M>), grid, block, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, AP, x, y, b)
+  if (blk == 1) { if (mode) LAUNCH_BLK(1, 1, c->A00.p); else LAUNCH_BLK(1, 0, c->A00.p); }
+  else if (blk == 2) { if (mode) LAUNCH_BLK(2, 1, c->A01.p); else LAUNCH_BLK(2, 0, c->A01.p); }
+  else if (blk == 3) { if (mode) LAUNCH_BLK(3, 1, c->A10.p); else LAUNCH_BLK(3, 0, c->A10.p); }
+  else { if (mode) LAUNCH_BLK(4, 1, c->A11.p); else LAUNCH_BLK(4, 0, c->A11.p); }
+#undef LAUNCH_BLK
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(TPB) void extract_diag_kernel(int nvo, const int *__restrict__ vdiag,
+                                                           const double *__restrict__ A00, double *__restrict__ dinv) {
+  const int row = blockIdx.x * TPB + threadIdx.x;
+  if (row >= nvo) return;
+  const size_t k = (size_t)vdiag[row];
+  const double d0 = A00[4 * k], d1 = A00[4 * k + 3];
+  *(double2 *)(dinv + 2 * (size_t)row) = make_double2(1.0 / d0, 1.0 / d1);
+}
+
+int k_extract_diag(cfdh_ctx *c) {
+  hipLaunchKernelGGL(extract_diag_kernel, dim3((c->nvo + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nvo, c->vdiag.p,
+                     c->A00.p, c->dinvA.p);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- Chebyshev on D^-1 A00
+// one step: r_out = r_in - A00 d_old ; d_new = c1 d_old + c2 D^-1 r_out ; x += d_new
+__global__ __launch_bounds__(TPB) void cheb_a00_step_kernel(int nvo, const int *__restrict__ vptr,
+                                                            const int *__restrict__ vcol, const double *__restrict__ A00,
+                                                            const double *__restrict__ dinv, const double *__restrict__ rin,
+                                                            double *__restrict__ rout, const double *__restrict__ dold,
+                                                            double *__restrict__ dnew, double *__restrict__ x, double c1,
+                                                            double c2) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  double a0 = 0, a1 = 0;
+  if (row < nvo) {
+    const int ks = vptr[row], ke = vptr[row + 1];
+    for (int k = ks + l; k < ke; k += 8) {
+      const int w = vcol[k];
+      if (w >= nvo) continue;
+      const double2 xx = *(const double2 *)(dold + 2 * (size_t)w);
+      const double2 b0 = *(const double2 *)(A00 + 4 * (size_t)k), b1 = *(const double2 *)(A00 + 4 * (size_t)k + 2);
+      a0 += b0.x * xx.x + b0.y * xx.y; a1 += b1.x * xx.x + b1.y * xx.y;
+    }
+  }
+  a0 = group8_sum(a0); a1 = group8_sum(a1);
+  if (row < nvo && l == 0) {
+    const size_t o = 2 * (size_t)row;
+    const double2 ri = *(const double2 *)(rin + o), di = *(const double2 *)(dinv + o), dd = *(const double2 *)(dold + o);
+    double2 xo = *(double2 *)(x + o);
+    const double r0 = ri.x - a0, r1 = ri.y - a1;
+    const double n0 = c1 * dd.x + c2 * di.x * r0, n1 = c1 * dd.y + c2 * di.y * r1;
+    *(double2 *)(rout + o) = make_double2(r0, r1);
+    *(double2 *)(dnew + o) = make_double2(n0, n1);
+    xo.x += n0; xo.y += n1;
+    *(double2 *)(x + o) = xo;
+  }
+}
+
+// d0 = D^-1 b / theta ; x = d0
+__global__ __launch_bounds__(TPB) void cheb_init_kernel(int n, const double *__restrict__ dinv, const double *__restrict__ b,
+                                                        double *__restrict__ d0, double *__restrict__ x, double itheta,
+                                                        int accumulate) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const double v = dinv[i] * b[i] * itheta;
+  d0[i] = v;
+  x[i] = accumulate ? x[i] + v : v;
+}
+
+// x = Cheb_k(D^-1 A00) b with zero initial guess; lambda in [lmax/ratio, lmax]
+int k_cheb_a00(cfdh_ctx *c, const double *b, double *x) {
+  const int nu = 2 * c->nvo;
+  const double lmax = c->lmaxA, lmin = lmax / c->opt.cheb_ratio;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  const double sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  double *dold = c->pu1.p, *dnew = c->pu2.p, *r = c->pr.p;
+  hipLaunchKernelGGL(cheb_init_kernel, dim3((nu + TPB - 1) / TPB), dim3(TPB), 0, c->stream, nu, c->dinvA.p, b, dold, x,
+                     1.0 / theta, 0);
+  const long long nthreads = 8ll * c->nvo;
+  dim3 grid((unsigned)((nthreads + TPB - 1) / TPB));
+  for (int k = 1; k < c->opt.cheb_degree; k++) {
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    prof_begin(c, 3);
+    hipLaunchKernelGGL(cheb_a00_step_kernel, grid, dim3(TPB), 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A00.p,
+                       c->dinvA.p, (k == 1) ? b : r, r, dold, dnew, x, c1, c2);
+    prof_end(c, 3);
+    std::swap(dold, dnew);
+    rho = rho_new;
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- scalar CSR (AMG levels)
+// MODE 0: y = A x; 1: y = b - A x; 2: y += A x
+template <int MODE>
+__global__ __launch_bounds__(TPB) void csr_spmv_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                       const double *__restrict__ val, const double *__restrict__ x,
+                                                       double *__restrict__ y, const double *__restrict__ b) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  double a = 0;
+  if (row < n) {
+    const int ks = rowptr[row], ke = rowptr[row + 1];
+    for (int k = ks + l; k < ke; k += 8) a += val[k] * x[col[k]];
+  }
+  a = group8_sum(a);
+  if (row < n && l == 0) {
+    if (MODE == 0) y[row] = a;
+    else if (MODE == 1) y[row] = b[row] - a;
+    else y[row] += a;
+  }
+}
+
+int k_csr_spmv(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mode, const double *b) {
+  const long long nthreads = 8ll * A.n;
+  dim3 grid((unsigned)((nthreads + TPB - 1) / TPB)), block(TPB);
+  if (mode == 0) hipLaunchKernelGGL(csr_spmv_kernel<0>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
+  else if (mode == 1) hipLaunchKernelGGL(csr_spmv_kernel<1>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
+  else hipLaunchKernelGGL(csr_spmv_kernel<2>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(TPB) void cheb_csr_step_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                            const double *__restrict__ val, const double *__restrict__ dinv,
+                                                            const double *__restrict__ rin, double *__restrict__ rout,
+                                                            const double *__restrict__ dold, double *__restrict__ dnew,
+                                                            double *__restrict__ x, double c1, double c2) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  double a = 0;
+  if (row < n) {
+    const int ks = rowptr[row], ke = rowptr[row + 1];
+    for (int k = ks + l; k < ke; k += 8) a += val[k] * dold[col[k]];
+  }
+  a = group8_sum(a);
+  if (row < n && l == 0) {
+    const double r = rin[row] - a;
+    const double dn = c1 * dold[row] + c2 * dinv[row] * r;
+    rout[row] = r; dnew[row] = dn; x[row] += dn;
+  }
+}
+
+// Chebyshev smoothing on level L: zero_guess ? x = S b : x <- x + S (b - A x)
+static int amg_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, bool zero_guess) {
+  const int n = L->n, deg = c->opt.amg_smooth_degree;
+  const double theta = 0.5 * (L->lmax + L->lmin), delta = 0.5 * (L->lmax - L->lmin), sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  double *dold = L->d0.p, *dnew = L->d1.p, *r = L->r.p;
+  const double *rin = b;
+  if (!zero_guess) { CHK(k_csr_spmv(c, L->A, x, r, 1, b)); rin = r; }
+  hipLaunchKernelGGL(cheb_init_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, L->dinv.p, rin, dold, x,
+                     1.0 / theta, zero_guess ? 0 : 1);
+  const long long nthreads = 8ll * n;
+  dim3 grid((unsigned)((nthreads + TPB - 1) / TPB));
+  for (int k = 1; k < deg; k++) {
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    if (L == c->amg[0]) prof_begin(c, 4);
+    hipLaunchKernelGGL(cheb_csr_step_kernel, grid, dim3(TPB), 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p,
+                       L->dinv.p, rin, r, dold, dnew, x, c1, c2);
+    if (L == c->amg[0]) prof_end(c, 4);
+    rin = r;
+    std::swap(dold, dnew);
+    rho = rho_new;
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// y = Minv b for the dense coarsest inverse: one wave per row
+__global__ __launch_bounds__(64) void dense_mv_kernel(int n, const double *__restrict__ Minv, const double *__restrict__ b,
+                                                      double *__restrict__ y) {
+  const int row = blockIdx.x, l = threadIdx.x;
+  double a = 0;
+  for (int k = l; k < n; k += 64) a += Minv[(size_t)row * n + k] * b[k];
+  a = wave_sum(a);
+  if (l == 0) y[row] = a;
+}
+
+static int amg_cycle(cfdh_ctx *c, size_t lev, const double *b, double *x) {
+  AmgLevel *L = c->amg[lev];
+  if (lev + 1 == c->amg.size()) {
+    hipLaunchKernelGGL(dense_mv_kernel, dim3(c->coarse_n), dim3(64), 0, c->stream, c->coarse_n, c->coarse_inv.p, b, x);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  AmgLevel *N = c->amg[lev + 1];
+  CHK(amg_smooth(c, L, b, x, true));
+  CHK(k_csr_spmv(c, L->A, x, L->r.p, 1, b));     // r = b - A x
+  CHK(k_csr_spmv(c, L->R, L->r.p, N->b.p, 0, nullptr));  // b_c = R r
+  CHK(amg_cycle(c, lev + 1, N->b.p, N->x.p));
+  CHK(k_csr_spmv(c, L->P, N->x.p, x, 2, nullptr));  // x += P x_c
+  CHK(amg_smooth(c, L, b, x, false));
+  return 0;
+}
+
+int k_amg_vcycle(cfdh_ctx *c, const double *b, double *x) { return amg_cycle(c, 0, b, x); }
+
+// ---------------------------------------------------------------- vector kernels
+__global__ __launch_bounds__(TPB) void axpy_kernel(int n, double a, const double *__restrict__ x, double *__restrict__ y) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) y[i] += a * x[i];
+}
+__global__ __launch_bounds__(TPB) void waxpy_kernel(int n, double a, const double *__restrict__ x, const double *__restrict__ y,
+                                                    double *__restrict__ w) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) w[i] = y[i] + a * x[i];
+}
+__global__ __launch_bounds__(TPB) void scale_kernel(int n, double a, double *__restrict__ x) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) x[i] *= a;
+}
+static inline int vgrid(int n) { int g = (n + TPB * 4 - 1) / (TPB * 4); return g < 1 ? 1 : (g > 2048 ? 2048 : g); }
+
+__global__ __launch_bounds__(TPB) void pmult_kernel(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ o) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) o[i] = a[i] * b[i];
+}
+int v_pointwise_mult(cfdh_ctx *c, int n, const double *a, const double *b, double *out) {
+  hipLaunchKernelGGL(pmult_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, a, b, out);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int v_copy(cfdh_ctx *c, int n, const double *x, double *y) {
+  HIPCHK(c, hipMemcpyAsync(y, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+int v_zero(cfdh_ctx *c, int n, double *y) {
+  HIPCHK(c, hipMemsetAsync(y, 0, sizeof(double) * (size_t)n, c->stream));
+  return 0;
+}
+int v_axpy(cfdh_ctx *c, int n, double a, const double *x, double *y) {
+  hipLaunchKernelGGL(axpy_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, a, x, y);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int v_waxpy(cfdh_ctx *c, int n, double a, const double *x, const double *y, double *w) {
+  hipLaunchKernelGGL(waxpy_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, a, x, y, w);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int v_scale(cfdh_ctx *c, int n, double a, double *x) {
+  hipLaunchKernelGGL(scale_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, a, x);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ---- reductions: per-block partials (fixed order) -> one final block; deterministic
+// OP 0: sum x*y, 1: max |x - y| (y may be null)
+template <int OP>
+__global__ __launch_bounds__(TPB) void reduce_partial_kernel(int n, const double *__restrict__ x, const double *__restrict__ y,
+                                                             double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double a = 0;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+    if (OP == 0) a += x[i] * y[i];
+    else a = fmax(a, fabs(y ? x[i] - y[i] : x[i]));
+  }
+  a = (OP == 0) ? block_sum(a, sh) : block_max(a, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+// out[v] = reduce(partial[v*stride .. +nblk)), one block per v; OP 2: sqrt of the sum
+template <int OP>
+__global__ __launch_bounds__(TPB) void reduce_final_kernel(int nblk, int stride, const double *__restrict__ partial,
+                                                           double *__restrict__ out) {
+  __shared__ double sh[4];
+  const double *pp = partial + (size_t)blockIdx.x * stride;
+  double a = 0;
+  for (int i = threadIdx.x; i < nblk; i += TPB) a = (OP == 1) ? fmax(a, pp[i]) : a + pp[i];
+  a = (OP == 1) ? block_max(a, sh) : block_sum(a, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
+
+static int read_scalars(cfdh_ctx *c, const double *dev, int n, double *host) {
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) host[i] = c->h_pinned[i];
+  return 0;
+}
+
+static int reduce_dev(cfdh_ctx *c, int op, int n, const double *x, const double *y, double *out_dev) {
+  const int nb = vgrid(n) > c->red_blocks ? c->red_blocks : vgrid(n);
+  if (op == 0) {
+    hipLaunchKernelGGL(reduce_partial_kernel<0>, dim3(nb), dim3(TPB), 0, c->stream, n, x, y, c->red_partial.p);
+    hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, out_dev);
+  } else {
+    hipLaunchKernelGGL(reduce_partial_kernel<1>, dim3(nb), dim3(TPB), 0, c->stream, n, x, y, c->red_partial.p);
+    hipLaunchKernelGGL(reduce_final_kernel<1>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, out_dev);
+  }
+  HIPCHK(c, hipGetLastError());
+  return comm_allreduce_dev(c, out_dev, 1, op);
+}
+
+int v_dot(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host) {
+  CHK(reduce_dev(c, 0, n, x, y, c->red_out.p));
+  return read_scalars(c, c->red_out.p, 1, out_host);
+}
+int v_norm2(cfdh_ctx *c, int n, const double *x, double *out_host) {
+  CHK(v_dot(c, n, x, x, out_host));
+  *out_host = sqrt(*out_host);
+  return 0;
+}
+int v_norminf_diff(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host) {
+  CHK(reduce_dev(c, 1, n, x, y, c->red_out.p));
+  return read_scalars(c, c->red_out.p, 1, out_host);
+}
+
+__global__ __launch_bounds__(TPB) void sub_scalar_kernel(int n, double *__restrict__ p, const double *__restrict__ s, double scale) {
+  const double m = s[0] * scale;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) p[i] -= m;
+}
+__global__ __launch_bounds__(TPB) void sum_partial_kernel(int n, const double *__restrict__ x, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double a = 0;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) a += x[i];
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+// p -= mean(p) over all ranks (constant-pressure null vector, stabilized_schur.py:282-293,319)
+int v_sub_mean(cfdh_ctx *c, int n, double *p) {
+  const int nb = vgrid(n) > c->red_blocks ? c->red_blocks : vgrid(n);
+  double *acc = c->red_out.p + 8;  // [sum, count]
+  hipLaunchKernelGGL(sum_partial_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, p, c->red_partial.p);
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, acc);
+  HIPCHK(c, hipGetLastError());
+  double scale = 1.0 / n;
+  if (c->nranks > 1) {
+    CHK(comm_allreduce_dev(c, acc, 1, 0));
+    // global count: every rank knows only its own n; reduce it once per call on the host side
+    double cnt = (double)n;
+    HIPCHK(c, hipMemcpyAsync(acc + 1, &cnt, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CHK(comm_allreduce_dev(c, acc + 1, 1, 0));
+    double tot;
+    CHK(read_scalars(c, acc + 1, 1, &tot));
+    scale = 1.0 / tot;
+  }
+  hipLaunchKernelGGL(sub_scalar_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, p, acc, scale);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ---- Gram-Schmidt building blocks: h_i = V_i . w for i < nvec (V column-major, leading dim ld)
+__global__ __launch_bounds__(TPB) void multidot_kernel(int n, const double *__restrict__ V, size_t ld, int nvec,
+                                                       const double *__restrict__ w, double *__restrict__ partial, int nblk) {
+  __shared__ double sh[4];
+  // each block owns a contiguous chunk so that w stays in registers across the nvec passes
+  const int per = (n + nblk - 1) / nblk;
+  const int lo = blockIdx.x * per, hi = min(n, lo + per);
+  for (int v = 0; v < nvec; v++) {
+    const double *vv = V + (size_t)v * ld;
+    double a = 0;
+    for (int i = lo + threadIdx.x; i < hi; i += TPB) a += vv[i] * w[i];
+    a = block_sum(a, sh);
+    if (threadIdx.x == 0) partial[(size_t)v * nblk + blockIdx.x] = a;
+  }
+}
+int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev) {
+  const int nb = 256;
+  if ((size_t)nvec * nb > c->red_partial.n) return cfdh_fail(c, CFDH_E_STATE, "multidot workspace too small");
+  hipLaunchKernelGGL(multidot_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, w, c->red_partial.p, nb);
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(nvec), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, h_dev);
+  HIPCHK(c, hipGetLastError());
+  return comm_allreduce_dev(c, h_dev, nvec, 0);
+}
+// w -= sum_i h_i V_i
+__global__ __launch_bounds__(TPB) void multiaxpy_kernel(int n, const double *__restrict__ V, size_t ld, int nvec,
+                                                        const double *__restrict__ h, double *__restrict__ w, double sign) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+    double a = w[i];
+    for (int v = 0; v < nvec; v++) a += sign * h[v] * V[(size_t)v * ld + i];
+    w[i] = a;
+  }
+}
+int v_multiaxpy(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, double *w) {
+  hipLaunchKernelGGL(multiaxpy_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, h_dev, w, -1.0);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int v_lincomb(cfdh_ctx *c, int n, const double *Z, int ld, int nvec, const double *y_dev, double *x) {
+  hipLaunchKernelGGL(multiaxpy_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, Z, (size_t)ld, nvec, y_dev, x, 1.0);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+__global__ void sqrt_kernel(double *s) { s[0] = sqrt(s[0]); }
+int v_norm_to_dev(cfdh_ctx *c, int n, const double *w, double *out_dev) {
+  CHK(reduce_dev(c, 0, n, w, w, out_dev));
+  hipLaunchKernelGGL(sqrt_kernel, dim3(1), dim3(1), 0, c->stream, out_dev);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+__global__ __launch_bounds__(TPB) void scale_inv_dev_kernel(int n, const double *__restrict__ w, const double *__restrict__ nrm,
+                                                            double *__restrict__ v) {
+  const double s = nrm[0] != 0.0 ? 1.0 / nrm[0] : 0.0;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) v[i] = w[i] * s;
+}
+int v_scale_inv_dev(cfdh_ctx *c, int n, const double *w, const double *nrm_dev, double *v) {
+  hipLaunchKernelGGL(scale_inv_dev_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, w, nrm_dev, v);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ||J n|| for the normalised constant-pressure vector n (MatNullSpaceTest, stabilized_schur.py:314)
+__global__ __launch_bounds__(TPB) void nulltest_kernel(int nvo, const int *__restrict__ vptr, const double *__restrict__ A01,
+                                                       const double *__restrict__ A11, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double a = 0;
+  for (int row = blockIdx.x * TPB + threadIdx.x; row < nvo; row += gridDim.x * TPB) {
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int k = vptr[row]; k < vptr[row + 1]; k++) { s0 += A01[2 * (size_t)k]; s1 += A01[2 * (size_t)k + 1]; s2 += A11[k]; }
+    a += s0 * s0 + s1 * s1 + s2 * s2;
+  }
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+int k_nullspace_test(cfdh_ctx *c, double *nrm) {
+  const int nb = vgrid(c->nvo) > c->red_blocks ? c->red_blocks : vgrid(c->nvo);
+  hipLaunchKernelGGL(nulltest_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nvo, c->vptr.p, c->A01.p, c->A11.p, c->red_partial.p);
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p);
+  HIPCHK(c, hipGetLastError());
+  CHK(comm_allreduce_dev(c, c->red_out.p, 1, 0));
+  double s;
+  CHK(read_scalars(c, c->red_out.p, 1, &s));
+  *nrm = sqrt(s);
+  return 0;
+}
+
+// ---------------------------------------------------------------- functionals
+// kind 0/1: drag / lift over exterior facets with the given marker (dfg_1.py:183-202)
+__global__ __launch_bounds__(TPB) void draglift_kernel(int nfac, int marker, int nvo, const int *__restrict__ fcell,
+                                                       const int *__restrict__ flocal, const int *__restrict__ fmarker,
+                                                       const int *__restrict__ cells, const unsigned char *__restrict__ cown,
+                                                       const double *__restrict__ coords,
+                                                       const double *__restrict__ x, double mu, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double aD = 0, aL = 0;
+  for (int k = blockIdx.x * TPB + threadIdx.x; k < nfac; k += gridDim.x * TPB) {
+    if (fmarker[k] != marker) continue;
+    const int e = fcell[k], fl = flocal[k];
+    if (!cown[e]) continue;
+    int vs[3];
+    double X[3][2];
+    for (int a = 0; a < 3; a++) { vs[a] = cells[3 * e + a]; X[a][0] = coords[2 * vs[a]]; X[a][1] = coords[2 * vs[a] + 1]; }
+    const double det = (X[1][0] - X[0][0]) * (X[2][1] - X[0][1]) - (X[1][1] - X[0][1]) * (X[2][0] - X[0][0]);
+    double g[3][2];
+    g[0][0] = (X[1][1] - X[2][1]) / det; g[0][1] = (X[2][0] - X[1][0]) / det;
+    g[1][0] = (X[2][1] - X[0][1]) / det; g[1][1] = (X[0][0] - X[2][0]) / det;
+    g[2][0] = (X[0][1] - X[1][1]) / det; g[2][1] = (X[1][0] - X[0][0]) / det;
+    const double area = 0.5 * fabs(det);
+    const double gfx = fl == 0 ? g[0][0] : (fl == 1 ? g[1][0] : g[2][0]);
+    const double gfy = fl == 0 ? g[0][1] : (fl == 1 ? g[1][1] : g[2][1]);
+    const double gl = hypot(gfx, gfy);
+    const double n0 = gfx / gl, n1 = gfy / gl;  // n = -FacetNormal
+    const double elen = 2.0 * area * gl;
+    const double t0 = n1, t1 = -n0;
+    double gu0 = 0, gu1 = 0;
+    for (int a = 0; a < 3; a++) {
+      const int uo = uoff(vs[a], nvo);
+      const double ut = x[uo] * t0 + x[uo + 1] * t1;
+      gu0 += ut * g[a][0]; gu1 += ut * g[a][1];
+    }
+    const double dn = gu0 * n0 + gu1 * n1;
+    const int a1 = vs[(fl + 1) % 3], a2 = vs[(fl + 2) % 3];
+    const double pm = 0.5 * (x[poff(a1, nvo)] + x[poff(a2, nvo)]);
+    aD += elen * (mu * dn * n1 - pm * n0);
+    aL -= elen * (mu * dn * n0 + pm * n1);
+  }
+  aD = block_sum(aD, sh);
+  aL = block_sum(aL, sh);
+  if (threadIdx.x == 0) { partial[blockIdx.x] = aD; partial[gridDim.x + blockIdx.x] = aL; }
+}
+// kind 2/3: int u.u, int p^2; with overlapping parts a cell is integrated only by
+// the rank that owns its first vertex (cell_owned), so global sums count it once
+__global__ __launch_bounds__(TPB) void l2_kernel(int nc, int nvo, const int *__restrict__ cells, const unsigned char *__restrict__ cown,
+                                                 const double *__restrict__ coords, const double *__restrict__ x,
+                                                 double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double au = 0, ap = 0;
+  for (int e = blockIdx.x * TPB + threadIdx.x; e < nc; e += gridDim.x * TPB) {
+    if (cown && !cown[e]) continue;
+    int vs[3];
+    double X[3][2];
+    for (int a = 0; a < 3; a++) { vs[a] = cells[3 * e + a]; X[a][0] = coords[2 * vs[a]]; X[a][1] = coords[2 * vs[a] + 1]; }
+    const double det = (X[1][0] - X[0][0]) * (X[2][1] - X[0][1]) - (X[1][1] - X[0][1]) * (X[2][0] - X[0][0]);
+    const double area = 0.5 * fabs(det);
+    double ux[3], uy[3], pp[3];
+    for (int a = 0; a < 3; a++) { const int uo = uoff(vs[a], nvo); ux[a] = x[uo]; uy[a] = x[uo + 1]; pp[a] = x[poff(vs[a], nvo)]; }
+    double su = 0, sp = 0;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        const double m = (a == b ? 2.0 : 1.0);
+        su += m * (ux[a] * ux[b] + uy[a] * uy[b]);
+        sp += m * pp[a] * pp[b];
+      }
+    au += area * su * (1.0 / 12.0);
+    ap += area * sp * (1.0 / 12.0);
+  }
+  au = block_sum(au, sh);
+  ap = block_sum(ap, sh);
+  if (threadIdx.x == 0) { partial[blockIdx.x] = au; partial[gridDim.x + blockIdx.x] = ap; }
+}
+
+int k_functional(cfdh_ctx *c, int kind, int marker, double *out) {
+  const int nb = 256;
+  if (kind == 0 || kind == 1) {
+    if (c->nfac == 0) { *out = 0; return 0; }
+    hipLaunchKernelGGL(draglift_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nfac, marker, c->nvo, c->d_fac_cell.p,
+                       c->d_fac_local.p, c->d_fac_marker.p, c->cells.p, c->cell_owned.p, c->coords.p, c->x.p, c->mu,
+                       c->red_partial.p);
+  } else if (kind == 2 || kind == 3) {
+    hipLaunchKernelGGL(l2_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nc, c->nvo, c->cells.p, c->cell_owned.p, c->coords.p,
+                       c->x.p, c->red_partial.p);
+  } else if (kind >= 4 && kind <= 6) {
+    const int nu = 2 * c->nvo;
+    const double *a = kind == 5 ? c->xprev.p : c->x.p;
+    const double *b = kind == 6 ? c->xprev.p : nullptr;
+    double v;
+    CHK(reduce_dev(c, 1, nu, a, b, c->red_out.p));
+    CHK(read_scalars(c, c->red_out.p, 1, &v));
+    *out = v;
+    return 0;
+  } else {
+    return cfdh_fail(c, CFDH_E_ARG, "unknown functional kind %d", kind);
+  }
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(2), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p);
+  HIPCHK(c, hipGetLastError());
+  CHK(comm_allreduce_dev(c, c->red_out.p, 2, 0));
+  double v[2];
+  CHK(read_scalars(c, c->red_out.p, 2, v));
+  if (kind == 0) *out = v[0];
+  else if (kind == 1) *out = v[1];
+  else if (kind == 2) *out = sqrt(v[0]);
+  else *out = sqrt(v[1]);
+  return 0;
+}
+
+// ---------------------------------------------------------------- halo pack
+__global__ __launch_bounds__(TPB) void halo_pack_kernel(int n, int nvo, const int *__restrict__ idx, const double *__restrict__ vec,
+                                                        double *__restrict__ buf) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const int v = idx[i];
+  buf[3 * (size_t)i] = vec[2 * (size_t)v];
+  buf[3 * (size_t)i + 1] = vec[2 * (size_t)v + 1];
+  buf[3 * (size_t)i + 2] = vec[2 * (size_t)nvo + v];
+}
+int k_halo_pack(cfdh_ctx *c, const double *vec) {
+  const int n = (int)c->send_idx.n;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(halo_pack_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, c->nvo, c->send_idx.p, vec,
+                     c->send_buf.p);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

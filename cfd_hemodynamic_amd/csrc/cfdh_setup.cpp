@@ -1,0 +1,489 @@
+// Host-side, one-off setup of libcfdh.so: internal vertex numbering, the fixed
+// vertex-graph CSR pattern (create_matrix_block, stabilized_schur.py:191), the
+// (row vertex, cell) incidence lists that drive the atomic-free assembly, and
+// the smoothed-aggregation hierarchy for the SELFP Schur matrix
+// Sp = A11 - A10 diag(A00)^-1 A01 (stabilized_schur.py:235).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <numeric>
+
+#include "cfdh_internal.hpp"
+
+int cfdh_fail(cfdh_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  extern std::string g_cfdh_last_error;
+  g_cfdh_last_error = buf;
+  if (c) c->err = buf;
+  return code;
+}
+
+// host threads for the one-off setup loops: never oversubscribe a cgroup-limited box
+int cfdh_host_threads() {
+  const char *e = getenv("CFDH_HOST_THREADS");
+  int n = e ? atoi(e) : 8;
+  return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+
+static inline uint32_t part1by1(uint32_t x) {
+  x &= 0x0000ffff;
+  x = (x ^ (x << 8)) & 0x00ff00ff;
+  x = (x ^ (x << 4)) & 0x0f0f0f0f;
+  x = (x ^ (x << 2)) & 0x33333333;
+  x = (x ^ (x << 1)) & 0x55555555;
+  return x;
+}
+
+int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, const int32_t *cells, const double *coords,
+                    int64_t nfac64, const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker) {
+  const int nv = (int)nv64, nvo = (int)nvo64, ncu = (int)nc64, nfac = (int)nfac64;
+  if (nv <= 0 || nvo <= 0 || nvo > nv || ncu <= 0) return cfdh_fail(c, CFDH_E_ARG, "bad mesh sizes");
+  if (nv64 > (1ll << 29) || nc64 > (1ll << 29)) return cfdh_fail(c, CFDH_E_ARG, "mesh too large for int32 indexing");
+  for (int64_t k = 0; k < 3 * nc64; k++)
+    if (cells[k] < 0 || cells[k] >= nv) return cfdh_fail(c, CFDH_E_ARG, "cell vertex index out of range");
+  for (int k = 0; k < nfac; k++)
+    if (fcell[k] < 0 || fcell[k] >= ncu || flocal[k] < 0 || flocal[k] > 2)
+      return cfdh_fail(c, CFDH_E_ARG, "facet (cell, local) out of range");
+  c->nv = nv; c->nvo = nvo; c->ng = nv - nvo;
+  c->NO = 3 * nvo; c->NL = 3 * nvo + 3 * c->ng;
+
+  // ---- internal numbering: owned vertices along a Morton curve, ghosts unchanged
+  c->perm.resize(nv); c->iperm.resize(nv);
+  {
+    std::vector<int> order(nvo);
+    std::iota(order.begin(), order.end(), 0);
+    const char *nr = getenv("CFDH_NO_RENUMBER");
+    if (!(nr && nr[0] == '1')) {
+      double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+      for (int v = 0; v < nv; v++)
+        for (int i = 0; i < 2; i++) { lo[i] = std::min(lo[i], coords[2 * v + i]); hi[i] = std::max(hi[i], coords[2 * v + i]); }
+      double ext = std::max(hi[0] - lo[0], hi[1] - lo[1]);
+      if (!(ext > 0)) return cfdh_fail(c, CFDH_E_ARG, "degenerate coordinates");
+      std::vector<uint32_t> key(nvo);
+      for (int v = 0; v < nvo; v++) {
+        uint32_t qx = (uint32_t)std::min(65535.0, (coords[2 * v] - lo[0]) / ext * 65535.0);
+        uint32_t qy = (uint32_t)std::min(65535.0, (coords[2 * v + 1] - lo[1]) / ext * 65535.0);
+        key[v] = part1by1(qx) | (part1by1(qy) << 1);
+      }
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+    }
+    for (int k = 0; k < nvo; k++) { c->iperm[k] = order[k]; c->perm[order[k]] = k; }
+    for (int v = nvo; v < nv; v++) { c->iperm[v] = v; c->perm[v] = v; }
+  }
+  c->h_coords.resize(2 * (size_t)nv);
+  for (int k = 0; k < nv; k++) { c->h_coords[2 * k] = coords[2 * c->iperm[k]]; c->h_coords[2 * k + 1] = coords[2 * c->iperm[k] + 1]; }
+
+  // ---- cells touching an owned vertex, internal ids, sorted by smallest vertex
+  {
+    std::vector<std::pair<int, int>> keyed;
+    keyed.reserve(ncu);
+    for (int e = 0; e < ncu; e++) {
+      int a = c->perm[cells[3 * e]], b = c->perm[cells[3 * e + 1]], d = c->perm[cells[3 * e + 2]];
+      if (a == b || b == d || a == d) return cfdh_fail(c, CFDH_E_ARG, "degenerate cell %d", e);
+      int mn = std::min(a, std::min(b, d));
+      if (mn < nvo) keyed.push_back({mn, e});
+    }
+    std::stable_sort(keyed.begin(), keyed.end());
+    c->nc = (int)keyed.size();
+    c->h_cells.resize(3 * (size_t)c->nc);
+    c->cell_user.resize(c->nc);
+    std::vector<int> cmap(ncu, -1);
+    for (int k = 0; k < c->nc; k++) {
+      int e = keyed[k].second;
+      cmap[e] = k; c->cell_user[k] = e;
+      for (int a = 0; a < 3; a++) c->h_cells[3 * k + a] = c->perm[cells[3 * e + a]];
+    }
+    c->fac_cell.clear(); c->fac_local.clear(); c->fac_marker.clear();
+    for (int k = 0; k < nfac; k++)
+      if (cmap[fcell[k]] >= 0) {
+        c->fac_cell.push_back(cmap[fcell[k]]); c->fac_local.push_back(flocal[k]);
+        c->fac_marker.push_back(fmarker ? fmarker[k] : 0);
+      }
+    c->nfac = (int)c->fac_cell.size();
+  }
+  const int nc = c->nc;
+  for (int e = 0; e < nc; e++) {
+    const int *v = &c->h_cells[3 * e];
+    const double *X = c->h_coords.data();
+    double det = (X[2 * v[1]] - X[2 * v[0]]) * (X[2 * v[2] + 1] - X[2 * v[0] + 1]) - (X[2 * v[1] + 1] - X[2 * v[0] + 1]) * (X[2 * v[2]] - X[2 * v[0]]);
+    if (!(std::fabs(det) > 0)) return cfdh_fail(c, CFDH_E_ARG, "zero-area cell %d", c->cell_user[e]);
+  }
+
+  // ---- vertex -> incident (cell, local) for owned rows; vertex graph
+  std::vector<int> vcptr(nvo + 1, 0);
+  for (int e = 0; e < nc; e++)
+    for (int a = 0; a < 3; a++) { int v = c->h_cells[3 * e + a]; if (v < nvo) vcptr[v + 1]++; }
+  for (int v = 0; v < nvo; v++) vcptr[v + 1] += vcptr[v];
+  const int ninc = vcptr[nvo];
+  std::vector<int> vcell(ninc);
+  {
+    std::vector<int> fill(nvo, 0);
+    for (int e = 0; e < nc; e++)
+      for (int a = 0; a < 3; a++) { int v = c->h_cells[3 * e + a]; if (v < nvo) vcell[vcptr[v] + fill[v]++] = 4 * e + a; }
+  }
+  c->h_vptr.assign(nvo + 1, 0);
+  c->h_vcol.clear(); c->h_vcol.reserve((size_t)7 * nvo);
+  c->h_vdiag.resize(nvo);
+  {
+    std::vector<int> tmp;
+    for (int v = 0; v < nvo; v++) {
+      tmp.clear(); tmp.push_back(v);
+      for (int k = vcptr[v]; k < vcptr[v + 1]; k++) { int e = vcell[k] >> 2; for (int a = 0; a < 3; a++) tmp.push_back(c->h_cells[3 * e + a]); }
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      if ((int)tmp.size() > 255) return cfdh_fail(c, CFDH_E_ARG, "vertex valence > 254 is not supported");
+      if (vcptr[v + 1] == vcptr[v]) return cfdh_fail(c, CFDH_E_ARG, "owned vertex %d has no cell", c->iperm[v]);
+      c->h_vdiag[v] = (int)c->h_vcol.size() + (int)(std::lower_bound(tmp.begin(), tmp.end(), v) - tmp.begin());
+      c->h_vcol.insert(c->h_vcol.end(), tmp.begin(), tmp.end());
+      c->h_vptr[v + 1] = (int)c->h_vcol.size();
+    }
+  }
+  c->nnzv = (int)c->h_vcol.size();
+  c->ninc = ninc;
+
+  // ---- incidence metadata (rotated so that the row vertex is local 0)
+  std::vector<int> inc_cell(ninc), inc_row(ninc);
+  std::vector<unsigned> inc_slot(ninc), inc_rank(ninc);
+  {
+    std::vector<unsigned char> cnt;
+    for (int v = 0; v < nvo; v++) {
+      const int *nb = &c->h_vcol[c->h_vptr[v]];
+      int deg = c->h_vptr[v + 1] - c->h_vptr[v];
+      cnt.assign(deg, 0);
+      for (int k = vcptr[v]; k < vcptr[v + 1]; k++) {
+        int e = vcell[k] >> 2, a = vcell[k] & 3;
+        unsigned slot = 0, rank = 0;
+        for (int b = 0; b < 3; b++) {
+          int w = c->h_cells[3 * e + (a + b) % 3];
+          int s = (int)(std::lower_bound(nb, nb + deg, w) - nb);
+          slot |= (unsigned)s << (8 * b);
+          rank |= (unsigned)cnt[s] << (8 * b);
+          cnt[s]++;
+        }
+        inc_cell[k] = vcell[k]; inc_row[k] = v; inc_slot[k] = slot; inc_rank[k] = rank;
+      }
+    }
+  }
+  // ---- workgroup blocks of whole rows
+  std::vector<int> blk_row(1, 0), blk_maxrank, blk_inc(1, 0);
+  {
+    int r0 = 0;
+    while (r0 < nvo) {
+      int r1 = r0, inc = 0, slots = 0, mr = 2;
+      while (r1 < nvo) {
+        int di = vcptr[r1 + 1] - vcptr[r1], ds = c->h_vptr[r1 + 1] - c->h_vptr[r1];
+        if (di > CFDH_MAX_INC || ds > CFDH_MAX_SLOTS) return cfdh_fail(c, CFDH_E_ARG, "vertex valence too large");
+        if (inc + di > CFDH_MAX_INC || slots + ds > CFDH_MAX_SLOTS || r1 - r0 >= CFDH_MAX_ROWS) break;
+        inc += di; slots += ds; mr = std::max(mr, di); r1++;
+      }
+      blk_row.push_back(r1); blk_maxrank.push_back(mr); blk_inc.push_back(vcptr[r1]);
+      r0 = r1;
+    }
+  }
+  c->nblk = (int)blk_maxrank.size();
+
+  // ---- uploads
+  hipStream_t s = c->stream;
+  std::vector<unsigned char> cflag(nc, 0);
+  for (int k = 0; k < c->nfac; k++) cflag[c->fac_cell[k]] |= (unsigned char)(1u << c->fac_local[k]);
+  HIPCHK(c, c->coords.upload(c->h_coords, s));
+  HIPCHK(c, c->cells.upload(c->h_cells, s));
+  HIPCHK(c, c->cflag.upload(cflag, s));
+  HIPCHK(c, c->mom.alloc(8 * (size_t)nc));
+  HIPCHK(c, c->vptr.upload(c->h_vptr, s));
+  HIPCHK(c, c->vcol.upload(c->h_vcol, s));
+  HIPCHK(c, c->vdiag.upload(c->h_vdiag, s));
+  HIPCHK(c, c->A00.alloc(4 * (size_t)c->nnzv));
+  HIPCHK(c, c->A01.alloc(2 * (size_t)c->nnzv));
+  HIPCHK(c, c->A10.alloc(2 * (size_t)c->nnzv));
+  HIPCHK(c, c->A11.alloc((size_t)c->nnzv));
+  HIPCHK(c, c->inc_cell.upload(inc_cell, s));
+  HIPCHK(c, c->inc_row.upload(inc_row, s));
+  HIPCHK(c, c->inc_slot.upload(inc_slot, s));
+  HIPCHK(c, c->inc_rank.upload(inc_rank, s));
+  HIPCHK(c, c->blk_row.upload(blk_row, s));
+  HIPCHK(c, c->blk_maxrank.upload(blk_maxrank, s));
+  HIPCHK(c, c->blk_inc.upload(blk_inc, s));
+  {
+    std::vector<unsigned char> cown(nc);
+    for (int k = 0; k < nc; k++) cown[k] = cells[3 * c->cell_user[k]] < nvo ? 1 : 0;
+    HIPCHK(c, c->cell_owned.upload(cown, s));
+  }
+  {
+    std::vector<double> rnd(2 * (size_t)nvo);
+    uint64_t st = 0x2545F4914F6CDD1Dull;
+    for (auto &v : rnd) { st = st * 6364136223846793005ull + 1442695040888963407ull; v = ((st >> 11) * (1.0 / 9007199254740992.0)) - 0.5; }
+    HIPCHK(c, c->prand.upload(rnd, s));
+  }
+  if (c->nfac) {
+    HIPCHK(c, c->d_fac_cell.upload(c->fac_cell, s));
+    HIPCHK(c, c->d_fac_local.upload(c->fac_local, s));
+    HIPCHK(c, c->d_fac_marker.upload(c->fac_marker, s));
+  }
+  c->h_bcflag.assign(nv, 0);
+  c->h_bcval.assign(3 * (size_t)nv, 0.0);
+  c->h_bcmult.assign(3 * (size_t)nv, 0.0);
+  HIPCHK(c, c->bcflag.alloc(nv));
+  HIPCHK(c, c->bcval.alloc(3 * (size_t)nv));
+  HIPCHK(c, c->bcmult.alloc(3 * (size_t)nv));
+  c->bc_dirty = true;
+  const size_t NL = c->NL;
+  HIPCHK(c, c->x.alloc(NL)); HIPCHK(c, c->xt.alloc(NL)); HIPCHK(c, c->xprev.alloc(NL));
+  HIPCHK(c, c->F.alloc(NL)); HIPCHK(c, c->dvec.alloc(NL));
+  HIPCHK(c, c->x.zero(s)); HIPCHK(c, c->xt.zero(s)); HIPCHK(c, c->xprev.zero(s)); HIPCHK(c, c->F.zero(s)); HIPCHK(c, c->dvec.zero(s));
+  c->red_blocks = 1024;
+  HIPCHK(c, c->red_partial.alloc((size_t)c->red_blocks * 260));
+  HIPCHK(c, c->red_out.alloc(1024));
+  HIPCHK(c, hipHostMalloc((void **)&c->h_pinned, 1024 * sizeof(double)));
+  HIPCHK(c, c->dinvA.alloc(2 * (size_t)nvo));
+  HIPCHK(c, c->pu0.alloc(2 * (size_t)nvo)); HIPCHK(c, c->pu1.alloc(2 * (size_t)nvo)); HIPCHK(c, c->pu2.alloc(2 * (size_t)nvo));
+  HIPCHK(c, c->pr.alloc(2 * (size_t)nvo));
+  HIPCHK(c, c->pp0.alloc(nvo)); HIPCHK(c, c->pp1.alloc(nvo));
+  HIPCHK(c, hipStreamSynchronize(s));
+  return 0;
+}
+
+// =============================================================================
+// Smoothed-aggregation AMG for the (lagged) SELFP Schur matrix -- host setup.
+// =============================================================================
+
+static void csr_spmv_host(const CsrHost &A, const double *x, double *y) {
+#pragma omp parallel for schedule(static) num_threads(cfdh_host_threads())
+  for (int i = 0; i < A.n; i++) {
+    double s = 0;
+    for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) s += A.val[k] * x[A.col[k]];
+    y[i] = s;
+  }
+}
+
+static double lam_max_host(const CsrHost &A, const std::vector<double> &dinv, int its) {
+  int n = A.n;
+  std::vector<double> v(n), w(n);
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < n; i++) { st = st * 6364136223846793005ull + 1442695040888963407ull; v[i] = ((st >> 11) * (1.0 / 9007199254740992.0)) - 0.5; }
+  double l = 1;
+  for (int it = 0; it < its; it++) {
+    csr_spmv_host(A, v.data(), w.data());
+    double nn = 0;
+    for (int i = 0; i < n; i++) { w[i] *= dinv[i]; nn += w[i] * w[i]; }
+    l = std::sqrt(nn);
+    if (!(l > 0)) return 1.0;
+    for (int i = 0; i < n; i++) v[i] = w[i] / l;
+  }
+  return l;
+}
+
+// standard three-phase greedy aggregation on the strength graph
+static int aggregate_host(const CsrHost &A, double theta, std::vector<int> &agg) {
+  int n = A.n;
+  std::vector<double> d(n, 0.0);
+  for (int i = 0; i < n; i++)
+    for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] == i) d[i] = std::fabs(A.val[k]);
+  std::vector<int> sptr(n + 1, 0), scol;
+  scol.reserve(A.col.size());
+  for (int i = 0; i < n; i++) {
+    for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) {
+      int j = A.col[k];
+      if (j != i && std::fabs(A.val[k]) >= theta * std::sqrt(d[i] * d[j])) scol.push_back(j);
+    }
+    sptr[i + 1] = (int)scol.size();
+  }
+  agg.assign(n, -1);
+  int na = 0;
+  for (int i = 0; i < n; i++) {
+    if (agg[i] >= 0) continue;
+    bool freeNb = sptr[i + 1] > sptr[i];
+    for (int k = sptr[i]; k < sptr[i + 1] && freeNb; k++) if (agg[scol[k]] >= 0) freeNb = false;
+    if (!freeNb) continue;
+    agg[i] = na;
+    for (int k = sptr[i]; k < sptr[i + 1]; k++) agg[scol[k]] = na;
+    na++;
+  }
+  std::vector<int> agg2 = agg;
+  for (int i = 0; i < n; i++) {
+    if (agg[i] >= 0) continue;
+    for (int k = sptr[i]; k < sptr[i + 1]; k++) if (agg[scol[k]] >= 0) { agg2[i] = agg[scol[k]]; break; }
+  }
+  agg.swap(agg2);
+  for (int i = 0; i < n; i++) {
+    if (agg[i] >= 0) continue;
+    agg[i] = na;
+    for (int k = sptr[i]; k < sptr[i + 1]; k++) if (agg[scol[k]] < 0) agg[scol[k]] = na;
+    na++;
+  }
+  return na;
+}
+
+// C = A * B (Gustavson, sorted output columns)
+static void spgemm_host(const CsrHost &A, const CsrHost &B, CsrHost &C) {
+  C.n = A.n; C.m = B.m;
+  C.rowptr.assign(A.n + 1, 0);
+  std::vector<std::vector<int>> cols(A.n);
+  std::vector<std::vector<double>> vals(A.n);
+#pragma omp parallel num_threads(cfdh_host_threads())
+  {
+    std::vector<int> mark(B.m, -1), list;
+    std::vector<double> acc(B.m, 0.0);
+#pragma omp for schedule(dynamic, 256)
+    for (int i = 0; i < A.n; i++) {
+      list.clear();
+      for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) {
+        int j = A.col[k];
+        double a = A.val[k];
+        for (int k2 = B.rowptr[j]; k2 < B.rowptr[j + 1]; k2++) {
+          int cc = B.col[k2];
+          if (mark[cc] != i) { mark[cc] = i; acc[cc] = 0.0; list.push_back(cc); }
+          acc[cc] += a * B.val[k2];
+        }
+      }
+      std::sort(list.begin(), list.end());
+      cols[i] = list;
+      vals[i].resize(list.size());
+      for (size_t t = 0; t < list.size(); t++) vals[i][t] = acc[list[t]];
+    }
+  }
+  for (int i = 0; i < A.n; i++) C.rowptr[i + 1] = C.rowptr[i] + (int)cols[i].size();
+  C.col.resize(C.rowptr[A.n]); C.val.resize(C.rowptr[A.n]);
+  for (int i = 0; i < A.n; i++) {
+    std::copy(cols[i].begin(), cols[i].end(), C.col.begin() + C.rowptr[i]);
+    std::copy(vals[i].begin(), vals[i].end(), C.val.begin() + C.rowptr[i]);
+  }
+}
+
+static void transpose_host(const CsrHost &A, CsrHost &T) {
+  T.n = A.m; T.m = A.n;
+  T.rowptr.assign(A.m + 1, 0);
+  for (int k = 0; k < A.nnz(); k++) T.rowptr[A.col[k] + 1]++;
+  for (int i = 0; i < A.m; i++) T.rowptr[i + 1] += T.rowptr[i];
+  T.col.resize(A.nnz()); T.val.resize(A.nnz());
+  std::vector<int> fill(T.rowptr.begin(), T.rowptr.end() - 1);
+  for (int i = 0; i < A.n; i++)
+    for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) { int p = fill[A.col[k]]++; T.col[p] = i; T.val[p] = A.val[k]; }
+}
+
+static int upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D) {
+  D.n = H.n; D.m = H.m; D.nnz = H.nnz();
+  HIPCHK(c, D.rowptr.upload(H.rowptr, c->stream));
+  HIPCHK(c, D.col.upload(H.col, c->stream));
+  HIPCHK(c, D.val.upload(H.val, c->stream));
+  return 0;
+}
+
+// dense inverse by Gauss-Jordan with partial pivoting (coarsest level, n <= ~500)
+static bool dense_inverse(std::vector<double> &a, int n) {
+  std::vector<double> inv((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++) inv[(size_t)i * n + i] = 1.0;
+  for (int col = 0; col < n; col++) {
+    int piv = col;
+    double best = std::fabs(a[(size_t)col * n + col]);
+    for (int r = col + 1; r < n; r++) if (std::fabs(a[(size_t)r * n + col]) > best) { best = std::fabs(a[(size_t)r * n + col]); piv = r; }
+    if (!(best > 0)) return false;
+    if (piv != col)
+      for (int k = 0; k < n; k++) { std::swap(a[(size_t)piv * n + k], a[(size_t)col * n + k]); std::swap(inv[(size_t)piv * n + k], inv[(size_t)col * n + k]); }
+    double d = 1.0 / a[(size_t)col * n + col];
+    for (int k = 0; k < n; k++) { a[(size_t)col * n + k] *= d; inv[(size_t)col * n + k] *= d; }
+    for (int r = 0; r < n; r++) {
+      if (r == col) continue;
+      double f = a[(size_t)r * n + col];
+      if (f == 0.0) continue;
+      for (int k = 0; k < n; k++) { a[(size_t)r * n + k] -= f * a[(size_t)col * n + k]; inv[(size_t)r * n + k] -= f * inv[(size_t)col * n + k]; }
+    }
+  }
+  a.swap(inv);
+  return true;
+}
+
+int cfdh_amg_setup(cfdh_ctx *c, const CsrHost &Sp) {
+  for (AmgLevel *l : c->amg) delete l;
+  c->amg.clear();
+  const cfdh_options &o = c->opt;
+  CsrHost A = Sp;
+  const int maxlev = 16;
+  for (;;) {
+    AmgLevel *L = new AmgLevel();
+    c->amg.push_back(L);
+    L->n = A.n;
+    std::vector<double> dinv(A.n, 1.0);
+    for (int i = 0; i < A.n; i++)
+      for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++)
+        if (A.col[k] == i && A.val[k] != 0.0) dinv[i] = 1.0 / A.val[k];
+    double lm = lam_max_host(A, dinv, 15);
+    L->lmax = 1.1 * lm;
+    L->lmin = L->lmax / o.amg_smooth_ratio;
+    CHK(upload_csr(c, A, L->A));
+    HIPCHK(c, L->dinv.upload(dinv, c->stream));
+    HIPCHK(c, L->x.alloc(A.n)); HIPCHK(c, L->b.alloc(A.n)); HIPCHK(c, L->r.alloc(A.n));
+    HIPCHK(c, L->d0.alloc(A.n)); HIPCHK(c, L->d1.alloc(A.n));
+    if (A.n <= o.amg_max_coarse || (int)c->amg.size() >= maxlev) break;
+    std::vector<int> agg;
+    int na = aggregate_host(A, o.amg_theta, agg);
+    if (na >= A.n || na < 1) break;  // no coarsening possible
+    // P = (I - omega D^-1 A) P0,  P0 = piecewise constant
+    CsrHost P0;
+    P0.n = A.n; P0.m = na;
+    P0.rowptr.resize(A.n + 1);
+    P0.col.resize(A.n); P0.val.assign(A.n, 1.0);
+    for (int i = 0; i <= A.n; i++) P0.rowptr[i] = i;
+    for (int i = 0; i < A.n; i++) P0.col[i] = agg[i];
+    CsrHost AP0, P;
+    spgemm_host(A, P0, AP0);
+    double omega = 4.0 / 3.0 / lm;
+    P.n = A.n; P.m = na;
+    P.rowptr.assign(A.n + 1, 0);
+    for (int i = 0; i < A.n; i++) {
+      bool has = false;
+      for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; k++) if (AP0.col[k] == agg[i]) has = true;
+      P.rowptr[i + 1] = P.rowptr[i] + (AP0.rowptr[i + 1] - AP0.rowptr[i]) + (has ? 0 : 1);
+    }
+    P.col.resize(P.rowptr[A.n]); P.val.resize(P.rowptr[A.n]);
+    for (int i = 0; i < A.n; i++) {
+      int p = P.rowptr[i];
+      bool placed = false;
+      for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; k++) {
+        int j = AP0.col[k];
+        double v = -omega * dinv[i] * AP0.val[k];
+        if (!placed && j > agg[i]) { P.col[p] = agg[i]; P.val[p] = 1.0; p++; placed = true; }
+        if (j == agg[i]) { v += 1.0; placed = true; }
+        P.col[p] = j; P.val[p] = v; p++;
+      }
+      if (!placed) { P.col[p] = agg[i]; P.val[p] = 1.0; p++; }
+    }
+    CsrHost R, AP, Ac;
+    transpose_host(P, R);
+    spgemm_host(A, P, AP);
+    spgemm_host(R, AP, Ac);
+    CHK(upload_csr(c, P, L->P));
+    CHK(upload_csr(c, R, L->R));
+    A.n = Ac.n; A.m = Ac.m;
+    A.rowptr.swap(Ac.rowptr); A.col.swap(Ac.col); A.val.swap(Ac.val);
+  }
+  // coarsest level: dense inverse; a singular (constant null vector) operator is
+  // regularised with alpha * 1 1^T so that the inverse acts as a pseudo-inverse
+  {
+    int n = A.n;
+    std::vector<double> D((size_t)n * n, 0.0);
+    double tr = 0;
+    for (int i = 0; i < n; i++)
+      for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) { D[(size_t)i * n + A.col[k]] = A.val[k]; if (A.col[k] == i) tr += std::fabs(A.val[k]); }
+    if (c->singular) {
+      double alpha = tr / n / n;
+      for (size_t k = 0; k < D.size(); k++) D[k] += alpha;
+    }
+    if (!dense_inverse(D, n)) return cfdh_fail(c, CFDH_E_STATE, "singular coarsest AMG operator (n=%d)", n);
+    HIPCHK(c, c->coarse_inv.upload(D, c->stream));
+    c->coarse_n = n;
+  }
+  c->sp_nnz = Sp.nnz();
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->opt.verbose) {
+    fprintf(stderr, "[cfdh] AMG hierarchy:");
+    for (AmgLevel *l : c->amg) fprintf(stderr, " (%d, nnz %d)", l->n, l->A.nnz);
+    fprintf(stderr, "\n");
+  }
+  return 0;
+}

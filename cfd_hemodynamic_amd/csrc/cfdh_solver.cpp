@@ -1,0 +1,352 @@
+// Host driver of the per-step solve (stabilized_schur.py:313-334): Newton with a
+// backtracking line search (SNES newtonls/bt), right-preconditioned FGMRES
+// (KSPFGMRES, restart/caps of :272-273) and a GPU block-Schur preconditioner
+//     z_u = C(A00) r_u ;  z_p = V(Sp)(r_p - A10 z_u) ;  z_u = C(A00)(r_u - A01 z_p)
+// with C = Jacobi-Chebyshev polynomial and V = one smoothed-aggregation V-cycle
+// on the (lagged) SELFP matrix Sp = A11 - A10 diag(A00)^-1 A01 -- the same
+// factorisation the reference configures (PCFIELDSPLIT Schur FULL / SELFP,
+// :231-235) with GPU-friendly sub-solvers instead of GMRES+ILU(0)/ILU(0).
+// All vectors stay in HBM; the host sees a few scalars per iteration.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#include "cfdh_internal.hpp"
+
+int cfdh_host_threads();
+
+static double wall_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+int cfdh_download_blocks(cfdh_ctx *c, std::vector<double> &a00, std::vector<double> &a01, std::vector<double> &a10,
+                         std::vector<double> &a11) {
+  const size_t nz = (size_t)c->nnzv;
+  a00.resize(4 * nz); a01.resize(2 * nz); a10.resize(2 * nz); a11.resize(nz);
+  HIPCHK(c, hipMemcpyAsync(a00.data(), c->A00.p, sizeof(double) * 4 * nz, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(a01.data(), c->A01.p, sizeof(double) * 2 * nz, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(a10.data(), c->A10.p, sizeof(double) * 2 * nz, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(a11.data(), c->A11.p, sizeof(double) * nz, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// Sp = A11 - A10 diag(A00)^-1 A01 on the owned vertices (rank-local, like the
+// reference's per-rank ASM blocks)
+static int build_schur_host(cfdh_ctx *c, CsrHost &S) {
+  std::vector<double> a00, a01, a10, a11;
+  CHK(cfdh_download_blocks(c, a00, a01, a10, a11));
+  const int nvo = c->nvo;
+  const std::vector<int> &vp = c->h_vptr, &vc = c->h_vcol;
+  std::vector<double> dinv(2 * (size_t)nvo);
+  for (int v = 0; v < nvo; v++) {
+    const size_t k = (size_t)c->h_vdiag[v];
+    dinv[2 * v] = 1.0 / a00[4 * k]; dinv[2 * v + 1] = 1.0 / a00[4 * k + 3];
+  }
+  S.n = S.m = nvo;
+  std::vector<std::vector<int>> cols(nvo);
+  std::vector<std::vector<double>> vals(nvo);
+#pragma omp parallel num_threads(cfdh_host_threads())
+  {
+    std::vector<int> mark(nvo, -1), list;
+    std::vector<double> acc(nvo, 0.0);
+#pragma omp for schedule(dynamic, 512)
+    for (int i = 0; i < nvo; i++) {
+      list.clear();
+      for (int k = vp[i]; k < vp[i + 1]; k++) {
+        const int w = vc[k];
+        if (w >= nvo) continue;
+        if (mark[w] != i) { mark[w] = i; acc[w] = 0.0; list.push_back(w); }
+        acc[w] += a11[k];
+        const double s0 = a10[2 * (size_t)k] * dinv[2 * w], s1 = a10[2 * (size_t)k + 1] * dinv[2 * w + 1];
+        if (s0 == 0.0 && s1 == 0.0) continue;
+        for (int k2 = vp[w]; k2 < vp[w + 1]; k2++) {
+          const int j = vc[k2];
+          if (j >= nvo) continue;
+          if (mark[j] != i) { mark[j] = i; acc[j] = 0.0; list.push_back(j); }
+          acc[j] -= s0 * a01[2 * (size_t)k2] + s1 * a01[2 * (size_t)k2 + 1];
+        }
+      }
+      std::sort(list.begin(), list.end());
+      cols[i] = list;
+      vals[i].resize(list.size());
+      for (size_t t = 0; t < list.size(); t++) vals[i][t] = acc[list[t]];
+    }
+  }
+  S.rowptr.assign(nvo + 1, 0);
+  for (int i = 0; i < nvo; i++) S.rowptr[i + 1] = S.rowptr[i] + (int)cols[i].size();
+  S.col.resize(S.rowptr[nvo]); S.val.resize(S.rowptr[nvo]);
+  for (int i = 0; i < nvo; i++) {
+    std::copy(cols[i].begin(), cols[i].end(), S.col.begin() + S.rowptr[i]);
+    std::copy(vals[i].begin(), vals[i].end(), S.val.begin() + S.rowptr[i]);
+  }
+  return 0;
+}
+
+// refresh the parts of the preconditioner that follow the current Jacobian:
+// always the Jacobi diagonal and the spectral bound of D^-1 A00; the Sp
+// hierarchy only when asked (lagged preconditioner)
+int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
+  const int nu = 2 * c->nvo;
+  CHK(k_extract_diag(c));
+  // lambda_max(D^-1 A00) by power iteration from a fixed start vector
+  double *v = c->pu0.p, *w = c->pu1.p;
+  CHK(v_copy(c, nu, c->prand.p, v));
+  double lam = 1.0;
+  for (int it = 0; it < 8; it++) {
+    CHK(k_spmv_block(c, 1, v, w, nullptr, 0));
+    CHK(v_pointwise_mult(c, nu, w, c->dinvA.p, w));
+    CHK(v_norm_to_dev(c, nu, w, c->red_out.p + 4));
+    CHK(v_scale_inv_dev(c, nu, w, c->red_out.p + 4, v));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->red_out.p + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  lam = c->h_pinned[0];
+  if (!(lam > 0) || !std::isfinite(lam)) return cfdh_fail(c, CFDH_E_DIVERGED, "non-finite spectral estimate of D^-1 A00 (NaN in the Jacobian?)");
+  c->lmaxA = 1.15 * lam;
+  if (refresh_amg || !c->pc_valid) {
+    CsrHost S;
+    CHK(build_schur_host(c, S));
+    CHK(cfdh_amg_setup(c, S));
+    c->pc_valid = true;
+    c->pc_its_ref = 0;
+    c->steps_since_refresh = 0;
+    c->last_stats.pc_refreshes++;
+  }
+  return 0;
+}
+
+int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z) {
+  const int nvo = c->nvo, nu = 2 * nvo;
+  const double *ru = r, *rp = r + nu;
+  double *zu = z, *zp = z + nu;
+  CHK(k_cheb_a00(c, ru, c->pu0.p));                       // y_u = C(A00) r_u
+  CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));     // t_p = r_p - A10 y_u
+  CHK(k_amg_vcycle(c, c->pp0.p, zp));                     // z_p = V(Sp) t_p
+  if (c->opt.schur_full) {
+    CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));         // t_u = r_u - A01 z_p
+    CHK(k_cheb_a00(c, c->pu0.p, zu));                     // z_u = C(A00) t_u
+  } else {
+    CHK(v_copy(c, nu, c->pu0.p, zu));
+  }
+  if (c->singular) CHK(v_sub_mean(c, nvo, zp));
+  return 0;
+}
+
+static int ensure_krylov(cfdh_ctx *c) {
+  const int m = c->opt.ksp_restart;
+  if (c->kry_m == m && c->kV.p) return 0;
+  const size_t NL = (size_t)c->NL;
+  HIPCHK(c, c->kV.alloc(NL * (m + 1)));
+  HIPCHK(c, c->kZ.alloc(NL * m));
+  HIPCHK(c, c->kw.alloc(NL));
+  HIPCHK(c, c->kh.alloc(2 * (size_t)(m + 1) + 8));
+  HIPCHK(c, c->ky.alloc(m + 8));
+  HIPCHK(c, c->kV.zero(c->stream)); HIPCHK(c, c->kZ.zero(c->stream)); HIPCHK(c, c->kw.zero(c->stream));
+  if ((size_t)(m + 2) * 256 > c->red_partial.n) HIPCHK(c, c->red_partial.alloc((size_t)(m + 2) * 256 + 1024));
+  c->kry_m = m;
+  return 0;
+}
+
+// Solve J x = b, x0 = 0.  Right preconditioning, convergence on the true
+// residual norm relative to |b| (KSP defaults: rtol, atol; KSP_NORM_UNPRECONDITIONED
+// for FGMRES).  Classical Gram-Schmidt with one re-orthogonalisation pass; the
+// 2j+3 scalars of an iteration come back in a single read.
+int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reason_out) {
+  CHK(ensure_krylov(c));
+  const int n = c->NO, m = c->kry_m;
+  const size_t ld = (size_t)c->NL;
+  const cfdh_options &o = c->opt;
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hh(2 * (size_t)(m + 1) + 8);
+  double bn;
+  CHK(v_zero(c, c->NL, x));
+  CHK(v_norm2(c, n, b, &bn));
+  int its = 0, reason = 0;
+  if (!std::isfinite(bn)) { *its_out = 0; *reason_out = -9; return 0; }
+  if (bn == 0.0) { *its_out = 0; *reason_out = 2; return 0; }
+  const double tol = std::max(o.ksp_rtol * bn, o.ksp_atol);
+  double *V = c->kV.p, *Z = c->kZ.p, *w = c->kw.p, *hd = c->kh.p;
+  bool first = true;
+  for (;;) {
+    double beta;
+    if (first) {
+      CHK(v_copy(c, n, b, V));  // r0 = b
+      beta = bn;
+      first = false;
+    } else {
+      CHK(comm_halo(c, x));
+      CHK(k_spmv_full(c, x, w));
+      CHK(v_waxpy(c, n, -1.0, w, b, V));
+      CHK(v_norm2(c, n, V, &beta));
+    }
+    if (beta <= tol) { reason = 2; break; }
+    if (its >= o.ksp_max_it) { reason = -3; break; }
+    if (!std::isfinite(beta)) { reason = -9; break; }
+    CHK(v_scale(c, n, 1.0 / beta, V));
+    std::fill(g.begin(), g.end(), 0.0);
+    g[0] = beta;
+    int j = 0;
+    bool done = false;
+    for (; j < m && its < o.ksp_max_it; j++) {
+      double *vj = V + (size_t)j * ld, *zj = Z + (size_t)j * ld, *vn = V + (size_t)(j + 1) * ld;
+      CHK(cfdh_pc_apply(c, vj, zj));
+      CHK(comm_halo(c, zj));
+      CHK(k_spmv_full(c, zj, w));
+      // CGS2: h1 = V^T w ; w -= V h1 ; h2 = V^T w ; w -= V h2 ; hn = |w|
+      CHK(v_multidot(c, n, V, (int)ld, j + 1, w, hd));
+      CHK(v_multiaxpy(c, n, V, (int)ld, j + 1, hd, w));
+      CHK(v_multidot(c, n, V, (int)ld, j + 1, w, hd + (m + 1)));
+      CHK(v_multiaxpy(c, n, V, (int)ld, j + 1, hd + (m + 1), w));
+      CHK(v_norm_to_dev(c, n, w, hd + 2 * (m + 1)));
+      CHK(v_scale_inv_dev(c, n, w, hd + 2 * (m + 1), vn));
+      HIPCHK(c, hipMemcpyAsync(c->h_pinned, hd, sizeof(double) * (2 * (size_t)(m + 1) + 1), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      double *Hj = &H[(size_t)j * (m + 1)];
+      for (int i = 0; i <= j; i++) Hj[i] = c->h_pinned[i] + c->h_pinned[(m + 1) + i];
+      Hj[j + 1] = c->h_pinned[2 * (m + 1)];
+      for (int i = 0; i < j; i++) {
+        const double t = cs[i] * Hj[i] + sn[i] * Hj[i + 1];
+        Hj[i + 1] = -sn[i] * Hj[i] + cs[i] * Hj[i + 1];
+        Hj[i] = t;
+      }
+      const double d = std::hypot(Hj[j], Hj[j + 1]);
+      if (!(d > 0) || !std::isfinite(d)) { reason = -9; done = true; j++; break; }
+      cs[j] = Hj[j] / d; sn[j] = Hj[j + 1] / d;
+      Hj[j] = d; Hj[j + 1] = 0.0;
+      g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
+      its++;
+      if (o.verbose > 1) fprintf(stderr, "[cfdh]     fgmres %3d  |r|/|b| = %.3e\n", its, std::fabs(g[j + 1]) / bn);
+      if (std::fabs(g[j + 1]) <= tol) { j++; done = true; break; }
+    }
+    if (reason == -9) break;
+    // y = H^-1 g ; x += Z y
+    for (int i = j - 1; i >= 0; i--) {
+      double s = g[i];
+      for (int k = i + 1; k < j; k++) s -= H[(size_t)k * (m + 1) + i] * y[k];
+      y[i] = s / H[(size_t)i * (m + 1) + i];
+    }
+    HIPCHK(c, hipMemcpyAsync(c->ky.p, y.data(), sizeof(double) * j, hipMemcpyHostToDevice, c->stream));
+    CHK(v_lincomb(c, n, Z, (int)ld, j, c->ky.p, x));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // y is a host temporary
+    (void)done;
+  }
+  *its_out = its;
+  *reason_out = reason;
+  return 0;
+}
+
+static int upload_bc(cfdh_ctx *c) {
+  if (!c->bc_dirty) return 0;
+  HIPCHK(c, hipMemcpyAsync(c->bcflag.p, c->h_bcflag.data(), c->h_bcflag.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->bcval.p, c->h_bcval.data(), sizeof(double) * c->h_bcval.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->bcmult.p, c->h_bcmult.data(), sizeof(double) * c->h_bcmult.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->bc_dirty = false;
+  return 0;
+}
+
+int cfdh_prepare_assembly(cfdh_ctx *c) {
+  CHK(upload_bc(c));
+  if (!c->mom_valid) {
+    CHK(comm_halo(c, c->xprev.p));
+    CHK(k_moments(c));
+  }
+  return 0;
+}
+
+int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
+  const int n = c->NO, nvo = c->nvo;
+  const cfdh_options &o = c->opt;
+  const double t_begin = wall_ms();
+  memset(st, 0, sizeof *st);
+  c->last_stats = *st;
+  if (!c->params_set) return cfdh_fail(c, CFDH_E_STATE, "cfdh_set_params was not called");
+  if (!c->state_set) return cfdh_fail(c, CFDH_E_STATE, "cfdh_set_state was not called");
+  CHK(cfdh_prepare_assembly(c));
+  if (o.remove_p_mean) CHK(v_sub_mean(c, nvo, c->x.p + 2 * (size_t)nvo));
+  CHK(comm_halo(c, c->x.p));
+  double t0 = wall_ms();
+  CHK(k_assemble(c, c->x.p, 1));
+  double fn;
+  CHK(v_norm2(c, n, c->F.p, &fn));
+  st->ms_assemble += wall_ms() - t0;
+  st->fnorm0 = fn;
+  // constant-pressure null space (MatNullSpaceTest: |J n| < 1e-7 for the unit vector n)
+  {
+    double nrm;
+    CHK(k_nullspace_test(c, &nrm));
+    const double np = c->nranks > 1 ? c->nvo_global : (double)nvo;
+    const int sing = (nrm / std::sqrt(np)) < 1e-7 ? 1 : 0;
+    if (sing != c->singular) { c->singular = sing; c->pc_valid = false; }
+  }
+  bool force_refresh = (o.pc_refresh > 0 && c->steps_since_refresh >= o.pc_refresh);
+  int reason = 0;
+  double *x = c->x.p, *xt = c->xt.p, *d = c->dvec.p;
+  for (int it = 0;; it++) {
+    if (o.verbose) fprintf(stderr, "[cfdh]   newton %d |F| = %.6e\n", it, fn);
+    if (!std::isfinite(fn)) { reason = CFDH_DIVERGED_FNORM_NAN; break; }
+    if (fn < o.snes_atol) { reason = CFDH_CONVERGED_FNORM_ABS; break; }
+    if (it > 0 && fn <= o.snes_rtol * st->fnorm0) { reason = CFDH_CONVERGED_FNORM_RELATIVE; break; }
+    if (it >= o.snes_max_it) { reason = CFDH_DIVERGED_MAX_IT; break; }
+    t0 = wall_ms();
+    CHK(cfdh_pc_update(c, force_refresh || o.pc_refresh < 0));
+    force_refresh = false;
+    st->ms_pc_setup += wall_ms() - t0;
+    t0 = wall_ms();
+    int kits = 0, kreason = 0;
+    CHK(cfdh_fgmres(c, c->F.p, d, &kits, &kreason));
+    if (kreason < 0 && c->pc_its_ref > 0) {
+      // a lagged hierarchy that stopped working: rebuild once and retry
+      CHK(cfdh_pc_update(c, true));
+      st->krylov_its += kits;
+      CHK(cfdh_fgmres(c, c->F.p, d, &kits, &kreason));
+    }
+    st->krylov_its += kits;
+    st->ms_solve += wall_ms() - t0;
+    if (kreason < 0) { reason = CFDH_DIVERGED_LINEAR_SOLVE; cfdh_fail(c, CFDH_E_DIVERGED, "FGMRES failed (reason %d) after %d iterations", kreason, kits); break; }
+    if (c->pc_its_ref == 0) c->pc_its_ref = std::max(kits, 1);
+    else if (o.pc_refresh == 0 && kits > (3 * c->pc_its_ref) / 2 + 5) force_refresh = true;  // adaptive lagging
+    // backtracking line search on 1/2 |F|^2 (Dennis-Schnabel, alpha = 1e-4)
+    t0 = wall_ms();
+    double lam = 1.0, fnew = 0.0;
+    bool ok = false;
+    for (int ls = 0; ls < 40; ls++) {
+      CHK(v_waxpy(c, n, -lam, d, x, xt));
+      CHK(comm_halo(c, xt));
+      CHK(k_assemble(c, xt, 1));  // residual and Jacobian at the trial point in one pass
+      CHK(v_norm2(c, n, c->F.p, &fnew));
+      if (std::isfinite(fnew) && (fnew * fnew <= fn * fn * (1.0 - 2.0e-4 * lam) || fnew < o.snes_atol)) { ok = true; break; }
+      double l2 = std::isfinite(fnew) ? fn * fn * lam * lam / (2.0 * (0.5 * fnew * fnew - 0.5 * fn * fn + fn * fn * lam)) : 0.0;
+      if (!(l2 > 0.1 * lam)) l2 = 0.1 * lam;
+      if (l2 > 0.5 * lam) l2 = 0.5 * lam;
+      lam = l2;
+    }
+    st->ms_assemble += wall_ms() - t0;
+    if (!ok) { reason = CFDH_DIVERGED_LINE_SEARCH; break; }
+    double dn, xn;
+    CHK(v_norm2(c, n, d, &dn));
+    CHK(v_norm2(c, n, xt, &xn));
+    std::swap(c->x.p, c->xt.p);
+    x = c->x.p; xt = c->xt.p;
+    st->newton_its = it + 1;
+    fn = fnew;
+    if (lam * dn < o.snes_stol * xn && fn > o.snes_rtol * st->fnorm0 && fn >= o.snes_atol) {
+      if (o.verbose) fprintf(stderr, "[cfdh]   newton %d |F| = %.6e (stol)\n", it + 1, fn);
+      reason = CFDH_CONVERGED_SNORM_RELATIVE;
+      break;
+    }
+  }
+  c->steps_since_refresh++;
+  st->fnorm = fn;
+  st->reason = reason;
+  st->pc_refreshes = c->last_stats.pc_refreshes;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  st->ms_total = wall_ms() - t_begin;
+  c->last_stats = *st;
+  if (reason < 0) {
+    if (c->err.empty() || reason != CFDH_DIVERGED_LINEAR_SOLVE) cfdh_fail(c, CFDH_E_DIVERGED, "Did not converge, reason: %d.", reason);
+    return CFDH_E_DIVERGED;
+  }
+  return 0;
+}

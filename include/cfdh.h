@@ -1,0 +1,199 @@
+/*
+ * cfdh.h -- C ABI of libcfdh.so: the MI355X (gfx950) implementation of the
+ * per-time-step hot path of the reference's `stabilized_schur` solver.
+ *
+ * The reference has no C-level interface for this path: its boundary is the
+ * duck-typed Python plugin surface
+ *     Solver(mesh, dt, rho, mu, f, initial_velocity=None, **kw)
+ *     Solver.setup(bcu, bcp, facet_tags=None, tags=None)
+ *     Solver.solveStep()
+ * (/root/reference/src/solvers/stabilized_schur.py:40-52,177-183,313 and
+ * /root/reference/src/solverBase.py:25-40,96-102), behind which DOLFINx/PETSc
+ * do the arithmetic.  Each entry point below cites the reference lines whose
+ * work it performs; INTEGRATION.md shows the ctypes stub that binds them from
+ * the reference's own `Solver` class.
+ *
+ * Conventions: every function returns 0 on success or a negative CFDH_E_*
+ * code and never throws; cfdh_last_error() gives the message.  All pointer
+ * arguments are caller-owned, C-contiguous host buffers that are copied at the
+ * call; outputs are written into caller-allocated buffers.  One context per
+ * GPU / per process rank; a context is not thread-safe.  Doubles are IEEE
+ * binary64, indices int32 (sizes int64), as in the reference
+ * (PETSc.ScalarType = float64, /root/reference/src/solverBase.py:37).
+ *
+ * Local numbering (multi-GPU): a context holds the vertices [0,nv) of its
+ * part, the first nv_owned of them owned, the rest ghosts (one-cell overlap;
+ * SURVEY.md 8e).  Velocity arrays are vertex-major/component-minor
+ * (u[2*v+i]), as DOLFINx lays out the blocked P1 space
+ * (stabilized_schur.py:55-57).
+ */
+#ifndef CFDH_H
+#define CFDH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFDH_ABI_VERSION 1
+
+enum {
+  CFDH_OK = 0,
+  CFDH_E_ARG = -1,      /* bad argument (ValueError on the Python side) */
+  CFDH_E_HIP = -2,      /* HIP runtime / device error */
+  CFDH_E_STATE = -3,    /* call out of order (e.g. solve before set_params) */
+  CFDH_E_DIVERGED = -4, /* Newton / Krylov did not converge (RuntimeError) */
+  CFDH_E_COMM = -5,     /* RCCL / halo exchange failure */
+  CFDH_E_NOMEM = -6
+};
+
+/* converged reasons, numbered after PETSc's SNESConvergedReason
+ * (stabilized_schur.py:332-334 raises on reason < 0) */
+enum {
+  CFDH_CONVERGED_FNORM_ABS = 2,
+  CFDH_CONVERGED_FNORM_RELATIVE = 3,
+  CFDH_CONVERGED_SNORM_RELATIVE = 4,
+  CFDH_DIVERGED_LINEAR_SOLVE = -3,
+  CFDH_DIVERGED_MAX_IT = -5,
+  CFDH_DIVERGED_LINE_SEARCH = -6,
+  CFDH_DIVERGED_FNORM_NAN = -4
+};
+
+typedef struct cfdh_ctx cfdh_ctx;
+
+typedef struct cfdh_options {
+  /* Newton: PETSc SNES defaults, cap of stabilized_schur.py:270 */
+  double snes_rtol, snes_atol, snes_stol;
+  int32_t snes_max_it;
+  /* outer FGMRES: PETSc KSP defaults, caps of stabilized_schur.py:272-273 */
+  double ksp_rtol, ksp_atol;
+  int32_t ksp_max_it, ksp_restart;
+  /* GPU preconditioner (replaces PCFIELDSPLIT Schur FULL/SELFP + ILU(0),
+   * stabilized_schur.py:231-264) */
+  int32_t cheb_degree;      /* Jacobi-Chebyshev sweeps per A00 solve */
+  double cheb_ratio;        /* lambda_max / lambda_min targeted */
+  int32_t schur_full;       /* 1: FULL factorisation (2 A00 solves), 0: LOWER+diag */
+  int32_t amg_smooth_degree;
+  double amg_smooth_ratio;
+  double amg_theta;         /* strength threshold of the aggregation */
+  int32_t amg_max_coarse;
+  int32_t pc_refresh;       /* 0: adaptive lagging of the Sp hierarchy, n>0: every n steps, -1: every Jacobian */
+  int32_t remove_p_mean;    /* nullsp.remove(x_n), stabilized_schur.py:319 */
+  int32_t verbose;
+} cfdh_options;
+
+typedef struct cfdh_stats {
+  int32_t newton_its, krylov_its, reason, pc_refreshes;
+  double fnorm0, fnorm;
+  double ms_assemble, ms_solve, ms_pc_setup, ms_total;
+} cfdh_stats;
+
+/* ---- life cycle --------------------------------------------------------- */
+
+/* Upload a (part of a) P1 triangle mesh and build the fixed CSR pattern.
+ * Replaces: functionspace/Function/create_matrix_block/create_vector_block
+ * (solverBase.py:104-142, stabilized_schur.py:55-57,191-193) and the DG0 cell
+ * size h = mesh.h (stabilized_schur.py:82-88).
+ * gdim must be 2.  cells [nc][3]; coords [nv][gdim];
+ * exterior facets: owning cell, local facet index (= local index of the
+ * opposite vertex), marker (0 = untagged). */
+int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_owned, int64_t nc,
+                const int32_t *cells, const double *coords, int64_t nfacets, const int32_t *facet_cells,
+                const int32_t *facet_local, const int32_t *facet_marker);
+void cfdh_destroy(cfdh_ctx *ctx);
+const char *cfdh_last_error(const cfdh_ctx *ctx); /* ctx may be NULL after a failed create */
+int cfdh_abi_version(void);
+
+/* dt, rho, mu Constants and body force (solverBase.py:36-40); mu_facet is the
+ * raw python float used in the ds term (stabilized_schur.py:79). */
+int cfdh_set_params(cfdh_ctx *ctx, double dt, double rho, double mu, double mu_facet, const double f[3]);
+int cfdh_default_options(cfdh_options *opt);
+int cfdh_set_options(cfdh_ctx *ctx, const cfdh_options *opt);
+
+/* ---- Dirichlet data ------------------------------------------------------ */
+
+/* Drop all DirichletBC objects (stabilized_schur.py:198-199 rebuilds them in setup). */
+int cfdh_clear_dirichlet(cfdh_ctx *ctx);
+/* Append one DirichletBC object (boundaryCondition.py:41-52): field 0 = velocity
+ * (values [n][gdim]), 1 = pressure (values [n]).  A later object overrides the
+ * value of a shared dof; the matrix diagonal counts the objects holding it.
+ * Re-callable every step (bc.update(), stabilized_schur.py:170). */
+int cfdh_add_dirichlet(cfdh_ctx *ctx, int field, int64_t n, const int32_t *nodes, const double *values);
+
+/* ---- state ---------------------------------------------------------------- */
+
+/* u_prev/p_prev (solverBase.py:121,139) and the Newton iterate x_n = (u,p)
+ * (stabilized_schur.py:216-223).  NULL keeps the device copy.  Arrays cover
+ * all nv local vertices (ghost entries are overwritten by the halo exchange). */
+int cfdh_set_state(cfdh_ctx *ctx, const double *u_prev, const double *p_prev, const double *u, const double *p);
+/* u_sol/p_sol after the step = the Newton iterate (updateSolution, :125-142) */
+int cfdh_get_solution(cfdh_ctx *ctx, double *u, double *p);
+/* u_residual/p_residual (_updateResidual, :295-311) */
+int cfdh_get_residual(cfdh_ctx *ctx, double *ru, double *rp);
+/* device-side u_prev <- u_sol, p_prev <- p_sol (scenario.py:306-307) */
+int cfdh_advance(cfdh_ctx *ctx);
+
+/* ---- assembly (exposed for parity tests) ---------------------------------- */
+
+/* assembleResidual (+ assembleJacobian when want_jacobian) at the current
+ * iterate: stabilized_schur.py:144-175. */
+int cfdh_assemble(cfdh_ctx *ctx, int want_jacobian);
+/* Monolithic scalar CSR of the owned rows in the reference's block ordering
+ * ([all u dofs | all p dofs], stabilized_schur.py:194-196,237-252), local
+ * column numbering.  Call with rowptr=col=vals=NULL to query nnz. */
+int cfdh_get_csr(cfdh_ctx *ctx, int64_t *nnz, int32_t *rowptr, int32_t *col, double *vals);
+/* y = J x on the device with the assembled Jacobian; x: [2*nv | nv] monolithic
+ * local vector, y: owned rows [2*nv_owned | nv_owned]. */
+int cfdh_spmv(cfdh_ctx *ctx, const double *x, double *y);
+
+/* ---- the step ------------------------------------------------------------- */
+
+/* solveStep (stabilized_schur.py:313-334): null-space handling, Newton with
+ * line search, FGMRES + block-Schur preconditioner; returns CFDH_E_DIVERGED
+ * with stats->reason < 0 when the reference would raise RuntimeError. */
+int cfdh_solve_step(cfdh_ctx *ctx, cfdh_stats *stats);
+
+/* kind 0: F_D, 1: F_L over the exterior facets of `marker`
+ * (/root/reference/src/scenarios/dfg_1.py:183-202; the scenario prints 500*F),
+ * 2: ||u||_L2, 3: ||p||_L2 (/root/reference/src/scenario.py:315-324),
+ * 4: ||u_sol||_inf, 5: ||u_prev||_inf, 6: ||u_sol-u_prev||_inf (scenario.py:268-280).
+ * Sums/maxima over the owned part; the caller (or the communicator) reduces. */
+int cfdh_functional(cfdh_ctx *ctx, int kind, int marker, double *out);
+
+/* ---- multi-GPU ---------------------------------------------- */
+
+/* Halo plan in local vertex numbers: for neighbour k, send_idx[send_ptr[k]..send_ptr[k+1])
+ * are owned vertices whose values go to rank nbr_rank[k]; recv_idx likewise the
+ * ghosts filled from it (ghosts must be numbered contiguously per neighbour, in
+ * neighbour order, starting at nv_owned). */
+int cfdh_set_halo(cfdh_ctx *ctx, int nnbr, const int32_t *nbr_rank, const int64_t *send_ptr,
+                  const int32_t *send_idx, const int64_t *recv_ptr, const int32_t *recv_idx);
+/* RCCL over xGMI: rank 0 creates the 128-byte unique id, the launcher
+ * broadcasts it, every rank calls cfdh_comm_init. */
+int cfdh_comm_unique_id(void *id128);
+int cfdh_comm_init(cfdh_ctx *ctx, const void *id128, int rank, int nranks);
+/* Host-staged alternative (CPU/gloo tests, debugging): the library calls back
+ * with host buffers.  allreduce: in-place sum (op 0) / max (op 1) of n doubles;
+ * exchange: send/recv byte buffers per neighbour as laid out by cfdh_set_halo
+ * (3 doubles per vertex: ux, uy, p). */
+typedef int (*cfdh_allreduce_fn)(void *user, double *buf, int n, int op);
+typedef int (*cfdh_exchange_fn)(void *user, const double *sendbuf, double *recvbuf);
+int cfdh_comm_set_callbacks(cfdh_ctx *ctx, cfdh_allreduce_fn ar, cfdh_exchange_fn ex, void *user, int rank, int nranks);
+
+/* ---- measurement ------------------------------------------------------------ */
+
+/* HIP-event timing of the hot kernels on the library's stream.
+ * kind 0: fused residual+Jacobian assembly, 1: monolithic SpMV, 2: tau moments,
+ * 3: A00 SpMV (Chebyshev sweep), 4: scalar CSR SpMV on Sp. */
+int cfdh_profile_enable(cfdh_ctx *ctx, int on);
+int cfdh_profile_get(cfdh_ctx *ctx, int kind, double *total_ms, int64_t *launches);
+int cfdh_profile_reset(cfdh_ctx *ctx);
+/* sizes for roofline accounting: 0 nv_owned, 1 nv, 2 nc, 3 vertex-graph nnz,
+ * 4 Sp nnz, 5 incidences, 6 AMG levels */
+int64_t cfdh_info(const cfdh_ctx *ctx, int what);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFDH_H */

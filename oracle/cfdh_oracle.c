@@ -289,7 +289,15 @@ orc_ctx *orc_create(int nv, int nc, const int *cells, const double *x, int nf, c
   c->Je = (double *)malloc(sizeof(double) * 81 * (size_t)nc);
   c->rho = 1; c->mu = 1; c->muf = 1; c->dt = 1;
 #ifdef _OPENMP
+  /* never oversubscribe a cgroup-limited box: default to <= 8 threads unless told otherwise */
   c->nthreads = omp_get_max_threads();
+  {
+    const char *e = getenv("CFDH_ORACLE_THREADS");
+    int cap = e ? atoi(e) : 8;
+    if (cap < 1) cap = 1;
+    if (c->nthreads > cap) c->nthreads = cap;
+    omp_set_num_threads(c->nthreads);
+  }
 #else
   c->nthreads = 1;
 #endif

@@ -1,0 +1,91 @@
+"""Shared problem builders for the tests: the BASELINE configs as plain arrays
+fed identically to the oracle (oracle/) and to the HIP library."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from cfd_hemodynamic_amd.fem import FunctionSpace, locate_dofs_topological  # noqa: E402
+from cfd_hemodynamic_amd.mesh import (create_dfg_channel, create_unit_square,  # noqa: E402
+                                      locate_entities_boundary)
+
+
+class Case:
+    """mesh + list of DirichletBC objects in reference order + physical parameters."""
+
+    def __init__(self, mesh, bcs, dt, rho, mu, f=(0.0, 0.0), markers=None):
+        self.mesh = mesh
+        self.bcs = bcs  # [(field, nodes int32, values)]
+        self.dt, self.rho, self.mu, self.f = dt, rho, mu, f
+        self.markers = markers or {}
+
+    @property
+    def nv(self):
+        return self.mesh.num_vertices
+
+
+def dfg_case(m, dt=0.01):
+    """DFG 2D-1 (dfg_1.py:55-91): inlet parabola on marker 2, no-slip on obstacle 5 and
+    walls 4 (that order: [inflow, obstacle, walls]), p=0 on outlet 3; rho=1, mu=1e-3."""
+    mesh, ft = create_dfg_channel(m)
+    V = FunctionSpace(mesh, 2)
+
+    def nodes(mk):
+        return locate_dofs_topological(V, 1, ft.find(mk))
+
+    inl = nodes(2)
+    y = mesh.x[inl, 1]
+    bcs = [
+        (0, inl, np.stack([4 * 0.3 * y * (0.41 - y) / 0.41**2, 0 * y], 1)),
+        (0, nodes(5), np.zeros((len(nodes(5)), 2))),
+        (0, nodes(4), np.zeros((len(nodes(4)), 2))),
+        (1, nodes(3), np.zeros(len(nodes(3)))),
+    ]
+    return Case(mesh, bcs, dt, 1.0, 1e-3, markers={"obstacle": 5, "ft": ft})
+
+
+def lid_case(nx, dt=0.01, mu=0.01):
+    """Lid-driven cavity (lid_driven2D.py:35-75): no-slip walls then lid u=(1,0), no pressure BC."""
+    mesh = create_unit_square(nx)
+    V = FunctionSpace(mesh, 2)
+    walls = locate_entities_boundary(
+        mesh, 1, lambda x: np.logical_or.reduce((np.isclose(x[0], 0), np.isclose(x[0], 1), np.isclose(x[1], 0))))
+    lid = locate_entities_boundary(mesh, 1, lambda x: np.isclose(x[1], 1.0) & (x[0] > 1e-10) & (x[0] < 1.0 - 1e-10))
+    nw = locate_dofs_topological(V, 1, walls)
+    nl = locate_dofs_topological(V, 1, lid)
+    bcs = [(0, nw, np.zeros((len(nw), 2))), (0, nl, np.tile([1.0, 0.0], (len(nl), 1)))]
+    return Case(mesh, bcs, dt, 1.0, mu)
+
+
+def make_oracle(case):
+    from oracle import orc
+    m = case.mesh
+    O = orc.Oracle(m.x, m.cells, m.facet_cells, m.facet_local, case.dt, case.rho, case.mu, case.f)
+    for field, nodes, vals in case.bcs:
+        (O.add_bc_u if field == 0 else O.add_bc_p)(nodes, vals)
+    return O
+
+
+def make_twin(case):
+    from oracle import np_twin as T
+    m = case.mesh
+    pb = T.Problem(m.x, m.cells, m.facet_cells, m.facet_local, T.Params(case.dt, case.rho, case.mu, case.f))
+    for field, nodes, vals in case.bcs:
+        (pb.add_bc_u if field == 0 else pb.add_bc_p)(nodes, vals)
+    return pb
+
+
+def make_ctx(case, device=0):
+    from cfd_hemodynamic_amd import _lib
+    m = case.mesh
+    ctx = _lib.Context(m.x, m.cells, m.facet_cells, m.facet_local, m.facet_marker, device=device)
+    ctx.set_params(case.dt, case.rho, case.mu, f=case.f)
+    for field, nodes, vals in case.bcs:
+        ctx.add_dirichlet(field, nodes, vals)
+    return ctx
