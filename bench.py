@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: time steps per second of the stabilized_schur step on the
+DFG 2D-1 mesh refined to ~1M P1/P1 DOFs (BASELINE.json configs[2]).
+
+  python bench.py --gpus N --steps K --warmup W
+
+N=1 runs in-process; for N>1 the driver launches one rank per GPU with
+torch.distributed.run.  A "step" is one full time step (moments, Newton with
+fused residual/Jacobian assembly, FGMRES + Schur/AMG preconditioner, u_prev
+update) with every field resident in HBM.  Rank 0 prints ONE JSON line carrying
+`roofline` (dominant kernel, HIP-event timed inside the timed region) and, at
+N=1, `cpu_baseline` (the CPU oracle running the same algorithm on the same
+mesh for a bounded number of steps on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def host_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
+def kernel_bytes(ctx):
+    """Algorithmic HBM bytes per launch of the instrumented kernels (DESIGN.md section 'Kernels')."""
+    nvo, nnzv, nc, ninc, spnnz = (ctx.info(k) for k in (0, 3, 2, 5, 4))
+    return {
+        # fused residual+Jacobian: SURVEY.md 8d figure, 624 B per vertex
+        0: ("asm_residual_jacobian", 624.0 * nvo),
+        # block SpMV: values 72 B + column 4 B per graph entry; rowptr 4, x 24, y 24 per row
+        1: ("spmv_full_block3x3", 76.0 * nnzv + 52.0 * nvo),
+        # tau moments: cells 12 + coords/u_prev gathers 2*16*3 (per cell, L2-resident per vertex: 32 B) + 64 B record out
+        2: ("tau_moments", 12.0 * nc + 32.0 * nvo + 64.0 * nc),
+        # Chebyshev step on A00: values 32 B + column 4 B per entry; rowptr 4 + 7 vectors x 16 B per row
+        3: ("cheb_step_A00", 36.0 * nnzv + 116.0 * nvo),
+        # Chebyshev step on Sp (scalar CSR): 12 B per entry; rowptr 4 + 7 vectors x 8 B per row
+        4: ("cheb_step_Sp", 12.0 * spnnz + 60.0 * nvo),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--m", type=int, default=200, help="DFG mesh parameter (m=200: 336,474 vertices, 1,009,422 DOF)")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "host"])
+    ap.add_argument("--verbose", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # gloo carries only the bootstrap (RCCL unique id) and the timing reduction;
+        # halo exchange and Krylov all-reduces run on RCCL inside libcfdh.so
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libcfdh.so has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    from cfd_hemodynamic_amd.parallel import PartComm
+    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+
+    dt = 0.01
+    comm = PartComm(rank, world, args.comm) if world > 1 else None
+    t0 = time.perf_counter()
+    sc = DFG1Benchmark("stabilized_schur", dt, 1.0, m=args.m, quiet=True, device=local_rank, comm=comm,
+                       verbose=args.verbose)
+    solver = sc.solver
+    ctx = solver.ctx
+    t_setup = time.perf_counter() - t0
+    nv = sc.mesh.num_vertices
+    ndof = 3 * nv
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    its_newton, its_krylov = [], []
+    for _ in range(args.warmup):
+        solver.solveStep()
+        solver.advance()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    sync_all()
+    t0 = time.perf_counter()
+    ms_asm = ms_solve = ms_pc = 0.0
+    for _ in range(args.steps):
+        solver.solveStep()
+        solver.advance()
+        st = solver.last_stats
+        its_newton.append(st.newton_its)
+        its_krylov.append(st.krylov_its)
+        ms_asm += st.ms_assemble
+        ms_solve += st.ms_solve
+        ms_pc += st.ms_pc_setup
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    # parity metrics of the run (global values)
+    drag, lift = sc.drag_lift()
+    l2u = solver.functional(2)
+
+    # roofline of the dominant instrumented kernel
+    kb = kernel_bytes(ctx)
+    kern = []
+    for kind, (name, nbytes) in kb.items():
+        ms, n = ctx.profile_get(kind)
+        if n:
+            kern.append({"kernel": name, "launches": n, "avg_us": 1e3 * ms / n, "total_ms": ms,
+                         "algorithmic_MB": nbytes / 1e6, "GBps": nbytes / (ms / n * 1e-3) / 1e9})
+    kern.sort(key=lambda k: -k["total_ms"])
+    roof = None
+    if kern:
+        d = kern[0]
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(d["kernel"])
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": d["kernel"], "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "avg_us": d["avg_us"],
+                "algorithmic_bytes": d["algorithmic_MB"] * 1e6}
+
+    out = {
+        "metric": "time-steps/sec, dfg_1 ~1M DOF (stabilized_schur)",
+        "value": args.steps / elapsed,
+        "unit": "time-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "dfg_1 (DFG 2D-1, Re=20) block-structured mesh m=%d: %d vertices, %d P1/P1 DOF, "
+                               "dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)"
+                               % (args.m, nv, ndof, dt),
+                   "parallelism": "element partition x%d (RCB), halo + dot all-reduce on %s" % (world, args.comm)},
+        "ms_assemble_per_step": ms_asm / args.steps,
+        "ms_solve_per_step": ms_solve / args.steps,
+        "ms_pc_setup_per_step": ms_pc / args.steps,
+        "newton_its_per_step": float(np.mean(its_newton)),
+        "krylov_its_per_step": float(np.mean(its_krylov)),
+        "setup_s": t_setup,
+        "drag_coefficient": drag,
+        "lift_coefficient": lift,
+        "velocity_l2": l2u,
+        "roofline": roof,
+        "kernels": kern,
+    }
+
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        from util import dfg_case, make_oracle
+        from oracle import orc
+        cores = min(host_cores(), 16)
+        os.environ["CFDH_ORACLE_THREADS"] = str(cores)
+        case = dfg_case(args.m, dt)
+        O = make_oracle(case)
+        O.set_threads(cores)
+        x = np.zeros(3 * nv)
+        O.set_un(np.zeros(2 * nv))
+        opts = orc.default_opts(pc_kind=1)  # same Newton/FGMRES/Schur/Chebyshev/AMG algorithm and tolerances
+        t0 = time.perf_counter()
+        nst = 0
+        for _ in range(args.warmup + args.cpu_steps):
+            ts = time.perf_counter()
+            x, so = O.solve_step(x, opts)
+            O.set_un(x[: 2 * nv])
+            nst += 1
+            if nst == args.warmup:
+                t0 = time.perf_counter()
+            if time.perf_counter() - t0 > 60.0 and nst > args.warmup:
+                break
+        ncpu = nst - args.warmup
+        tcpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": ncpu / tcpu, "unit": "time-steps/s", "cores": cores, "kind": "port",
+            "sample": "steps %d..%d of the same mesh/dt from t=0 with the C oracle (oracle/cfdh_oracle.c, pc_kind=1: "
+                      "same Newton + FGMRES + Schur/Chebyshev/AMG algorithm and tolerances, OpenMP)" % (args.warmup + 1, nst),
+            "ms_per_step": 1e3 * tcpu / max(ncpu, 1),
+        }
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

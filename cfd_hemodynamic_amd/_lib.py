@@ -42,7 +42,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp)
 SYMBOLS = [
     "cfdh_create", "cfdh_destroy", "cfdh_last_error", "cfdh_abi_version", "cfdh_set_params", "cfdh_default_options",
     "cfdh_set_options", "cfdh_clear_dirichlet", "cfdh_add_dirichlet", "cfdh_set_state", "cfdh_get_solution",
-    "cfdh_get_residual", "cfdh_advance", "cfdh_assemble", "cfdh_get_csr", "cfdh_spmv", "cfdh_solve_step",
+    "cfdh_get_previous", "cfdh_get_residual", "cfdh_advance", "cfdh_assemble", "cfdh_get_csr", "cfdh_spmv", "cfdh_solve_step",
     "cfdh_functional", "cfdh_set_halo", "cfdh_comm_unique_id", "cfdh_comm_init", "cfdh_comm_set_callbacks",
     "cfdh_profile_enable", "cfdh_profile_get", "cfdh_profile_reset", "cfdh_info",
 ]
@@ -86,6 +86,7 @@ def lib():
     L.cfdh_set_state.argtypes = [vp, dp, dp, dp, dp]
     L.cfdh_get_solution.argtypes = [vp, dp, dp]
     L.cfdh_get_residual.argtypes = [vp, dp, dp]
+    L.cfdh_get_previous.argtypes = [vp, dp, dp]
     L.cfdh_advance.argtypes = [vp]
     L.cfdh_assemble.argtypes = [vp, C.c_int]
     L.cfdh_get_csr.argtypes = [vp, lp, ip, ip, dp]
@@ -197,6 +198,12 @@ class Context:
         u = np.empty(2 * self.nv) if u is None else u
         p = np.empty(self.nv) if p is None else p
         self._chk(self.L.cfdh_get_solution(self.h, _dp(u), _dp(p)))
+        return u, p
+
+    def get_previous(self, u=None, p=None):
+        u = np.empty(2 * self.nv) if u is None else u
+        p = np.empty(self.nv) if p is None else p
+        self._chk(self.L.cfdh_get_previous(self.h, _dp(u), _dp(p)))
         return u, p
 
     def get_residual(self):

@@ -9,6 +9,13 @@ std::string g_cfdh_last_error;
 
 int cfdh_prepare_assembly(cfdh_ctx *c);
 
+// every entry point makes the context's device current for the calling thread
+#define ENTER(c)                         \
+  do {                                   \
+    if (!(c)) return CFDH_E_ARG;         \
+    (void)hipSetDevice((c)->device);     \
+  } while (0)
+
 extern "C" {
 
 int cfdh_abi_version(void) { return CFDH_ABI_VERSION; }
@@ -75,7 +82,7 @@ void cfdh_destroy(cfdh_ctx *c) {
 }
 
 int cfdh_set_params(cfdh_ctx *c, double dt, double rho, double mu, double mu_facet, const double f[3]) {
-  if (!c) return CFDH_E_ARG;
+  ENTER(c);
   if (!(dt > 0) || !(rho > 0) || !(mu > 0)) return cfdh_fail(c, CFDH_E_ARG, "dt, rho, mu must be positive");
   const bool changed = !c->params_set || dt != c->dt || rho != c->rho || mu != c->mu;
   c->dt = dt; c->rho = rho; c->mu = mu; c->muf = mu_facet;
@@ -98,7 +105,7 @@ int cfdh_set_options(cfdh_ctx *c, const cfdh_options *o) {
 }
 
 int cfdh_clear_dirichlet(cfdh_ctx *c) {
-  if (!c) return CFDH_E_ARG;
+  ENTER(c);
   std::fill(c->h_bcflag.begin(), c->h_bcflag.end(), 0);
   std::fill(c->h_bcval.begin(), c->h_bcval.end(), 0.0);
   std::fill(c->h_bcmult.begin(), c->h_bcmult.end(), 0.0);
@@ -164,7 +171,7 @@ static int upload_vec(cfdh_ctx *c, const std::vector<double> &h, double *dev) {
 }
 
 int cfdh_set_state(cfdh_ctx *c, const double *u_prev, const double *p_prev, const double *u, const double *p) {
-  if (!c) return CFDH_E_ARG;
+  ENTER(c);
   std::vector<double> h, cur;
   if (u_prev || p_prev) {
     const std::vector<double> *keep = nullptr;
@@ -184,15 +191,23 @@ int cfdh_set_state(cfdh_ctx *c, const double *u_prev, const double *p_prev, cons
 }
 
 int cfdh_get_solution(cfdh_ctx *c, double *u, double *p) {
-  if (!c) return CFDH_E_ARG;
+  ENTER(c);
   std::vector<double> h;
   CHK(download_vec(c, c->x.p, h));
   unpack_vec(c, h, u, p);
   return 0;
 }
 
+int cfdh_get_previous(cfdh_ctx *c, double *u, double *p) {
+  ENTER(c);
+  std::vector<double> h;
+  CHK(download_vec(c, c->xprev.p, h));
+  unpack_vec(c, h, u, p);
+  return 0;
+}
+
 int cfdh_get_residual(cfdh_ctx *c, double *ru, double *rp) {
-  if (!c) return CFDH_E_ARG;
+  ENTER(c);
   std::vector<double> h;
   CHK(download_vec(c, c->F.p, h));
   // ghost entries of F are not defined: report zeros there
@@ -202,14 +217,14 @@ int cfdh_get_residual(cfdh_ctx *c, double *ru, double *rp) {
 }
 
 int cfdh_advance(cfdh_ctx *c) {
-  if (!c) return CFDH_E_ARG;
+  ENTER(c);
   CHK(v_copy(c, c->NL, c->x.p, c->xprev.p));
   c->mom_valid = false;
   return 0;
 }
 
 int cfdh_assemble(cfdh_ctx *c, int want_jacobian) {
-  if (!c) return CFDH_E_ARG;
+  ENTER(c);
   if (!c->params_set) return cfdh_fail(c, CFDH_E_STATE, "cfdh_set_params was not called");
   CHK(cfdh_prepare_assembly(c));
   CHK(comm_halo(c, c->x.p));
@@ -278,7 +293,7 @@ int cfdh_spmv(cfdh_ctx *c, const double *x, double *y) {
 }
 
 int cfdh_solve_step(cfdh_ctx *c, cfdh_stats *stats) {
-  if (!c) return CFDH_E_ARG;
+  ENTER(c);
   cfdh_stats st;
   c->err.clear();
   int rc = cfdh_newton_step(c, &st);
@@ -292,7 +307,7 @@ int cfdh_functional(cfdh_ctx *c, int kind, int marker, double *out) {
 }
 
 int cfdh_profile_enable(cfdh_ctx *c, int on) {
-  if (!c) return CFDH_E_ARG;
+  ENTER(c);
   prof_flush(c);
   c->prof_on = on != 0;
   return 0;
@@ -305,7 +320,7 @@ int cfdh_profile_get(cfdh_ctx *c, int kind, double *total_ms, int64_t *launches)
   return 0;
 }
 int cfdh_profile_reset(cfdh_ctx *c) {
-  if (!c) return CFDH_E_ARG;
+  ENTER(c);
   prof_flush(c);
   for (auto &p : c->prof) { p.total_ms = 0; p.launches = 0; }
   return 0;

@@ -30,9 +30,13 @@ NcclApi g_nccl;
 
 bool load_nccl(std::string &why) {
   if (g_nccl.lib) return true;
+  // reuse an RCCL the process already holds (PyTorch ships one, built against the HIP
+  // runtime that is then also ours) before loading the ROCm one
   const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
   void *h = nullptr;
-  for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+  for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD); if (h) break; }
+  if (!h)
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
   if (!h) { why = std::string("cannot dlopen librccl: ") + dlerror(); return false; }
 #define SYM(field, name)                                          \
   *(void **)(&g_nccl.field) = dlsym(h, name);                     \

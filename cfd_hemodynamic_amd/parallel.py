@@ -1,0 +1,231 @@
+"""Element partition of the mesh over the GPUs of one node.
+
+The reference's only parallel strategy is DOLFINx's MPI cell partition with
+ghost layers (`/root/reference/src/scenarios/dfg_1.py:105-167` builds the mesh on
+rank 0 and distributes it; every assembly/solve call is collective).  Here every
+rank generates the same (synthetic, deterministic) mesh, vertices are assigned to
+parts by recursive coordinate bisection, and each part keeps
+
+  * its owned vertices (numbered first, ascending global id),
+  * every cell touching an owned vertex (one-cell overlap, so that owned matrix
+    rows are complete without a reverse scatter-add), and
+  * the remaining vertices of those cells as ghosts, grouped by owner rank.
+
+`PartComm` carries the two exchanges of the hot path -- forward halo of the
+iterate and scalar all-reduce of the Krylov dots -- either on RCCL inside
+libcfdh.so (one process per GPU, xGMI) or, for tests, staged through the host
+over torch.distributed/gloo.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def partition_vertices_rcb(x, nparts):
+    """Recursive coordinate bisection of the vertex set into `nparts` parts of
+    (nearly) equal size; returns owner[nv] in [0,nparts).  Deterministic."""
+    x = np.asarray(x, dtype=np.float64)
+    owner = np.zeros(len(x), dtype=np.int32)
+
+    def rec(idx, p0, np_):
+        if np_ == 1:
+            owner[idx] = p0
+            return
+        nl = np_ // 2
+        pts = x[idx]
+        ext = pts.max(axis=0) - pts.min(axis=0)
+        ax = int(np.argmax(ext))
+        # stable order: coordinate then global index
+        order = np.lexsort((idx, pts[:, ax]))
+        k = (len(idx) * nl) // np_
+        rec(idx[order[:k]], p0, nl)
+        rec(idx[order[k:]], p0 + nl, np_ - nl)
+
+    rec(np.arange(len(x)), 0, int(nparts))
+    return owner
+
+
+class LocalPart:
+    """The piece of the global mesh that rank `rank` works on, in local numbering."""
+
+    def __init__(self, mesh, owner, rank):
+        cells = mesh.cells
+        nparts = int(owner.max()) + 1
+        self.rank, self.nparts = int(rank), nparts
+        cown = owner[cells]  # [nc,3]
+        mine = (cown == rank).any(axis=1)
+        self.cell_ids = np.nonzero(mine)[0]
+        lc = cells[self.cell_ids]
+        verts = np.unique(lc)
+        vown = owner[verts]
+        owned = verts[vown == rank]
+        ghosts = verts[vown != rank]
+        gorder = np.lexsort((ghosts, owner[ghosts]))
+        ghosts = ghosts[gorder]
+        self.owned_global = owned
+        self.ghost_global = ghosts
+        self.nvo, self.ng = len(owned), len(ghosts)
+        self.l2g = np.concatenate([owned, ghosts]).astype(np.int64)
+        g2l = -np.ones(mesh.num_vertices, dtype=np.int64)
+        g2l[self.l2g] = np.arange(len(self.l2g))
+        self.g2l = g2l
+        self.cells = g2l[lc].astype(np.int32)
+        self.x = mesh.x[self.l2g]
+        # exterior facets of the local cells
+        cmap = -np.ones(mesh.num_cells, dtype=np.int64)
+        cmap[self.cell_ids] = np.arange(len(self.cell_ids))
+        fsel = np.nonzero(cmap[mesh.facet_cells] >= 0)[0]
+        self.facet_ids = fsel
+        self.facet_cells = cmap[mesh.facet_cells[fsel]].astype(np.int32)
+        self.facet_local = mesh.facet_local[fsel].astype(np.int32)
+        self.facet_marker = mesh.facet_marker[fsel].astype(np.int32)
+        # halo plan
+        gown = owner[ghosts]
+        self.nbr = np.unique(gown).astype(np.int32)  # ranks I receive from
+        # vertices of mine needed by q: share a cell with a q-owned vertex
+        need = set()
+        send = {}
+        for a in range(3):
+            for b in range(3):
+                if a == b:
+                    continue
+                sel = (cown[:, a] == rank) & (cown[:, b] != rank)
+                if sel.any():
+                    pairs = np.stack([cown[sel, b], cells[sel, a]], axis=1)
+                    need.update(map(tuple, np.unique(pairs, axis=0)))
+        for q, v in sorted(need):
+            send.setdefault(int(q), []).append(int(v))
+        nbrs = sorted(set(self.nbr.tolist()) | set(send.keys()))
+        self.nbr = np.asarray(nbrs, dtype=np.int32)
+        sp, si, rp, ri = [0], [], [0], []
+        for q in nbrs:
+            sv = np.asarray(sorted(send.get(q, [])), dtype=np.int64)
+            si.extend(g2l[sv].tolist())
+            sp.append(len(si))
+            rv = np.nonzero(gown == q)[0] + self.nvo
+            ri.extend(rv.tolist())
+            rp.append(len(ri))
+        self.send_ptr = np.asarray(sp, dtype=np.int64)
+        self.send_idx = np.asarray(si, dtype=np.int32)
+        self.recv_ptr = np.asarray(rp, dtype=np.int64)
+        self.recv_idx = np.asarray(ri, dtype=np.int32)
+
+    @property
+    def nv(self):
+        return self.nvo + self.ng
+
+
+class PartComm:
+    """Communicator of a partitioned solve.  backend 'rccl': libcfdh.so talks RCCL
+    itself (the unique id is broadcast through torch.distributed); backend 'host':
+    host-staged exchange over the torch.distributed default group (gloo)."""
+
+    def __init__(self, rank=0, size=1, backend="rccl"):
+        self.rank, self.size, self.backend = int(rank), int(size), backend
+        self.part = None
+        self._keep = None
+
+    @classmethod
+    def from_torch(cls, backend="rccl"):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return cls(0, 1, backend)
+        return cls(dist.get_rank(), dist.get_world_size(), backend)
+
+    def make_part(self, mesh):
+        owner = partition_vertices_rcb(mesh.x, self.size)
+        self.owner = owner
+        self.part = LocalPart(mesh, owner, self.rank)
+        return self.part
+
+    # -- collective helpers on the host (norms, gathers of the harness) -------------
+    def allreduce(self, value, op="sum"):
+        if self.size == 1:
+            return value
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def barrier(self):
+        if self.size > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def allgather_owned(self, local_vals, bs, nv_global):
+        """Assemble the global nodal array from the owned slices of every rank."""
+        part = self.part
+        out = np.zeros(nv_global * bs)
+        mine = np.asarray(local_vals).reshape(-1, bs)[: part.nvo]
+        if self.size == 1:
+            out.reshape(-1, bs)[part.owned_global] = mine
+            return out
+        import torch.distributed as dist
+        objs = [None] * self.size
+        dist.all_gather_object(objs, (part.owned_global, mine))
+        for g, v in objs:
+            out.reshape(-1, bs)[g] = v
+        return out
+
+    def host_exchange(self, s, r, width=3):
+        """Forward halo over torch.distributed: `s` holds `width` doubles per send vertex in
+        send_idx order, `r` receives `width` doubles per ghost in ghost order."""
+        import torch.distributed as dist
+        part = self.part
+        reqs = []
+        for k, q in enumerate(part.nbr):
+            a, b = width * int(part.recv_ptr[k]), width * int(part.recv_ptr[k + 1])
+            if b > a:
+                reqs.append(dist.irecv(r[a:b], src=int(q)))
+        for k, q in enumerate(part.nbr):
+            a, b = width * int(part.send_ptr[k]), width * int(part.send_ptr[k + 1])
+            if b > a:
+                reqs.append(dist.isend(s[a:b].clone(), dst=int(q)))
+        for rq in reqs:
+            rq.wait()
+
+    # -- wiring a libcfdh context -------------------------------------------------
+    def attach(self, ctx):
+        part = self.part
+        if self.size == 1:
+            return
+        ctx.set_halo(part.nbr, part.send_ptr, part.send_idx, part.recv_ptr, part.recv_idx)
+        if self.backend == "rccl":
+            import torch
+            import torch.distributed as dist
+            from . import _lib
+            uid = _lib.rccl_unique_id() if self.rank == 0 else bytes(128)
+            t = torch.tensor(list(uid), dtype=torch.uint8)
+            dist.broadcast(t, src=0)
+            ctx.comm_init_rccl(bytes(t.tolist()), self.rank, self.size)
+        else:
+            self._attach_host(ctx)
+
+    def _attach_host(self, ctx):
+        import torch
+        import torch.distributed as dist
+        part = self.part
+        nsend, nrecv = int(part.send_ptr[-1]), int(part.recv_ptr[-1])
+
+        def allreduce(user, buf, n, op):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(n,))
+                t = torch.from_numpy(a)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("allreduce callback failed:", e)
+                return 1
+
+        def exchange(user, sendbuf, recvbuf):
+            try:
+                s = torch.from_numpy(np.ctypeslib.as_array(sendbuf, shape=(max(3 * nsend, 1),)))
+                r = torch.from_numpy(np.ctypeslib.as_array(recvbuf, shape=(max(3 * nrecv, 1),)))
+                self.host_exchange(s, r)
+                return 0
+            except Exception as e:
+                print("exchange callback failed:", e)
+                return 1
+
+        ctx.comm_set_callbacks(allreduce, exchange, self.rank, self.size)

@@ -1,0 +1,217 @@
+"""`Scenario` ABC + the time loop that calls the hot path, with the reference's
+semantics (/root/reference/src/scenario.py:20-360): solver loaded by name,
+kwargs filtered by the constructor signature, `setup()`, `solve()` with the
+float-accumulated `while t < T`, the every-10th-step early stop evaluated before
+the prev-copy, final L2 norms written to norms.txt.
+
+Differences, all outside the hot path: no ADIOS2/VTX output (results are kept in
+memory and, optionally, written as .npz snapshots), no tqdm bar.  When the
+solver offers `advance()`/`functional()` the loop keeps the fields in HBM
+(`device_resident=True`, default) instead of copying `*.x.array` through the
+host every step; `device_resident=False` runs the reference's literal loop.
+"""
+from __future__ import annotations
+
+import inspect
+import os
+import time
+from abc import ABC, abstractmethod
+from importlib import import_module
+from typing import Callable
+
+import numpy as np
+
+from .boundaryCondition import BoundaryCondition
+from .fem import Function
+from .solverBase import SolverBase
+
+
+class Scenario(ABC):
+    @property
+    @abstractmethod
+    def mesh(self):
+        pass
+
+    @property
+    @abstractmethod
+    def bcu(self) -> list[BoundaryCondition]:
+        pass
+
+    @property
+    @abstractmethod
+    def bcp(self) -> list[BoundaryCondition]:
+        pass
+
+    @abstractmethod
+    def initial_velocity(self, x: np.ndarray) -> np.ndarray:
+        pass
+
+    def exact_velocity(self, t):
+        pass
+
+    def __init__(self, solver_name: str, scenario_name: str, rho: float, mu: float, dt: float, T: float, f: list,
+                 early_stop_tolerance: float = 1e-3, **solver_kwargs):
+        self.solver_name = solver_name
+        self.scenario_name = scenario_name
+        self.early_stop_tolerance = early_stop_tolerance
+        try:
+            solver_module = import_module(f"{__package__}.solvers.{solver_name}")
+        except ImportError as e:
+            raise ImportError(
+                f"Could not import solver '{solver_name}'. Ensure {__package__}/solvers/{solver_name}.py exists "
+                f"and all its dependencies are available.\nUnderlying error: {e}\n"
+                f"Available solvers: {self._list_available_solvers()}") from e
+        if not hasattr(solver_module, "Solver"):
+            raise ValueError(f"Solver module 'solvers/{solver_name}.py' does not define a 'Solver' class.")
+        self.solverClass: type[SolverBase] = solver_module.Solver
+        sig = inspect.signature(self.solverClass.__init__)
+        accepted = sig.parameters
+        has_var_keyword = any(p.kind == inspect.Parameter.VAR_KEYWORD for p in accepted.values())
+        filtered = solver_kwargs if has_var_keyword else {k: v for k, v in solver_kwargs.items() if k in accepted}
+        try:
+            self.solver = self.solverClass(self.mesh, dt, rho, mu, f, initial_velocity=self.initial_velocity, **filtered)
+        except TypeError as e:
+            raise RuntimeError(f"Failed to instantiate solver '{solver_name}': {e}. "
+                               f"Check that the Solver class has the correct constructor signature.") from e
+        except Exception as e:
+            raise RuntimeError(f"Error while initializing solver '{solver_name}': {type(e).__name__}: {e}") from e
+        self.T = T
+        self.has_exact_solution = self.__class__.exact_velocity is not Scenario.exact_velocity
+        self.dt = dt
+        self.step_stats = []
+
+    @staticmethod
+    def _list_available_solvers():
+        d = os.path.join(os.path.dirname(__file__), "solvers")
+        try:
+            s = [f[:-3] for f in os.listdir(d) if f.endswith(".py") and not f.startswith("_")]
+            return s if s else ["(none found)"]
+        except OSError:
+            return ["(could not list)"]
+
+    @property
+    def facet_tags(self):
+        return getattr(self, "_ft", None)
+
+    @property
+    def tags(self) -> dict:
+        return {
+            "inlet": getattr(self, "inlet_marker", None),
+            "outlet": getattr(self, "outlet_marker", None),
+            "wall": getattr(self, "wall_marker", None),
+            "obstacle": getattr(self, "obstacle_marker", None),
+        }
+
+    def setup(self):
+        self.solver.setup(self.bcu, self.bcp, facet_tags=self.facet_tags, tags=self.tags)
+        if self.mesh.comm.rank == 0 and not getattr(self, "quiet", False):
+            nV = self.solver.V.dofmap.index_map.size_global * self.solver.V.dofmap.index_map_bs
+            nQ = self.solver.Q.dofmap.index_map.size_global * self.solver.Q.dofmap.index_map_bs
+            print(f"DOFs: {nV + nQ} (Velocity: {nV}, Pressure: {nQ})")
+            print(f"Suggested cores: {(nV + nQ) / 20000:.1f}")
+
+    def solve(self, output_folder: str = None, afterStepCallback: Callable[[float], None] = None,
+              device_resident: bool = True, max_steps: int = None) -> str:
+        mesh, T, solver = self.mesh, self.T, self.solver
+        quiet = getattr(self, "quiet", False)
+        if output_folder and mesh.comm.rank == 0:
+            os.makedirs(output_folder, exist_ok=True)
+        mesh.comm.barrier()
+        solver.initStressForm()
+        t = 0.0
+        solver.u_sol.interpolate(self.initial_velocity)
+        error_log = None
+        if self.has_exact_solution:
+            error_log = open(f"{output_folder}/err.txt", "w") if (output_folder and mesh.comm.rank == 0) else None
+            u_e = Function(solver.V)
+            u_e.interpolate(lambda x: self.exact_velocity(t)(x))
+            error = self.compute_error(solver.u_sol, u_e, mesh)
+            if error_log:
+                error_log.write("t = %.3f: error = %.3g" % (t, error) + "\n")
+        fast = device_resident and hasattr(solver, "advance") and hasattr(solver, "functional")
+        i = 0
+        self.step_stats = []
+        self.stopped_early = False
+        while t < T:
+            t0 = time.perf_counter()
+            solver.solveStep()
+            st = getattr(solver, "last_stats", None)
+            self.step_stats.append((time.perf_counter() - t0, st))
+            i += 1
+            t += self.dt
+            if self.has_exact_solution:
+                u_e.interpolate(self.exact_velocity(t))
+                error = self.compute_error(u_e, solver.u_sol, mesh)
+                if error_log:
+                    error_log.write("t = %.3f: error = %.3g" % (t, error) + "\n")
+            if not fast:
+                solver.assemble_wss()
+            if afterStepCallback:
+                afterStepCallback(t)
+            if (i + 1) % 10 == 0:
+                if fast:
+                    u_sol_norm = solver.functional(4)
+                    u_prev_norm = solver.functional(5)
+                    u_diff_norm = solver.functional(6)
+                else:
+                    u_sol_arr = solver.u_sol.x.array
+                    u_prev_arr = solver.u_prev.x.array
+                    u_sol_norm = mesh.comm.allreduce(np.linalg.norm(u_sol_arr, ord=np.inf))
+                    u_prev_norm = mesh.comm.allreduce(np.linalg.norm(u_prev_arr, ord=np.inf))
+                    u_diff_norm = mesh.comm.allreduce(np.linalg.norm(u_sol_arr - u_prev_arr, ord=np.inf))
+                rel_diff = (u_diff_norm / max(u_sol_norm, 1e-12)) / self.dt
+                if mesh.comm.rank == 0 and not quiet:
+                    print(f"Step {i+1}: t={t:.3f} ||u_sol||={u_sol_norm:.6e}, ||u_prev||={u_prev_norm:.6e}, "
+                          f"||diff||={u_diff_norm:.6e} rel_diff/dt={rel_diff:.6e}")
+                if rel_diff < self.early_stop_tolerance:
+                    if mesh.comm.rank == 0 and not quiet:
+                        print(f"Early stopping at t={t:.3f}, because (||u_sol - u_prev||_inf / ||u_sol||_inf) / dt = "
+                              f"{rel_diff:.20e} < {self.early_stop_tolerance}")
+                    self.stopped_early = True
+                    break
+            if fast:
+                solver.advance()
+            else:
+                solver.u_prev.x.array[:] = solver.u_sol.x.array[:]
+                solver.p_prev.x.array[:] = solver.p_sol.x.array[:]
+            if max_steps is not None and i >= max_steps:
+                break
+        self.num_steps = i
+        self.t_end = t
+        if fast:
+            norm_v, norm_p = solver.functional(2), solver.functional(3)
+        else:
+            norm_v, norm_p = self._l2_norms_host()
+        self.norm_v, self.norm_p = norm_v, norm_p
+        solver.assemble_wss()
+        if output_folder and mesh.comm.rank == 0:
+            with open(os.path.join(output_folder, "norms.txt"), "w") as f:
+                f.write(f"L2 norm of velocity: {norm_v}\n")
+                f.write(f"L2 norm of pressure: {norm_p}\n")
+            np.savez(os.path.join(output_folder, "final.npz"), x=mesh.x, cells=mesh.cells,
+                     velocity=solver.u_sol.x.array, pressure=solver.p_sol.x.array,
+                     wss=solver.shear_stress.x.array)
+        if error_log:
+            error_log.close()
+        return output_folder
+
+    def _l2_norms_host(self):
+        m = self.mesh
+        area = m.cell_areas()
+        mab = area[:, None, None] * (1.0 + np.eye(3))[None] / 12.0
+        ue = self.solver.u_sol.x.array.reshape(-1, 2)[m.cells]
+        pe = self.solver.p_sol.x.array[m.cells]
+        return (float(np.sqrt(np.einsum("cab,cai,cbi->", mab, ue, ue))),
+                float(np.sqrt(np.einsum("cab,ca,cb->", mab, pe, pe))))
+
+    @staticmethod
+    def compute_error(u: Function, u_aprox: Function, mesh) -> float:
+        """Relative L2 error (/root/reference/src/scenario.py:350-360)."""
+        area = mesh.cell_areas()
+        mab = area[:, None, None] * (1.0 + np.eye(3))[None] / 12.0
+        bs = u.function_space.bs
+        a = u.x.array.reshape(-1, bs)[mesh.cells]
+        b = u_aprox.x.array.reshape(-1, bs)[mesh.cells]
+        d = b - a
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return float(np.sqrt(np.einsum("cab,cai,cbi->", mab, d, d)) / np.sqrt(np.einsum("cab,cai,cbi->", mab, a, a)))

@@ -1,0 +1,67 @@
+"""2-D stenosed channel with the boundary data of
+/root/reference/src/scenarios/stenosis.py:124-156 (walls no-slip, parabolic
+inlet `v_max (1 - ((y-R_in)/R_in)^2)` only when `v_max` is given, no pressure
+condition) on the structured y-profile mesh of `mesh.create_stenosis_channel`.
+Units mm, g, s: rho = 1.06e-3 g/mm^3, mu = 3.5e-3 (stenosis.py:27-31)."""
+from __future__ import annotations
+
+import numpy as np
+
+from ..boundaryCondition import BoundaryCondition
+from ..fem import Function
+from ..mesh import create_stenosis_channel
+from ..scenario import Scenario
+
+
+class StenosisSimulation(Scenario):
+    inlet_marker = 1
+    outlet_marker = 2
+    wall_marker = 3
+
+    def __init__(self, solver_name, dt, T, f: tuple[float, float] = (0, 0), *, rho=1.06e-3, mu=3.5e-3, ny=32,
+                 L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, severity=0.5, v_max=None, **solver_kwargs):
+        self._mesh = None
+        self._ft = None
+        self._bcu = None
+        self._bcp = None
+        self.ny, self.L, self.R_in, self.R_out = int(ny), L, R_in, R_out
+        self.x_sten, self.severity, self.v_max = x_sten, severity, v_max
+        self.quiet = bool(solver_kwargs.get("quiet", False))
+        super().__init__(solver_name, "stenosis", rho, mu, dt, T, f, **solver_kwargs)
+        self.setup()
+
+    @property
+    def mesh(self):
+        if not self._mesh:
+            self._mesh, self._ft = create_stenosis_channel(self.ny, self.L, self.R_in, self.R_out, self.x_sten, self.severity)
+        return self._mesh
+
+    def inlet_profile(self, x):
+        v = np.zeros((2, x.shape[1]))
+        v[0] = self.v_max * (1.0 - ((x[1] - self.R_in) / self.R_in) ** 2)
+        return v
+
+    @property
+    def bcu(self):
+        if not self._bcu:
+            fdim = 1
+            u0 = Function(self.solver.V)
+            bc_w = BoundaryCondition(u0)
+            bc_w.initTopological(fdim, self._ft.find(self.wall_marker))
+            self._bcu = [bc_w]
+            if self.v_max is not None:
+                ui = Function(self.solver.V)
+                ui.interpolate(self.inlet_profile)
+                bc_i = BoundaryCondition(ui)
+                bc_i.initTopological(fdim, self._ft.find(self.inlet_marker))
+                self._bcu = [bc_i, bc_w]
+        return self._bcu
+
+    @property
+    def bcp(self):
+        if not self._bcp:
+            self._bcp = []
+        return self._bcp
+
+    def initial_velocity(self, x):
+        return np.zeros((2, x.shape[1]))

@@ -1,0 +1,128 @@
+"""`SolverBase` with the reference's plugin surface
+(/root/reference/src/solverBase.py:25-195): Constants dt/rho/mu/f, spaces V/Q,
+state Functions u_sol/p_sol/u_prev/p_prev/u_residual/p_residual, the stress
+helpers and `assemble_wss`."""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Callable
+
+import numpy as np
+
+from .boundaryCondition import BoundaryCondition
+from .fem import Constant, Function, FunctionSpace
+
+
+class SolverBase(ABC):
+    @abstractmethod
+    def __init__(self, mesh, dt: float, rho: float, mu: float, f: list,
+                 initial_velocity: Callable[[np.ndarray], np.ndarray] = None):
+        self.mesh = mesh
+        self.dt = Constant(mesh, dt)
+        self.rho = Constant(mesh, rho)
+        self.mu = Constant(mesh, mu)
+        self.f = Constant(mesh, f)
+        self._u_sol = self._p_sol = self._u_prev = self._p_prev = None
+        self._V = self._Q = None
+
+    @property
+    def u_sol(self):
+        assert self._u_sol is not None, "Velocity solution function is not initialized. call initVelocitySpace() first."
+        return self._u_sol
+
+    @property
+    def p_sol(self):
+        assert self._p_sol is not None, "Pressure solution function is not initialized. call initPressureSpace() first."
+        return self._p_sol
+
+    @property
+    def u_prev(self):
+        assert self._u_prev is not None, "Velocity solution function is not initialized. call initVelocitySpace() first."
+        return self._u_prev
+
+    @property
+    def p_prev(self):
+        assert self._p_prev is not None, "Pressure solution function is not initialized. call initPressureSpace() first."
+        return self._p_prev
+
+    @property
+    def V(self):
+        assert self._V is not None, "Velocity function space is not initialized. call initVelocitySpace() first."
+        return self._V
+
+    @property
+    def Q(self):
+        assert self._Q is not None, "Pressure function space is not initialized. call initPressureSpace() first."
+        return self._Q
+
+    @abstractmethod
+    def setup(self, bcu: list[BoundaryCondition], bcp: list[BoundaryCondition]) -> None:
+        pass
+
+    @abstractmethod
+    def solveStep(self) -> None:
+        pass
+
+    def initVelocitySpace(self, family, cell, deegre, shape=None) -> None:
+        if int(deegre) != 1:
+            raise ValueError("only P1 velocity is implemented")
+        self._V = FunctionSpace(self.mesh, self.mesh.geometry.dim if shape is None else int(shape[0]))
+        self._u_sol = Function(self.V, name="velocity")
+        self._u_prev = Function(self.V)
+        self.u_residual = Function(self.V, name="u_residual")
+
+    def initPressureSpace(self, family, cell, deegre, shape=None) -> None:
+        if int(deegre) != 1:
+            raise ValueError("only P1 pressure is implemented")
+        self._Q = FunctionSpace(self.mesh, 1)
+        self._p_sol = Function(self.Q, name="pressure")
+        self._p_prev = Function(self.Q)
+        self.p_residual = Function(self.Q, name="p_residual")
+
+    def initStressForm(self):
+        """Allocates the stress fields the Scenario writes
+        (/root/reference/src/solverBase.py:144-173)."""
+        self.normal_stress = Function(FunctionSpace(self.mesh, 1), name="normal_stress")
+        self.shear_stress = Function(FunctionSpace(self.mesh, self.mesh.geometry.dim), name="shear_stress")
+
+    def assemble_wss(self):
+        """Wall shear stress  (1/|e|) oint w . (T - (T.n) n),  T = -sigma(u,p) n
+        (/root/reference/src/solverBase.py:163-195), assembled on the host from
+        the current solution.  Post-processing, outside the timed hot path."""
+        if not hasattr(self, "shear_stress"):
+            return
+        mesh = self.mesh
+        u = self.u_sol.x.array.reshape(-1, 2)
+        mu = float(self.mu.value)
+        fc, fl, fv = mesh.facet_cells, mesh.facet_local, mesh.facet_vertices
+        cells = mesh.cells[fc]
+        X = mesh.x[cells]
+        det = (X[:, 1, 0] - X[:, 0, 0]) * (X[:, 2, 1] - X[:, 0, 1]) - (X[:, 1, 1] - X[:, 0, 1]) * (X[:, 2, 0] - X[:, 0, 0])
+        g = np.empty((len(fc), 3, 2))
+        g[:, 0, 0] = (X[:, 1, 1] - X[:, 2, 1]) / det
+        g[:, 0, 1] = (X[:, 2, 0] - X[:, 1, 0]) / det
+        g[:, 1, 0] = (X[:, 2, 1] - X[:, 0, 1]) / det
+        g[:, 1, 1] = (X[:, 0, 0] - X[:, 2, 0]) / det
+        g[:, 2, 0] = (X[:, 0, 1] - X[:, 1, 1]) / det
+        g[:, 2, 1] = (X[:, 1, 0] - X[:, 0, 0]) / det
+        idx = np.arange(len(fc))
+        gf = g[idx, fl]
+        n = -gf / np.linalg.norm(gf, axis=1)[:, None]
+        G = np.einsum("cai,caj->cij", g, u[cells])  # d_i u_j
+        E = 0.5 * (G + np.transpose(G, (0, 2, 1)))
+        # tangential part of T = -(2 mu E - p I) n : the pressure part is purely normal
+        T = -2.0 * mu * np.einsum("cij,cj->ci", E, n)
+        Tt = T - np.einsum("ci,ci->c", T, n)[:, None] * n
+        out = self.shear_stress.x.array.reshape(-1, 2)
+        out[:] = 0.0
+        # (1/|e|) oint lambda_a Tt = Tt / 2 per facet vertex
+        np.add.at(out, fv[:, 0], 0.5 * Tt)
+        np.add.at(out, fv[:, 1], 0.5 * Tt)
+
+    @staticmethod
+    def epsilon(u):
+        raise NotImplementedError("symbolic forms are not part of the GPU path; see csrc/cfdh_kernels.hip")
+
+    @staticmethod
+    def sigma(u, p, mu):
+        raise NotImplementedError("symbolic forms are not part of the GPU path; see csrc/cfdh_kernels.hip")

@@ -1,0 +1,177 @@
+"""Drop-in `Solver` for the reference's `--solver stabilized_schur`
+(/root/reference/src/solvers/stabilized_schur.py:40-334): SUPG/PSPG/LSIC
+stabilised P1/P1 Navier-Stokes, Newton linearisation, Schur-complement
+preconditioned FGMRES -- executed by hand-written gfx950 kernels in
+libcfdh.so (include/cfdh.h) instead of FEniCSx/PETSc.
+
+Same constructor, `setup(bcu, bcp, facet_tags=None, tags=None)`, `solveStep()`,
+state Functions and error behaviour (RuntimeError "Did not converge, reason: r.").
+Fields live in HBM between steps; the host arrays behind `*.x.array` are
+synchronised lazily (download on read, upload when the caller may have
+written).  Extra, optional keyword arguments tune the solver:
+`newton_rtol`, `krylov_rtol`, `device`, `verbose`, `quiet`, `options` (dict of
+cfdh_options fields) and `comm` (a parallel.PartComm: the mesh is then
+partitioned by elements over the ranks, one GPU each, as DOLFINx partitions it
+over MPI ranks in the reference).
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import numpy as np
+
+from .. import _lib
+from ..boundaryCondition import BoundaryCondition
+from ..solverBase import SolverBase
+
+
+class Solver(SolverBase):
+    MAX_ITER = 20
+
+    def __init__(self, mesh, dt: float, rho: float, mu: float, f: list,
+                 initial_velocity: Callable[[np.ndarray], np.ndarray] = None, **kwargs):
+        super().__init__(mesh, dt, rho, mu, f)
+        super().initVelocitySpace("Lagrange", mesh.topology.cell_name(), 1, shape=(mesh.geometry.dim,))
+        super().initPressureSpace("Lagrange", mesh.topology.cell_name(), 1)
+        if initial_velocity:
+            self.u_prev.interpolate(initial_velocity)
+        self._mu_float = float(mu)  # raw python float of the ds term (stabilized_schur.py:79)
+        self._verbose = int(kwargs.get("verbose", 0))
+        self._quiet = bool(kwargs.get("quiet", False))
+        self._comm = kwargs.get("comm", None)
+        device = int(kwargs.get("device", 0))
+        self._part = None
+        if self._comm is not None and self._comm.size > 1:
+            part = self._comm.make_part(mesh)
+            self._part = part
+            self.ctx = _lib.Context(part.x, part.cells, part.facet_cells, part.facet_local, part.facet_marker,
+                                    nv_owned=part.nvo, device=device)
+            self._comm.attach(self.ctx)
+        else:
+            self.ctx = _lib.Context(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, mesh.facet_marker,
+                                    device=device)
+        ff = np.atleast_1d(np.asarray(f, dtype=np.float64))
+        self.ctx.set_params(float(dt), float(rho), float(mu), mu_facet=self._mu_float, f=ff)
+        self.options = self.ctx.default_options()
+        if "newton_rtol" in kwargs:
+            self.options.snes_rtol = float(kwargs["newton_rtol"])
+        if "krylov_rtol" in kwargs:
+            self.options.ksp_rtol = float(kwargs["krylov_rtol"])
+        for k, v in dict(kwargs.get("options", {})).items():
+            setattr(self.options, k, v)
+        self.options.verbose = self._verbose
+        self.ctx.set_options(self.options)
+        self.last_stats = None
+        self._bcs = []
+        self._bc_cache = None
+        # lazy host/device synchronisation of the state Functions
+        self._dev_newer = {"sol": False, "res": False}
+        self._prev_host_dirty = True
+        self._prev_dev_newer = False
+        self._u_sol.x._pre_access = self._sync_solution
+        self._p_sol.x._pre_access = self._sync_solution
+        self.u_residual.x._pre_access = self._sync_residual
+        self.p_residual.x._pre_access = self._sync_residual
+        self._u_prev.x._pre_access = self._sync_previous
+        self._p_prev.x._pre_access = self._sync_previous
+        self._u_prev.x._post_access = self._mark_prev_dirty
+        self._p_prev.x._post_access = self._mark_prev_dirty
+
+    # -- global <-> local (identity on one GPU) ------------------------------------
+    def _loc_u(self, a):
+        return a if self._part is None else np.ascontiguousarray(a.reshape(-1, 2)[self._part.l2g]).reshape(-1)
+
+    def _loc_p(self, a):
+        return a if self._part is None else np.ascontiguousarray(a[self._part.l2g])
+
+    def _store(self, dst_u, dst_p, lu, lp):
+        if self._part is None:
+            dst_u[:] = lu
+            dst_p[:] = lp
+        else:
+            nvg = self.mesh.num_vertices
+            dst_u[:] = self._comm.allgather_owned(lu, 2, nvg)
+            dst_p[:] = self._comm.allgather_owned(lp, 1, nvg)
+
+    # -- lazy sync -----------------------------------------------------------
+    def _sync_solution(self):
+        if self._dev_newer["sol"]:
+            self._dev_newer["sol"] = False
+            lu, lp = self.ctx.get_solution()
+            self._store(self._u_sol.x._array, self._p_sol.x._array, lu, lp)
+
+    def _sync_residual(self):
+        if self._dev_newer["res"]:
+            self._dev_newer["res"] = False
+            ru, rp = self.ctx.get_residual()
+            self._store(self.u_residual.x._array, self.p_residual.x._array, ru, rp)
+
+    def _sync_previous(self):
+        if self._prev_dev_newer:
+            self._prev_dev_newer = False
+            lu, lp = self.ctx.get_previous()
+            self._store(self._u_prev.x._array, self._p_prev.x._array, lu, lp)
+
+    def _mark_prev_dirty(self):
+        self._prev_host_dirty = True
+
+    # -- reference API ---------------------------------------------------------
+    def setup(self, bcu: list[BoundaryCondition], bcp: list[BoundaryCondition], facet_tags=None, tags=None) -> None:
+        self.bcu_d = [bc.getBC(self.V) for bc in bcu]
+        self.bcp_d = [bc.getBC(self.Q) for bc in bcp]
+        self._bcs = [(0, bc) for bc in self.bcu_d] + [(1, bc) for bc in self.bcp_d]
+        self._bc_cache = None
+        self._upload_bcs()
+        # x_n = (u_prev, p_prev): initial guess of the first step (stabilized_schur.py:216-223)
+        self._sync_previous()
+        up, pp = self._loc_u(self._u_prev.x._array), self._loc_p(self._p_prev.x._array)
+        self.ctx.set_state(u_prev=up, p_prev=pp, u=up, p=pp)
+        self._prev_host_dirty = False
+
+    def _bc_nodes_values(self, field, bc):
+        g = bc.g.x._array
+        nodes = bc.dofs
+        vals = g.reshape(-1, 2)[nodes] if field == 0 else g[nodes]
+        if self._part is not None:
+            loc = self._part.g2l[nodes]
+            keep = loc >= 0
+            nodes, vals = loc[keep].astype(np.int32), vals[keep]
+        return nodes, np.array(vals, copy=True)
+
+    def _upload_bcs(self):
+        items = [self._bc_nodes_values(fld, bc) for fld, bc in self._bcs]
+        vals = [v for _, v in items]
+        if self._bc_cache is not None and len(vals) == len(self._bc_cache) and all(
+                np.array_equal(a, b) for a, b in zip(vals, self._bc_cache)):
+            return
+        self.ctx.clear_dirichlet()
+        for (fld, _), (nodes, v) in zip(self._bcs, items):
+            self.ctx.add_dirichlet(fld, nodes, v)
+        self._bc_cache = vals
+
+    def solveStep(self):
+        for _, bc in self._bcs:
+            bc.update()  # stabilized_schur.py:170
+        self._upload_bcs()
+        if self._prev_host_dirty and not self._prev_dev_newer:
+            self.ctx.set_state(u_prev=self._loc_u(self._u_prev.x._array), p_prev=self._loc_p(self._p_prev.x._array))
+        self._prev_host_dirty = False
+        st = self.ctx.solve_step()  # raises RuntimeError("Did not converge, reason: r.") like :332-334
+        self.last_stats = st
+        self._dev_newer["sol"] = True
+        self._dev_newer["res"] = True
+        if not self._quiet and self.mesh.comm.rank == 0:
+            print(f"Solver converged in {st.newton_its} nonlinear iterations"
+                  f" (with total number of {st.krylov_its} linear iterations)")
+
+    # -- device-resident extras ---------------------------------------------------
+    def advance(self):
+        """u_prev <- u_sol, p_prev <- p_sol without leaving HBM (the copy of
+        /root/reference/src/scenario.py:306-307)."""
+        self.ctx.advance()
+        self._prev_dev_newer = True
+        self._prev_host_dirty = False
+
+    def functional(self, kind, marker=0):
+        """Global value (the library reduces over the ranks)."""
+        return self.ctx.functional(kind, marker)

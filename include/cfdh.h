@@ -129,6 +129,8 @@ int cfdh_add_dirichlet(cfdh_ctx *ctx, int field, int64_t n, const int32_t *nodes
 int cfdh_set_state(cfdh_ctx *ctx, const double *u_prev, const double *p_prev, const double *u, const double *p);
 /* u_sol/p_sol after the step = the Newton iterate (updateSolution, :125-142) */
 int cfdh_get_solution(cfdh_ctx *ctx, double *u, double *p);
+/* u_prev/p_prev as held on the device (after cfdh_advance they equal the last solution) */
+int cfdh_get_previous(cfdh_ctx *ctx, double *u_prev, double *p_prev);
 /* u_residual/p_residual (_updateResidual, :295-311) */
 int cfdh_get_residual(cfdh_ctx *ctx, double *ru, double *rp);
 /* device-side u_prev <- u_sol, p_prev <- p_sol (scenario.py:306-307) */

@@ -77,6 +77,13 @@ typedef struct orc_ctx {
   /* solver workspace (lazily allocated) */
   csr_t A00f, Sp;         /* ILU factors */
   int *sp_rowptr, *sp_col;
+  /* pc_kind 1 */
+  struct amg_level *amg;
+  int amg_nlev, amg_valid, amg_its_ref, amg_force;
+  double *amg_cinv;
+  int amg_cn;
+  double *dinvA, lmaxA;
+  int singular;
   int nthreads;
   char err[256];
 } orc_ctx;
@@ -90,6 +97,17 @@ typedef struct {
   int sub_max_it, sub_restart;
   int remove_p_mean; /* nullsp.remove(x_n), stabilized_schur.py:319 */
   int verbose;
+  /* pc_kind 0: the reference's sub-solvers (GMRES(30)+ILU(0) on A00, ILU(0) on Sp);
+   * pc_kind 1: CPU port of the sub-solvers the GPU path uses inside the same Schur
+   * factorisation (Jacobi-Chebyshev on A00, one smoothed-aggregation V-cycle on the
+   * lagged Sp) -- used where ILU(0) stops converging (>~50k vertices) and as the
+   * like-for-like CPU baseline of bench.py */
+  int pc_kind;
+  int cheb_degree;
+  double cheb_ratio;
+  int amg_smooth_degree;
+  double amg_smooth_ratio, amg_theta;
+  int amg_max_coarse;
 } orc_opts;
 
 typedef struct {
@@ -367,6 +385,7 @@ orc_ctx *orc_create(int nv, int nc, const int *cells, const double *x, int nf, c
   return c;
 }
 
+static void amg_free(struct orc_ctx *c);
 static void free_csr(csr_t *m) { free(m->rowptr); free(m->col); free(m->val); free(m->diag); memset(m, 0, sizeof *m); }
 
 void orc_destroy(orc_ctx *c) {
@@ -375,6 +394,7 @@ void orc_destroy(orc_ctx *c) {
   free(c->bcmult); free(c->un); free(c->Mom); free(c->Fe); free(c->Je); free(c->vcptr); free(c->vcell);
   free(c->vptr); free(c->vadj); free(c->rowptr); free(c->col); free(c->val); free(c->cellpos);
   free_csr(&c->A00f); free_csr(&c->Sp); free(c->sp_rowptr); free(c->sp_col);
+  amg_free(c); free(c->dinvA);
   free(c);
 }
 
@@ -599,8 +619,259 @@ static void ilu_solve(const csr_t *m, const double *b, double *x) {
   }
 }
 
+
+/* ------------------------------------------------------------------ pc_kind 1: Chebyshev + SA-AMG (CPU port) */
+
+typedef struct amg_level {
+  csr_t A, P, R;
+  double *dinv, *x, *b, *r, *d0, *d1;
+  double lmax, lmin;
+  int n;
+} amg_level;
+
+static void csr_alloc(csr_t *m, int n, int nnz) {
+  m->n = n; m->rowptr = (int *)calloc(n + 1, sizeof(int)); m->col = (int *)malloc(sizeof(int) * (nnz > 0 ? nnz : 1));
+  m->val = (double *)malloc(sizeof(double) * (nnz > 0 ? nnz : 1)); m->diag = NULL;
+}
+static void csr_mult(const csr_t *A, const double *x, double *y, int mode, const double *b) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < A->n; i++) {
+    double s = 0;
+    for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) s += A->val[k] * x[A->col[k]];
+    if (mode == 0) y[i] = s; else if (mode == 1) y[i] = b[i] - s; else y[i] += s;
+  }
+}
+/* C = A * B, B has mB columns; sorted columns */
+static void csr_spgemm(const csr_t *A, const csr_t *B, int mB, csr_t *C) {
+  int n = A->n, cap = A->rowptr[n] * 4 + 16, nn = 0;
+  C->n = n; C->rowptr = (int *)calloc(n + 1, sizeof(int)); C->col = (int *)malloc(sizeof(int) * cap);
+  C->val = (double *)malloc(sizeof(double) * cap); C->diag = NULL;
+  int *mark = (int *)malloc(sizeof(int) * mB);
+  double *acc = (double *)malloc(sizeof(double) * mB);
+  for (int i = 0; i < mB; i++) mark[i] = -1;
+  for (int i = 0; i < n; i++) {
+    int start = nn;
+    for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) {
+      int j = A->col[k];
+      double a = A->val[k];
+      for (int k2 = B->rowptr[j]; k2 < B->rowptr[j + 1]; k2++) {
+        int cc = B->col[k2];
+        if (mark[cc] != i) {
+          mark[cc] = i; acc[cc] = 0.0;
+          if (nn == cap) { cap *= 2; C->col = (int *)realloc(C->col, sizeof(int) * cap); C->val = (double *)realloc(C->val, sizeof(double) * cap); }
+          C->col[nn++] = cc;
+        }
+        acc[cc] += a * B->val[k2];
+      }
+    }
+    qsort(C->col + start, nn - start, sizeof(int), cmp_int);
+    for (int k = start; k < nn; k++) C->val[k] = acc[C->col[k]];
+    C->rowptr[i + 1] = nn;
+  }
+  free(mark); free(acc);
+}
+static void csr_transpose(const csr_t *A, int m, csr_t *T) {
+  int nnz = A->rowptr[A->n];
+  csr_alloc(T, m, nnz);
+  for (int k = 0; k < nnz; k++) T->rowptr[A->col[k] + 1]++;
+  for (int i = 0; i < m; i++) T->rowptr[i + 1] += T->rowptr[i];
+  int *fill = (int *)malloc(sizeof(int) * (m + 1));
+  memcpy(fill, T->rowptr, sizeof(int) * (m + 1));
+  for (int i = 0; i < A->n; i++)
+    for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) { int p = fill[A->col[k]]++; T->col[p] = i; T->val[p] = A->val[k]; }
+  free(fill);
+}
+static double power_lmax(const csr_t *A, const double *dinv, int its) {
+  int n = A->n;
+  double *v = (double *)malloc(sizeof(double) * n), *w = (double *)malloc(sizeof(double) * n);
+  unsigned long long st = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < n; i++) { st = st * 6364136223846793005ull + 1442695040888963407ull; v[i] = ((double)(st >> 11) * (1.0 / 9007199254740992.0)) - 0.5; }
+  double l = 1;
+  for (int it = 0; it < its; it++) {
+    csr_mult(A, v, w, 0, NULL);
+    double nn = 0;
+    for (int i = 0; i < n; i++) { w[i] *= dinv[i]; nn += w[i] * w[i]; }
+    l = sqrt(nn);
+    if (!(l > 0)) { l = 1; break; }
+    for (int i = 0; i < n; i++) v[i] = w[i] / l;
+  }
+  free(v); free(w);
+  return l;
+}
+static int amg_aggregate(const csr_t *A, double theta, int *agg) {
+  int n = A->n;
+  double *d = (double *)calloc(n, sizeof(double));
+  for (int i = 0; i < n; i++)
+    for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) if (A->col[k] == i) d[i] = fabs(A->val[k]);
+  int *sptr = (int *)calloc(n + 1, sizeof(int)), *scol = (int *)malloc(sizeof(int) * (A->rowptr[n] + 1));
+  int ns = 0;
+  for (int i = 0; i < n; i++) {
+    for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) {
+      int j = A->col[k];
+      if (j != i && fabs(A->val[k]) >= theta * sqrt(d[i] * d[j])) scol[ns++] = j;
+    }
+    sptr[i + 1] = ns;
+  }
+  for (int i = 0; i < n; i++) agg[i] = -1;
+  int na = 0;
+  for (int i = 0; i < n; i++) {
+    if (agg[i] >= 0) continue;
+    int ok = sptr[i + 1] > sptr[i];
+    for (int k = sptr[i]; k < sptr[i + 1] && ok; k++) if (agg[scol[k]] >= 0) ok = 0;
+    if (!ok) continue;
+    agg[i] = na;
+    for (int k = sptr[i]; k < sptr[i + 1]; k++) agg[scol[k]] = na;
+    na++;
+  }
+  int *agg2 = (int *)malloc(sizeof(int) * n);
+  memcpy(agg2, agg, sizeof(int) * n);
+  for (int i = 0; i < n; i++) {
+    if (agg[i] >= 0) continue;
+    for (int k = sptr[i]; k < sptr[i + 1]; k++) if (agg[scol[k]] >= 0) { agg2[i] = agg[scol[k]]; break; }
+  }
+  memcpy(agg, agg2, sizeof(int) * n);
+  free(agg2);
+  for (int i = 0; i < n; i++) {
+    if (agg[i] >= 0) continue;
+    agg[i] = na;
+    for (int k = sptr[i]; k < sptr[i + 1]; k++) if (agg[scol[k]] < 0) agg[scol[k]] = na;
+    na++;
+  }
+  free(d); free(sptr); free(scol);
+  return na;
+}
+static void amg_free(orc_ctx *c) {
+  for (int l = 0; l < c->amg_nlev; l++) {
+    amg_level *L = &c->amg[l];
+    free_csr(&L->A); free_csr(&L->P); free_csr(&L->R);
+    free(L->dinv); free(L->x); free(L->b); free(L->r); free(L->d0); free(L->d1);
+  }
+  free(c->amg); c->amg = NULL; c->amg_nlev = 0;
+  free(c->amg_cinv); c->amg_cinv = NULL;
+}
+static int dense_inv(double *a, int n) {
+  double *inv = (double *)calloc((size_t)n * n, sizeof(double));
+  for (int i = 0; i < n; i++) inv[(size_t)i * n + i] = 1.0;
+  for (int col = 0; col < n; col++) {
+    int piv = col;
+    double best = fabs(a[(size_t)col * n + col]);
+    for (int r = col + 1; r < n; r++) if (fabs(a[(size_t)r * n + col]) > best) { best = fabs(a[(size_t)r * n + col]); piv = r; }
+    if (!(best > 0)) { free(inv); return -1; }
+    if (piv != col)
+      for (int k = 0; k < n; k++) {
+        double t = a[(size_t)piv * n + k]; a[(size_t)piv * n + k] = a[(size_t)col * n + k]; a[(size_t)col * n + k] = t;
+        t = inv[(size_t)piv * n + k]; inv[(size_t)piv * n + k] = inv[(size_t)col * n + k]; inv[(size_t)col * n + k] = t;
+      }
+    double d = 1.0 / a[(size_t)col * n + col];
+    for (int k = 0; k < n; k++) { a[(size_t)col * n + k] *= d; inv[(size_t)col * n + k] *= d; }
+    for (int r = 0; r < n; r++) {
+      if (r == col) continue;
+      double f = a[(size_t)r * n + col];
+      if (f == 0.0) continue;
+      for (int k = 0; k < n; k++) { a[(size_t)r * n + k] -= f * a[(size_t)col * n + k]; inv[(size_t)r * n + k] -= f * inv[(size_t)col * n + k]; }
+    }
+  }
+  memcpy(a, inv, sizeof(double) * (size_t)n * n);
+  free(inv);
+  return 0;
+}
+/* smoothed aggregation hierarchy of S (copied) */
+static int amg_setup(orc_ctx *c, const csr_t *S, const orc_opts *o) {
+  amg_free(c);
+  c->amg = (amg_level *)calloc(16, sizeof(amg_level));
+  csr_t A;
+  int nnz = S->rowptr[S->n];
+  csr_alloc(&A, S->n, nnz);
+  memcpy(A.rowptr, S->rowptr, sizeof(int) * (S->n + 1)); memcpy(A.col, S->col, sizeof(int) * nnz); memcpy(A.val, S->val, sizeof(double) * nnz);
+  for (;;) {
+    amg_level *L = &c->amg[c->amg_nlev++];
+    int n = A.n;
+    L->n = n; L->A = A;
+    L->dinv = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) {
+      L->dinv[i] = 1.0;
+      for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] == i && A.val[k] != 0.0) L->dinv[i] = 1.0 / A.val[k];
+    }
+    double lm = power_lmax(&A, L->dinv, 15);
+    L->lmax = 1.1 * lm; L->lmin = L->lmax / o->amg_smooth_ratio;
+    L->x = (double *)calloc(n, sizeof(double)); L->b = (double *)calloc(n, sizeof(double)); L->r = (double *)calloc(n, sizeof(double));
+    L->d0 = (double *)calloc(n, sizeof(double)); L->d1 = (double *)calloc(n, sizeof(double));
+    if (n <= o->amg_max_coarse || c->amg_nlev >= 16) break;
+    int *agg = (int *)malloc(sizeof(int) * n);
+    int na = amg_aggregate(&A, o->amg_theta, agg);
+    if (na >= n || na < 1) { free(agg); break; }
+    csr_t P0, AP0, P, R, AP, Ac;
+    csr_alloc(&P0, n, n);
+    for (int i = 0; i <= n; i++) P0.rowptr[i] = i;
+    for (int i = 0; i < n; i++) { P0.col[i] = agg[i]; P0.val[i] = 1.0; }
+    csr_spgemm(&A, &P0, na, &AP0);
+    double omega = 4.0 / 3.0 / lm;
+    /* P = P0 - omega D^-1 A P0 (A has a diagonal, so AP0 contains column agg[i]) */
+    csr_alloc(&P, n, AP0.rowptr[n]);
+    memcpy(P.rowptr, AP0.rowptr, sizeof(int) * (n + 1)); memcpy(P.col, AP0.col, sizeof(int) * AP0.rowptr[n]);
+    for (int i = 0; i < n; i++)
+      for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; k++)
+        P.val[k] = -omega * L->dinv[i] * AP0.val[k] + (AP0.col[k] == agg[i] ? 1.0 : 0.0);
+    csr_transpose(&P, na, &R);
+    csr_spgemm(&A, &P, na, &AP);
+    csr_spgemm(&R, &AP, na, &Ac);
+    L->P = P; L->R = R;
+    free_csr(&P0); free_csr(&AP0); free_csr(&AP); free(agg);
+    A = Ac;
+  }
+  {
+    int n = A.n;
+    double *D = (double *)calloc((size_t)n * n, sizeof(double)), tr = 0;
+    for (int i = 0; i < n; i++)
+      for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) { D[(size_t)i * n + A.col[k]] = A.val[k]; if (A.col[k] == i) tr += fabs(A.val[k]); }
+    if (c->singular) { double al = tr / n / n; for (size_t k = 0; k < (size_t)n * n; k++) D[k] += al; }
+    if (dense_inv(D, n)) { free(D); snprintf(c->err, sizeof c->err, "singular coarsest AMG operator"); return -1; }
+    c->amg_cinv = D; c->amg_cn = n;
+  }
+  return 0;
+}
+static void cheb_smooth(const csr_t *A, const double *dinv, double lmin, double lmax, int deg, const double *b, double *x,
+                        int zero_guess, double *r, double *d0, double *d1) {
+  const int n = A->n;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  const double *rin = b;
+  if (!zero_guess) { csr_mult(A, x, r, 1, b); rin = r; }
+  double *dold = d0, *dnew = d1;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) { double v = dinv[i] * rin[i] / theta; dold[i] = v; x[i] = zero_guess ? v : x[i] + v; }
+  for (int k = 1; k < deg; k++) {
+    double rho_new = 1.0 / (2.0 * sigma - rho), c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+      double s = 0;
+      for (int kk = A->rowptr[i]; kk < A->rowptr[i + 1]; kk++) s += A->val[kk] * dold[A->col[kk]];
+      double rr = rin[i] - s, dn = c1 * dold[i] + c2 * dinv[i] * rr;
+      r[i] = rr; dnew[i] = dn; x[i] += dn;
+    }
+    rin = r;
+    double *t = dold; dold = dnew; dnew = t;
+    rho = rho_new;
+  }
+}
+static void amg_vcycle(orc_ctx *c, const orc_opts *o, int lev, const double *b, double *x) {
+  amg_level *L = &c->amg[lev];
+  if (lev + 1 == c->amg_nlev) {
+    int n = c->amg_cn;
+    for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < n; k++) s += c->amg_cinv[(size_t)i * n + k] * b[k]; x[i] = s; }
+    return;
+  }
+  amg_level *N = &c->amg[lev + 1];
+  cheb_smooth(&L->A, L->dinv, L->lmin, L->lmax, o->amg_smooth_degree, b, x, 1, L->r, L->d0, L->d1);
+  csr_mult(&L->A, x, L->r, 1, b);
+  csr_mult(&L->R, L->r, N->b, 0, NULL);
+  amg_vcycle(c, o, lev + 1, N->b, N->x);
+  csr_mult(&L->P, N->x, x, 2, NULL);
+  cheb_smooth(&L->A, L->dinv, L->lmin, L->lmax, o->amg_smooth_degree, b, x, 0, L->r, L->d0, L->d1);
+}
+
 /* PC setup for the current Jacobian: ILU(0) of A00 and of Sp = A11 - A10 D^-1 A01 */
-static int pc_setup(orc_ctx *c) {
+static int pc_setup(orc_ctx *c, const orc_opts *o) {
   const int nv = c->nv, nu = 2 * nv;
   /* A00 copy */
   csr_t *A = &c->A00f;
@@ -667,6 +938,18 @@ static int pc_setup(orc_ctx *c) {
       for (int k = s; k < e; k++) pos[S->col[k]] = -1;
     }
     free(pos);
+  }
+  if (o->pc_kind == 1) {
+    /* Jacobi diagonal + spectral bound every Jacobian, hierarchy lagged (as on the GPU) */
+    free(c->dinvA); c->dinvA = Dinv;
+    csr_t A00v; /* view of the unfactored copy */
+    A00v = *A;
+    c->lmaxA = 1.15 * power_lmax(&A00v, Dinv, 8);
+    if (!c->amg_valid || c->amg_force) {
+      if (amg_setup(c, S, o)) return -1;
+      c->amg_valid = 1; c->amg_force = 0; c->amg_its_ref = 0;
+    }
+    return 0;
   }
   free(Dinv);
   if (ilu0(A)) { snprintf(c->err, sizeof c->err, "zero pivot in ILU(A00)"); return -1; }
@@ -749,10 +1032,26 @@ typedef struct {
   double *yu, *yp, *tu, *tp;
   double sub_rtol;
   int sub_max_it, sub_its;
+  const orc_opts *o;
+  double *cr, *cd0, *cd1;
 } pc_ws;
 
 static void pc_apply(orc_ctx *c, pc_ws *p, const double *r, double *z) {
   const int nv = c->nv, nu = 2 * nv;
+  if (p->o->pc_kind == 1) {
+    const orc_opts *o = p->o;
+    const csr_t *A = &c->A00f;
+    const double lmin = c->lmaxA / o->cheb_ratio;
+    cheb_smooth(A, c->dinvA, lmin, c->lmaxA, o->cheb_degree, r, p->yu, 1, p->cr, p->cd0, p->cd1);
+    blk_mult(c, 3, p->yu, p->tp);
+    for (int i = 0; i < nv; i++) p->tp[i] = r[nu + i] - p->tp[i];
+    amg_vcycle(c, o, 0, p->tp, z + nu);
+    blk_mult(c, 2, z + nu, p->tu);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nu; i++) p->tu[i] = r[i] - p->tu[i];
+    cheb_smooth(A, c->dinvA, lmin, c->lmaxA, o->cheb_degree, p->tu, z, 1, p->cr, p->cd0, p->cd1);
+    return;
+  }
   a00_solve(c, &p->sub, r, p->yu, p->sub_rtol, p->sub_max_it, &p->sub_its); /* y_u = A00^-1 r_u */
   blk_mult(c, 3, p->yu, p->tp);                                            /* A10 y_u */
   for (int i = 0; i < nv; i++) p->tp[i] = r[nu + i] - p->tp[i];
@@ -840,6 +1139,8 @@ void orc_default_opts(orc_opts *o) {
   o->ksp_rtol = 1e-5; o->ksp_atol = 1e-50; o->ksp_max_it = 1000; o->ksp_restart = 200;
   o->sub_rtol = 1e-5; o->sub_max_it = 10000; o->sub_restart = 30;
   o->remove_p_mean = 1; o->verbose = 0;
+  o->pc_kind = 0; o->cheb_degree = 3; o->cheb_ratio = 10.0; o->amg_smooth_degree = 2; o->amg_smooth_ratio = 8.0;
+  o->amg_theta = 0.08; o->amg_max_coarse = 300;
 }
 
 /* One time step: Newton on the monolithic vector xv (in: initial guess = previous
@@ -855,7 +1156,10 @@ int orc_solve_step(orc_ctx *c, double *xv, const orc_opts *o, orc_stats *st) {
   pc.yu = (double *)malloc(sizeof(double) * nu); pc.tu = (double *)malloc(sizeof(double) * nu);
   pc.yp = (double *)malloc(sizeof(double) * nv); pc.tp = (double *)malloc(sizeof(double) * nv);
   pc.sub_rtol = o->sub_rtol; pc.sub_max_it = o->sub_max_it;
+  pc.o = o;
+  pc.cr = (double *)malloc(sizeof(double) * nu); pc.cd0 = (double *)malloc(sizeof(double) * nu); pc.cd1 = (double *)malloc(sizeof(double) * nu);
   int singular = !c->any_pbc;
+  if (singular != c->singular) { c->singular = singular; c->amg_valid = 0; }
   if (o->remove_p_mean) remove_pmean(c, xv);
   double t0 = now_ms();
   orc_assemble(c, xv, 1, F);
@@ -869,8 +1173,14 @@ int orc_solve_step(orc_ctx *c, double *xv, const orc_opts *o, orc_stats *st) {
     if (it > 0 && fn <= o->snes_rtol * st->fnorm0) { reason = 3; break; }
     if (it >= o->snes_max_it) { reason = -5; break; }
     t0 = now_ms();
-    if (pc_setup(c)) { reason = -3; break; }
+    if (pc_setup(c, o)) { reason = -3; break; }
+    int its_before = st->krylov_its;
     int kr = fgmres(c, o, &pc, F, d, singular, &st->krylov_its);
+    if (o->pc_kind == 1) { /* adaptive lagging of the hierarchy, as in libcfdh */
+      int kits = st->krylov_its - its_before;
+      if (c->amg_its_ref == 0) c->amg_its_ref = kits > 0 ? kits : 1;
+      else if (kits > (3 * c->amg_its_ref) / 2 + 5) c->amg_force = 1;
+    }
     st->ms_solve += now_ms() - t0;
     if (kr < 0) { reason = -3; snprintf(c->err, sizeof c->err, "linear solve failed (%d)", kr); break; }
     /* bt line search on 1/2|F|^2 (Dennis-Schnabel backtracking, alpha = 1e-4) */
@@ -906,7 +1216,7 @@ int orc_solve_step(orc_ctx *c, double *xv, const orc_opts *o, orc_stats *st) {
   st->reason = reason;
   st->sub_its = pc.sub_its;
   gm_free(&pc.sub);
-  free(pc.yu); free(pc.tu); free(pc.yp); free(pc.tp);
+  free(pc.yu); free(pc.tu); free(pc.yp); free(pc.tp); free(pc.cr); free(pc.cd0); free(pc.cd1);
   free(F); free(d); free(xt); free(Ft);
   return reason;
 }

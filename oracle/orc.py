@@ -26,7 +26,9 @@ class Opts(C.Structure):
                 ("snes_max_it", C.c_int), ("ksp_rtol", C.c_double), ("ksp_atol", C.c_double),
                 ("ksp_max_it", C.c_int), ("ksp_restart", C.c_int), ("sub_rtol", C.c_double),
                 ("sub_max_it", C.c_int), ("sub_restart", C.c_int), ("remove_p_mean", C.c_int),
-                ("verbose", C.c_int)]
+                ("verbose", C.c_int), ("pc_kind", C.c_int), ("cheb_degree", C.c_int), ("cheb_ratio", C.c_double),
+                ("amg_smooth_degree", C.c_int), ("amg_smooth_ratio", C.c_double), ("amg_theta", C.c_double),
+                ("amg_max_coarse", C.c_int)]
 
 
 class Stats(C.Structure):

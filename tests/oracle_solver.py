@@ -1,0 +1,42 @@
+"""Test double: a `Solver` with the plugin surface of cfd_hemodynamic_amd.solverBase backed by
+the CPU oracle, so that the Scenario harness (host logic) can run without a GPU.
+TEST INFRASTRUCTURE -- never imported by the product."""
+import numpy as np
+
+from cfd_hemodynamic_amd.solverBase import SolverBase
+from oracle import orc
+
+
+class Solver(SolverBase):
+    def __init__(self, mesh, dt, rho, mu, f, initial_velocity=None, **kwargs):
+        super().__init__(mesh, dt, rho, mu, f)
+        self.initVelocitySpace("Lagrange", "triangle", 1, shape=(2,))
+        self.initPressureSpace("Lagrange", "triangle", 1)
+        if initial_velocity:
+            self.u_prev.interpolate(initial_velocity)
+        self.O = orc.Oracle(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, dt, rho, mu, f)
+        self.opts = orc.default_opts(pc_kind=int(kwargs.get("pc_kind", 1)))
+        for k, v in dict(kwargs.get("options", {})).items():
+            setattr(self.opts, k, v)
+        self.nv = mesh.num_vertices
+        self.last_stats = None
+        self.calls = 0
+
+    def setup(self, bcu, bcp, facet_tags=None, tags=None):
+        self._bcs = [(0, bc.getBC(self.V)) for bc in bcu] + [(1, bc.getBC(self.Q)) for bc in bcp]
+        self.x_n = np.concatenate([self.u_prev.x.array, self.p_prev.x.array])
+
+    def solveStep(self):
+        self.O.clear_bcs()
+        for fld, bc in self._bcs:
+            bc.update()
+            if fld == 0:
+                self.O.add_bc_u(bc.dofs, bc.g.x.array.reshape(-1, 2)[bc.dofs])
+            else:
+                self.O.add_bc_p(bc.dofs, bc.g.x.array[bc.dofs])
+        self.O.set_un(self.u_prev.x.array)
+        self.x_n, st = self.O.solve_step(self.x_n, self.opts)
+        self.u_sol.x.array[:] = self.x_n[: 2 * self.nv]
+        self.p_sol.x.array[:] = self.x_n[2 * self.nv:]
+        self.last_stats = st
+        self.calls += 1

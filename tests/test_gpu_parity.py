@@ -1,0 +1,277 @@
+"""Parity tests proper: the HIP path through the C-ABI against the CPU oracle on the same seeded
+inputs, the committed golden vectors, and size-independent properties at the BASELINE sizes.
+Tolerances (fp64): element/assembly/SpMV 1e-13 relative; converged step solution 1e-9;
+drag/lift/L2 1e-8 (north_star asks 1e-6)."""
+import numpy as np
+import pytest
+
+from util import dfg_case, lid_case, load_golden, make_ctx, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
+
+
+def _tight(ctx, **kw):
+    o = ctx.default_options()
+    for k, v in {**TIGHT, **kw}.items():
+        setattr(o, k, v)
+    ctx.set_options(o)
+    return o
+
+
+def _rand_state(nv, seed):
+    rng = np.random.default_rng(seed)
+    return 0.1 * rng.standard_normal(3 * nv), 0.1 * rng.standard_normal(2 * nv)
+
+
+@pytest.mark.parametrize("case_fn,arg", [(dfg_case, 12), (lid_case, 16), (dfg_case, 37)])
+def test_assembly_and_spmv_match_oracle(case_fn, arg):
+    case = case_fn(arg)
+    nv = case.nv
+    O, ctx = make_oracle(case), make_ctx(case)
+    xv, un = _rand_state(nv, 11)  # does not satisfy the Dirichlet data: lifting is exercised
+    O.set_un(un)
+    F = O.assemble(xv)
+    J = O.csr()
+    ctx.set_state(u_prev=un, p_prev=np.zeros(nv), u=xv[: 2 * nv], p=xv[2 * nv:])
+    ctx.assemble(True)
+    Fg = np.concatenate(ctx.get_residual())
+    Jg = ctx.get_csr()
+    assert np.abs(F - Fg).max() <= 1e-13 * np.abs(F).max()
+    assert abs(J - Jg).max() <= 1e-13 * abs(J).max()
+    v = np.random.default_rng(3).standard_normal(3 * nv)
+    assert np.abs(ctx.spmv(v) - J @ v).max() <= 1e-13 * np.abs(J @ v).max()
+    # residual-only evaluation (lifting still applied) gives the same F
+    ctx.assemble(False)
+    assert np.array_equal(np.concatenate(ctx.get_residual()), Fg)
+    ctx.close()
+
+
+def test_assembly_is_bitwise_reproducible():
+    """No atomics: LDS accumulation in fixed rounds -> identical bits run to run."""
+    case = dfg_case(24)
+    nv = case.nv
+    xv, un = _rand_state(nv, 5)
+    outs = []
+    for _ in range(2):
+        ctx = make_ctx(case)
+        ctx.set_state(u_prev=un, p_prev=np.zeros(nv), u=xv[: 2 * nv], p=xv[2 * nv:])
+        ctx.assemble(True)
+        outs.append((np.concatenate(ctx.get_residual()), ctx.get_csr().data.copy()))
+        ctx.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("name", ["dfg_m6", "lid_n8"])
+def test_golden_vectors(name):
+    import scipy.sparse as sp
+    case, g = load_golden(name)
+    nv = case.nv
+    ctx = make_ctx(case)
+    ctx.set_state(u_prev=g["u_prev"].ravel(), p_prev=np.zeros(nv), u=g["state"][: 2 * nv], p=g["state"][2 * nv:])
+    ctx.assemble(True)
+    F = np.concatenate(ctx.get_residual())
+    assert np.abs(F - g["F"]).max() <= 1e-13 * np.abs(g["F"]).max()
+    Jg = sp.csr_matrix((g["J_data"], g["J_indices"], g["J_indptr"]), shape=(3 * nv, 3 * nv))
+    assert abs(ctx.get_csr() - Jg).max() <= 1e-13 * abs(Jg).max()
+    _tight(ctx)
+    z2, z1 = np.zeros(2 * nv), np.zeros(nv)
+    ctx.set_state(u_prev=z2, p_prev=z1, u=z2, p=z1)
+    for k in (1, 2):
+        st = ctx.solve_step()
+        assert st.reason > 0
+        x = np.concatenate(ctx.get_solution())
+        ctx.advance()
+        ref = g["step%d" % k]
+        assert np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref)
+    assert np.allclose([ctx.functional(2), ctx.functional(3)], g["l2"], rtol=1e-9)
+    if "drag_lift" in g:
+        assert np.allclose([ctx.functional(0, 5), ctx.functional(1, 5)], g["drag_lift"], rtol=1e-7, atol=1e-12)
+    ctx.close()
+
+
+@pytest.mark.parametrize("case_fn,arg,nsteps", [(dfg_case, 16, 4), (lid_case, 24, 3)])
+def test_time_steps_match_oracle(case_fn, arg, nsteps):
+    """Same mesh, dt, initial state; both sides converged tightly; the oracle runs the reference's
+    own preconditioner configuration (ILU-based), the GPU its Chebyshev/AMG one."""
+    from oracle import orc
+    case = case_fn(arg)
+    nv = case.nv
+    O, ctx = make_oracle(case), make_ctx(case)
+    _tight(ctx)
+    z2, z1 = np.zeros(2 * nv), np.zeros(nv)
+    ctx.set_state(u_prev=z2, p_prev=z1, u=z2, p=z1)
+    x = np.zeros(3 * nv)
+    O.set_un(z2)
+    opts = orc.default_opts(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10, sub_rtol=1e-8)
+    for _ in range(nsteps):
+        st = ctx.solve_step()
+        assert st.reason > 0 and st.newton_its <= 6
+        xg = np.concatenate(ctx.get_solution())
+        ctx.advance()
+        x, _ = O.solve_step(x, opts)
+        O.set_un(x[: 2 * nv])
+        assert np.linalg.norm(xg - x) <= 1e-9 * np.linalg.norm(x)
+    assert abs(ctx.functional(2) - O.functional(x, 2)) <= 1e-10 * O.functional(x, 2)
+    assert abs(ctx.functional(3) - O.functional(x, 3)) <= 1e-8 * O.functional(x, 3)
+    if "ft" in case.markers:
+        obst = case.markers["ft"].find(5)
+        for kind in (0, 1):
+            a, b = ctx.functional(kind, 5), O.functional(x, kind, obst)
+            assert abs(a - b) <= 1e-8 * abs(b) + 1e-14
+    # inf-norm functionals of the early-stop test (scenario.py:268-280)
+    u, _ = ctx.get_solution()
+    up, _ = ctx.get_previous()
+    assert ctx.functional(4) == np.abs(u).max() and ctx.functional(6) == np.abs(u - up).max()
+    ctx.close()
+
+
+def test_reference_default_tolerances_and_divergence_error():
+    case = dfg_case(16)
+    nv = case.nv
+    ctx = make_ctx(case)
+    z2, z1 = np.zeros(2 * nv), np.zeros(nv)
+    ctx.set_state(u_prev=z2, p_prev=z1, u=z2, p=z1)
+    st = ctx.solve_step()  # PETSc defaults
+    assert st.reason in (3, 4) and st.newton_its <= 5 and st.krylov_its > 0
+    # RuntimeError exactly like stabilized_schur.py:332-334 when Newton cannot converge
+    o = ctx.default_options()
+    o.snes_max_it, o.snes_rtol, o.snes_stol = 1, 1e-15, 0.0
+    ctx.set_options(o)
+    ctx.set_state(u_prev=z2, p_prev=z1, u=z2, p=z1)
+    with pytest.raises(RuntimeError, match=r"Did not converge, reason: -5"):
+        ctx.solve_step()
+    ctx.close()
+
+
+def test_solver_class_and_scenario_drop_in():
+    """The plugin surface end to end: Scenario loop (device-resident and the reference's literal
+    host-copy loop) -> identical results; drag/lift against the oracle-driven loop."""
+    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+    from oracle import orc
+    kw = dict(m=12, quiet=True, options=dict(TIGHT))
+    a = DFG1Benchmark("stabilized_schur", 0.01, 0.12, **kw)
+    a.setup()  # the reference calls setup() twice (dfg_1.py:38 and simulation.py:269)
+    a.solve(None, device_resident=True)
+    b = DFG1Benchmark("stabilized_schur", 0.01, 0.12, **kw)
+    b.solve(None, device_resident=False)
+    assert a.num_steps == b.num_steps == 13
+    assert np.array_equal(a.solver.u_sol.x.array, b.solver.u_sol.x.array)
+    assert np.array_equal(a.solver.p_sol.x.array, b.solver.p_sol.x.array)
+    assert abs(a.norm_v - b.norm_v) <= 1e-12 * a.norm_v
+    # oracle-driven loop
+    case = dfg_case(12)
+    nv = case.nv
+    O = make_oracle(case)
+    x = np.zeros(3 * nv)
+    O.set_un(np.zeros(2 * nv))
+    opts = orc.default_opts(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10, pc_kind=1)
+    for _ in range(13):
+        x, _ = O.solve_step(x, opts)
+        O.set_un(x[: 2 * nv])
+    obst = case.markers["ft"].find(5)
+    cd, cl = 500 * O.functional(x, 0, obst), 500 * O.functional(x, 1, obst)
+    assert abs(a.drag - cd) <= 1e-8 * abs(cd) and abs(a.lift - cl) <= 1e-7 * abs(cl)
+    assert abs(a.norm_v - O.functional(x, 2)) <= 1e-10 * a.norm_v
+    xg = np.concatenate([a.solver.u_sol.x.array, a.solver.p_sol.x.array])
+    assert np.linalg.norm(xg - x) <= 1e-9 * np.linalg.norm(x)
+    assert a.p_diff is not None and np.isfinite(a.p_diff)
+    assert a.solver.shear_stress.x.array.any()
+
+
+def test_time_dependent_dirichlet_values():
+    """bc.update() re-reads the source every step (stabilized_schur.py:170): a pulsatile inlet
+    `v(t) = v0 (1 + 0.5 sin 2 pi t)` through the Function the BoundaryCondition wraps."""
+    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+    sc = DFG1Benchmark("stabilized_schur", 0.01, 0.05, m=8, quiet=True)
+    src = sc.bcu[0].f
+    base = src.x.array.copy()
+
+    def cb(t):
+        src.x.array[:] = base * (1.0 + 0.5 * np.sin(2 * np.pi * t))
+
+    sc.solve(None, afterStepCallback=cb)
+    u = sc.solver.u_sol.x.array.reshape(-1, 2)
+    inl = sc.solver.bcu_d[0].dofs
+    # the callback takes effect one step late: last step used t = T - dt
+    t_used = sc.t_end - sc.dt
+    assert np.allclose(u[inl], (base * (1.0 + 0.5 * np.sin(2 * np.pi * t_used))).reshape(-1, 2)[inl], atol=1e-14)
+
+
+# ---------------------------------------------------------------- full-size properties
+@pytest.fixture(scope="module")
+def big():
+    case = dfg_case(200)  # BASELINE configs[2]: 336k vertices, 1.0M DOF
+    ctx = make_ctx(case)
+    yield case, ctx
+    ctx.close()
+
+
+def test_full_size_jacobian_consistency(big):
+    """At ~1M DOF: J v equals the central difference of the device residual (size-independent
+    property; rel 1e-6), and SpMV is linear to round-off."""
+    case, ctx = big
+    nv = case.nv
+    assert 3 * nv > 1_000_000
+    rng = np.random.default_rng(0)
+    u = np.zeros((nv, 2))
+    u[:, 0] = 4 * 0.3 * case.mesh.x[:, 1] * (0.41 - case.mesh.x[:, 1]) / 0.41**2
+    u += 1e-3 * rng.uniform(-1, 1, u.shape)  # SURVEY.md 8d micro-benchmark state
+    p = 1e-2 * rng.standard_normal(nv)
+    for fld, nodes, vals in case.bcs:  # satisfy the Dirichlet data so that F is differentiable in x
+        if fld == 0:
+            u[nodes] = vals
+        else:
+            p[nodes] = vals
+    un = u.ravel().copy()
+    v = rng.standard_normal(3 * nv)
+    isbc = np.zeros(3 * nv, bool)
+    for fld, nodes, _ in case.bcs:
+        if fld == 0:
+            isbc[2 * nodes] = isbc[2 * nodes + 1] = True
+        else:
+            isbc[2 * nv + nodes] = True
+    v[isbc] = 0.0
+    x0 = np.concatenate([u.ravel(), p])
+    ctx.set_state(u_prev=un, p_prev=np.zeros(nv), u=x0[: 2 * nv], p=x0[2 * nv:])
+    ctx.assemble(True)
+    Jv = ctx.spmv(v)
+    eps = 1e-6
+
+    def F_at(x):
+        ctx.set_state(u=x[: 2 * nv], p=x[2 * nv:])
+        ctx.assemble(False)
+        return np.concatenate(ctx.get_residual())
+
+    fd = (F_at(x0 + eps * v) - F_at(x0 - eps * v)) / (2 * eps)
+    assert np.linalg.norm(fd[~isbc] - Jv[~isbc]) <= 1e-6 * np.linalg.norm(Jv[~isbc])
+    w = rng.standard_normal(3 * nv)
+    ctx.set_state(u=x0[: 2 * nv], p=x0[2 * nv:])
+    ctx.assemble(True)
+    lhs = ctx.spmv(2.0 * v - 3.0 * w)
+    rhs = 2.0 * ctx.spmv(v) - 3.0 * ctx.spmv(w)
+    assert np.abs(lhs - rhs).max() <= 1e-12 * np.abs(rhs).max()
+
+
+def test_full_size_steps_converge_and_are_consistent(big):
+    """Two steps from rest at ~1M DOF with default and with tight tolerances agree to the solver
+    noise level; Newton converges in a handful of iterations."""
+    case, ctx = big
+    nv = case.nv
+    z2, z1 = np.zeros(2 * nv), np.zeros(nv)
+    res = []
+    for tight in (False, True):
+        o = ctx.default_options()
+        if tight:
+            o.snes_rtol, o.ksp_rtol, o.snes_stol = 1e-11, 1e-9, 0.0
+        ctx.set_options(o)
+        ctx.set_state(u_prev=z2, p_prev=z1, u=z2, p=z1)
+        for _ in range(2):
+            st = ctx.solve_step()
+            assert st.reason > 0 and st.newton_its <= 6
+            ctx.advance()
+        res.append((ctx.functional(0, 5), ctx.functional(2), st.fnorm))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
+    assert abs(res[0][1] - res[1][1]) <= 1e-7 * res[1][1]
+    assert res[1][2] < 1e-9

@@ -1,0 +1,76 @@
+import numpy as np
+import pytest
+
+from cfd_hemodynamic_amd.mesh import (DFG_H, DFG_L, DFG_R, create_dfg_channel, create_stenosis_channel,
+                                      create_unit_square, locate_entities_boundary)
+from cfd_hemodynamic_amd.parallel import LocalPart, partition_vertices_rcb
+
+
+def test_unit_square_right_diagonals():
+    m = create_unit_square(3)
+    assert m.num_vertices == 16 and m.num_cells == 18 and m.num_facets == 12
+    assert np.isclose(m.cell_areas().sum(), 1.0)
+    # first square split along (0,0)-(1,1): both cells contain vertices 0 and 5
+    assert {0, 5} <= set(m.cells[0]) and {0, 5} <= set(m.cells[1])
+    assert np.allclose(m.h(), np.sqrt(2) / 3)
+
+
+@pytest.mark.parametrize("mm", [6, 18])
+def test_dfg_channel(mm):
+    m, ft = create_dfg_channel(mm)
+    area = DFG_L * DFG_H - np.pi * DFG_R**2
+    # polygonal cylinder: area error O(1/m^2)
+    assert abs(m.cell_areas().sum() - area) < 0.02 / mm**2 + 1e-12 + np.pi * DFG_R**2 * (2 * np.pi / (4 * mm)) ** 2 / 6 * 1.5
+    assert m.cell_areas().min() > 0
+    assert set(np.unique(ft.values)) == {2, 3, 4, 5}
+    obst = m.facet_vertices[ft.find(5)]
+    r = np.linalg.norm(m.x[np.unique(obst)] - np.array([0.2, 0.2]), axis=1)
+    assert np.allclose(r, DFG_R)
+    assert len(ft.find(5)) == 4 * mm and len(ft.find(2)) == mm and len(ft.find(3)) == mm
+    if mm == 18:
+        assert 2500 < m.num_vertices < 3000  # ~8k DOF, the reference's coarse gmsh mesh
+
+
+def test_dfg_refined_size():
+    m, _ = create_dfg_channel(60)
+    assert abs(m.num_vertices - 8.37 * 60**2) / (8.37 * 60**2) < 0.03
+
+
+def test_locate_entities_all_vertices_rule():
+    m = create_unit_square(4)
+    lid = locate_entities_boundary(m, 1, lambda x: np.isclose(x[1], 1.0) & (x[0] > 1e-10) & (x[0] < 1 - 1e-10))
+    # the two top facets touching the corners are excluded (lid_driven2D.py:65-67)
+    assert len(lid) == 2
+
+
+def test_stenosis_channel_markers():
+    m, ft = create_stenosis_channel(8, L=20.0, x_sten=8.0)
+    assert set(np.unique(ft.values)) == {1, 2, 3}
+    assert m.cell_areas().min() > 0
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 4, 8])
+def test_partition_and_halo_plan(nparts):
+    m, _ = create_dfg_channel(8)
+    owner = partition_vertices_rcb(m.x, nparts)
+    counts = np.bincount(owner, minlength=nparts)
+    assert counts.min() >= counts.max() - nparts  # balanced
+    parts = [LocalPart(m, owner, r) for r in range(nparts)]
+    assert sum(p.nvo for p in parts) == m.num_vertices
+    seen_cells = np.zeros(m.num_cells, dtype=int)
+    for p in parts:
+        # owned rows are complete: every cell touching an owned vertex is local
+        touch = (owner[m.cells] == p.rank).any(axis=1)
+        assert np.array_equal(np.nonzero(touch)[0], p.cell_ids)
+        seen_cells[p.cell_ids[owner[m.cells[p.cell_ids, 0]] == p.rank]] += 1
+        # ghosts contiguous per neighbour, in neighbour order
+        assert np.array_equal(p.recv_idx, np.arange(p.nvo, p.nv))
+        assert np.all(np.diff(owner[p.ghost_global]) >= 0)
+    assert np.all(seen_cells == 1)  # each cell integrated by exactly one rank (first-vertex rule)
+    # send lists mirror the neighbours' receive lists
+    for p in parts:
+        for k, q in enumerate(p.nbr):
+            sent = p.l2g[p.send_idx[p.send_ptr[k]:p.send_ptr[k + 1]]]
+            qk = list(parts[q].nbr).index(p.rank)
+            recv = parts[q].l2g[parts[q].recv_idx[parts[q].recv_ptr[qk]:parts[q].recv_ptr[qk + 1]]]
+            assert np.array_equal(sent, recv)

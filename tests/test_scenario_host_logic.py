@@ -1,0 +1,122 @@
+"""Host logic of the plugin surface (Scenario loop, BoundaryCondition, Function) without a GPU:
+the Scenario harness is driven by a test double backed by the CPU oracle."""
+import sys
+import types
+
+import numpy as np
+import pytest
+
+import oracle_solver
+from cfd_hemodynamic_amd.boundaryCondition import BoundaryCondition
+from cfd_hemodynamic_amd.fem import Function, FunctionSpace
+from cfd_hemodynamic_amd.mesh import create_unit_square
+
+
+@pytest.fixture()
+def oracle_backend(monkeypatch):
+    mod = types.ModuleType("cfd_hemodynamic_amd.solvers._oracle_double")
+    mod.Solver = oracle_solver.Solver
+    monkeypatch.setitem(sys.modules, "cfd_hemodynamic_amd.solvers._oracle_double", mod)
+    return "_oracle_double"
+
+
+def test_function_interpolate_layout():
+    m = create_unit_square(2)
+    V = FunctionSpace(m, 2)
+    f = Function(V)
+    f.interpolate(lambda x: np.vstack((x[0] + 10 * x[1], -x[0])))
+    a = f.x.array.reshape(-1, 2)
+    assert np.allclose(a[:, 0], m.x[:, 0] + 10 * m.x[:, 1]) and np.allclose(a[:, 1], -m.x[:, 0])
+    assert V.dofmap.index_map.size_global == m.num_vertices and V.dofmap.index_map_bs == 2
+
+
+def test_boundary_condition_update_reinterpolates_source():
+    m = create_unit_square(2)
+    V = FunctionSpace(m, 2)
+    src = Function(V)
+    bc = BoundaryCondition(src)
+    bc.initGeometrical(lambda x: np.isclose(x[0], 0.0))
+    d = bc.getBC(V)
+    assert set(d.dofs) == {0, 3, 6}
+    src.x.array[:] = 7.0
+    assert d.g.x.array.max() == 0.0
+    d.update()  # boundaryCondition.py:48-51
+    assert d.g.x.array.min() == 7.0
+
+
+def test_time_loop_counts_and_early_stop(oracle_backend):
+    """scenario.py:243-307: float-accumulated `while t < T`; early-stop test at (i+1)%10==0
+    comparing u_sol with the not-yet-updated u_prev (SURVEY.md Appendix B 4,5)."""
+    from cfd_hemodynamic_amd.scenarios.lid_driven2D import LidDriven2DSimulation
+    sc = LidDriven2DSimulation(oracle_backend, 0.01, 0.1, nx=6, mu=0.1, quiet=True)
+    sc.solve(None)
+    assert sc.num_steps == 11  # T=0.1, dt=0.01 -> 11 steps by float accumulation
+    assert sc.solver.calls == 11
+    # reference semantics of the state copy
+    assert np.array_equal(sc.solver.u_prev.x.array, sc.solver.u_sol.x.array)
+    # a loose tolerance stops at the first check, after step 9
+    sc2 = LidDriven2DSimulation(oracle_backend, 0.01, 1.0, nx=6, mu=0.1, quiet=True)
+    sc2.early_stop_tolerance = 1e9
+    sc2.solve(None)
+    assert sc2.num_steps == 9 and sc2.stopped_early
+
+
+def test_unknown_solver_and_kwarg_filtering(oracle_backend):
+    from cfd_hemodynamic_amd.scenarios.lid_driven2D import LidDriven2DSimulation
+    with pytest.raises(ImportError, match="Could not import solver"):
+        LidDriven2DSimulation("does_not_exist", 0.01, 0.1, nx=4)
+    sc = LidDriven2DSimulation(oracle_backend, 0.01, 0.02, nx=4, quiet=True, some_unused_kwarg=3)
+    assert sc.solver.nv == 25
+
+
+def test_poiseuille_steady_state(oracle_backend):
+    """Analytic known answer of the reference (unit_square.py:100-104): u = (4y(1-y), 0) with
+    mu=1: inlet profile, no-slip walls, p=0 outlet; discretisation-limited on P1."""
+    from cfd_hemodynamic_amd.mesh import locate_entities_boundary
+    from cfd_hemodynamic_amd.scenario import Scenario
+
+    class Channel(Scenario):
+        def __init__(self, solver_name):
+            self._mesh = create_unit_square(16)
+            self.quiet = True
+            super().__init__(solver_name, "unit_square", 1.0, 1.0, 0.05, 2.0, (0, 0))
+            self.setup()
+
+        mesh = property(lambda self: self._mesh)
+
+        @property
+        def bcu(self):
+            V = self.solver.V
+            ui = Function(V)
+            ui.interpolate(lambda x: np.vstack((4 * x[1] * (1 - x[1]), 0 * x[1])))
+            b1 = BoundaryCondition(ui)
+            b1.initTopological(1, locate_entities_boundary(self.mesh, 1, lambda x: np.isclose(x[0], 0)))
+            u0 = Function(V)
+            b2 = BoundaryCondition(u0)
+            b2.initTopological(1, locate_entities_boundary(self.mesh, 1, lambda x: np.isclose(x[1], 0) | np.isclose(x[1], 1)))
+            return [b1, b2]
+
+        @property
+        def bcp(self):
+            p0 = Function(self.solver.Q)
+            b = BoundaryCondition(p0)
+            b.initTopological(1, locate_entities_boundary(self.mesh, 1, lambda x: np.isclose(x[0], 1)))
+            return [b]
+
+        def initial_velocity(self, x):
+            return np.zeros((2, x.shape[1]))
+
+        def exact_velocity(self, t):
+            return lambda x: np.vstack((4 * x[1] * (1 - x[1]), 0 * x[1]))
+
+    sc = Channel(oracle_backend)
+    sc.early_stop_tolerance = 1e-6
+    sc.solve(None)
+    u_e = Function(sc.solver.V)
+    u_e.interpolate(sc.exact_velocity(0))
+    err = sc.compute_error(u_e, sc.solver.u_sol, sc.mesh)
+    assert err < 3e-2, err  # stabilised P1/P1 on 16x16, outlet do-nothing terms of stabilized_schur.py:79
+    # pressure drop of Poiseuille flow: dp/dx = -8 mu
+    p = sc.solver.p_sol.x.array.reshape(17, 17)
+    slope = (p[8, 4] - p[8, 12]) / 0.5  # interior, away from the inlet/outlet boundary terms
+    assert abs(slope - 8.0) < 0.4, slope

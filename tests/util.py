@@ -89,3 +89,19 @@ def make_ctx(case, device=0):
     for field, nodes, vals in case.bcs:
         ctx.add_dirichlet(field, nodes, vals)
     return ctx
+
+
+def load_golden(name):
+    """Golden case -> (Case-like object with raw arrays, npz dict)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+
+    class RawMesh:
+        pass
+
+    m = RawMesh()
+    m.x, m.cells = g["x"], g["cells"]
+    m.facet_cells, m.facet_local, m.facet_marker = g["facet_cells"], g["facet_local"], g["facet_marker"]
+    m.num_vertices = len(m.x)
+    bcs = [(int(g["bc%d_field" % k]), g["bc%d_nodes" % k], g["bc%d_vals" % k]) for k in range(int(g["nbc"]))]
+    case = Case(m, bcs, float(g["dt"]), float(g["rho"]), float(g["mu"]), tuple(g["f"]))
+    return case, g
