@@ -28,7 +28,7 @@ int cfdh_default_options(cfdh_options *o) {
   o->snes_rtol = 1e-8; o->snes_atol = 1e-50; o->snes_stol = 1e-8; o->snes_max_it = 100;
   o->ksp_rtol = 1e-5; o->ksp_atol = 1e-50; o->ksp_max_it = 1000; o->ksp_restart = 200;
   o->cheb_degree = 3; o->cheb_ratio = 10.0; o->schur_full = 1;
-  o->amg_smooth_degree = 2; o->amg_smooth_ratio = 8.0; o->amg_theta = 0.08; o->amg_max_coarse = 300;
+  o->amg_smooth_degree = 1; o->amg_smooth_ratio = 8.0; o->amg_theta = 0.08; o->amg_max_coarse = 300;
   o->pc_refresh = 0; o->remove_p_mean = 1; o->verbose = 0;
   return 0;
 }
@@ -49,6 +49,7 @@ int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_own
   if (!c) return cfdh_fail(nullptr, CFDH_E_NOMEM, "out of host memory");
   c->device = device;
   cfdh_default_options(&c->opt);
+  { const char *e = getenv("CFDH_NO_GRAPH"); c->use_graph = !(e && e[0] == '1'); }
   memset(&c->last_stats, 0, sizeof c->last_stats);
   int rc = 0;
   do {
@@ -75,6 +76,7 @@ void cfdh_destroy(cfdh_ctx *c) {
   for (AmgLevel *l : c->amg) delete l;
   c->amg.clear();
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  for (auto &e : c->pc_graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   hipStream_t s = c->stream;
   delete c;
@@ -101,6 +103,7 @@ int cfdh_set_options(cfdh_ctx *c, const cfdh_options *o) {
                           o->amg_smooth_ratio != c->opt.amg_smooth_ratio;
   c->opt = *o;
   if (pc_changed) c->pc_valid = false;
+  c->pc_graph_valid = false;  // degrees / schur_full are baked into the captured graph
   return 0;
 }
 

@@ -147,6 +147,10 @@ struct cfdh_ctx {
   double lmaxA = 0;
   dbuf<double> pu0, pu1, pu2, pr, pp0, pp1;  // PC work vectors
   dbuf<double> prand;                        // fixed start vector of the power iteration
+  dbuf<double> cheb_coef;                    // [1/theta, (c1,c2) per step] of the A00 Chebyshev solve
+  struct PcGraph { const double *r; double *z; hipGraphExec_t exec; };
+  std::vector<PcGraph> pc_graphs;            // one captured preconditioner application per Krylov slot
+  bool pc_graph_valid = false, capturing = false, use_graph = true;
   std::vector<AmgLevel *> amg;
   dbuf<double> coarse_inv;  // dense inverse of the coarsest operator
   int coarse_n = 0;
@@ -213,7 +217,8 @@ int k_assemble(cfdh_ctx *c, const double *xstate, int mode);  // mode 0: F only,
 int k_spmv_full(cfdh_ctx *c, const double *x, double *y);
 int k_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b, double alpha);  // y = b*? see .hip
 int k_extract_diag(cfdh_ctx *c);
-int k_cheb_a00(cfdh_ctx *c, const double *b, double *x);  // x = Cheb_k(A00) b, zero initial guess
+int k_cheb_a00(cfdh_ctx *c, const double *b, double *x);
+int k_cheb_a00_coeffs(cfdh_ctx *c);  // x = Cheb_k(A00) b, zero initial guess
 int k_csr_spmv(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mode, const double *b);  // mode 0: y=Ax, 1: y=b-Ax, 2: y+=Ax
 int k_amg_vcycle(cfdh_ctx *c, const double *b, double *x);
 int k_nullspace_test(cfdh_ctx *c, double *nrm);
@@ -228,7 +233,8 @@ int v_dot(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host
 int v_norm2(cfdh_ctx *c, int n, const double *x, double *out_host);
 int v_norminf_diff(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host);  // y may be null
 int v_sub_mean(cfdh_ctx *c, int n, double *p);  // remove the (global) mean of p[0..n)
-int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev);
+int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww);
+int v_scale_to(cfdh_ctx *c, int n, double a, const double *x, double *y);  // y = a x
 int v_multiaxpy(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, double *w);  // w -= sum h_i V_i
 int v_norm_to_dev(cfdh_ctx *c, int n, const double *w, double *out_dev);  // ||w|| (global) into device scalar
 int v_scale_inv_dev(cfdh_ctx *c, int n, const double *w, const double *nrm_dev, double *v);  // v = w / *nrm

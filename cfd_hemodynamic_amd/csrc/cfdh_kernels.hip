@@ -31,7 +31,7 @@ int k_upload_quadrature(cfdh_ctx *c) {
 
 // ---------------------------------------------------------------- profiling
 void prof_begin(cfdh_ctx *c, int kind) {
-  if (!c->prof_on) return;
+  if (!c->prof_on || c->capturing) return;
   if (c->ev_next + 2 > c->ev_pool.size()) {
     for (int i = 0; i < 64; i++) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->ev_pool.push_back(e); }
   }
@@ -41,7 +41,7 @@ void prof_begin(cfdh_ctx *c, int kind) {
   c->ev_pending.push_back(r);
 }
 void prof_end(cfdh_ctx *c, int kind) {
-  if (!c->prof_on || c->ev_pending.empty()) return;
+  if (!c->prof_on || c->capturing || c->ev_pending.empty()) return;
   (void)kind;
   (void)hipEventRecord(c->ev_pending.back().b, c->stream);
   if (c->ev_pending.size() >= 4096) prof_flush(c);
@@ -604,12 +604,17 @@ int k_extract_diag(cfdh_ctx *c) {
 
 // ---------------------------------------------------------------- Chebyshev on D^-1 A00
 // one step: r_out = r_in - A00 d_old ; d_new = c1 d_old + c2 D^-1 r_out ; x += d_new
+// FIRST: fused with the zero-guess initialisation (d_old = D^-1 r_in / theta formed while gathering,
+// x = d_old + d_new); LAST: r_out / d_new not written.  Coefficients come from device memory so that
+// a captured graph of the preconditioner survives a refresh of the spectral bound of D^-1 A00.
+template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(TPB) void cheb_a00_step_kernel(int nvo, const int *__restrict__ vptr,
                                                             const int *__restrict__ vcol, const double *__restrict__ A00,
                                                             const double *__restrict__ dinv, const double *__restrict__ rin,
                                                             double *__restrict__ rout, const double *__restrict__ dold,
-                                                            double *__restrict__ dnew, double *__restrict__ x, double c1,
-                                                            double c2) {
+                                                            double *__restrict__ dnew, double *__restrict__ x,
+                                                            const double *__restrict__ coef, int kstep) {
+  const double c1 = coef[2 * kstep], c2 = coef[2 * kstep + 1], itheta = coef[0];
   const int gid = blockIdx.x * TPB + threadIdx.x;
   const int row = gid >> 3, l = gid & 7;
   double a0 = 0, a1 = 0;
@@ -618,7 +623,13 @@ __global__ __launch_bounds__(TPB) void cheb_a00_step_kernel(int nvo, const int *
     for (int k = ks + l; k < ke; k += 8) {
       const int w = vcol[k];
       if (w >= nvo) continue;
-      const double2 xx = *(const double2 *)(dold + 2 * (size_t)w);
+      double2 xx;
+      if (FIRST) {
+        const double2 dj = *(const double2 *)(dinv + 2 * (size_t)w), rj = *(const double2 *)(rin + 2 * (size_t)w);
+        xx = make_double2(dj.x * rj.x * itheta, dj.y * rj.y * itheta);
+      } else {
+        xx = *(const double2 *)(dold + 2 * (size_t)w);
+      }
       const double2 b0 = *(const double2 *)(A00 + 4 * (size_t)k), b1 = *(const double2 *)(A00 + 4 * (size_t)k + 2);
       a0 += b0.x * xx.x + b0.y * xx.y; a1 += b1.x * xx.x + b1.y * xx.y;
     }
@@ -626,56 +637,85 @@ __global__ __launch_bounds__(TPB) void cheb_a00_step_kernel(int nvo, const int *
   a0 = group8_sum(a0); a1 = group8_sum(a1);
   if (row < nvo && l == 0) {
     const size_t o = 2 * (size_t)row;
-    const double2 ri = *(const double2 *)(rin + o), di = *(const double2 *)(dinv + o), dd = *(const double2 *)(dold + o);
-    double2 xo = *(double2 *)(x + o);
+    const double2 ri = *(const double2 *)(rin + o), di = *(const double2 *)(dinv + o);
+    double2 dd;
+    if (FIRST) dd = make_double2(di.x * ri.x * itheta, di.y * ri.y * itheta);
+    else dd = *(const double2 *)(dold + o);
     const double r0 = ri.x - a0, r1 = ri.y - a1;
     const double n0 = c1 * dd.x + c2 * di.x * r0, n1 = c1 * dd.y + c2 * di.y * r1;
-    *(double2 *)(rout + o) = make_double2(r0, r1);
-    *(double2 *)(dnew + o) = make_double2(n0, n1);
-    xo.x += n0; xo.y += n1;
-    *(double2 *)(x + o) = xo;
+    if (!LAST) {
+      *(double2 *)(rout + o) = make_double2(r0, r1);
+      *(double2 *)(dnew + o) = make_double2(n0, n1);
+    }
+    if (FIRST) {
+      *(double2 *)(x + o) = make_double2(dd.x + n0, dd.y + n1);
+    } else {
+      double2 xo = *(double2 *)(x + o);
+      xo.x += n0; xo.y += n1;
+      *(double2 *)(x + o) = xo;
+    }
   }
 }
 
 // d0 = D^-1 b / theta ; x = d0
 __global__ __launch_bounds__(TPB) void cheb_init_kernel(int n, const double *__restrict__ dinv, const double *__restrict__ b,
                                                         double *__restrict__ d0, double *__restrict__ x, double itheta,
-                                                        int accumulate) {
+                                                        int accumulate, const double *__restrict__ coef) {
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
+  if (coef) itheta = coef[0];
   const double v = dinv[i] * b[i] * itheta;
   d0[i] = v;
   x[i] = accumulate ? x[i] + v : v;
 }
 
-// x = Cheb_k(D^-1 A00) b with zero initial guess; lambda in [lmax/ratio, lmax]
-int k_cheb_a00(cfdh_ctx *c, const double *b, double *x) {
-  const int nu = 2 * c->nvo;
+// Chebyshev coefficients of the A00 solve -> device (called whenever lmaxA changes)
+int k_cheb_a00_coeffs(cfdh_ctx *c) {
   const double lmax = c->lmaxA, lmin = lmax / c->opt.cheb_ratio;
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
   const double sigma = theta / delta;
   double rho = 1.0 / sigma;
-  double *dold = c->pu1.p, *dnew = c->pu2.p, *r = c->pr.p;
-  hipLaunchKernelGGL(cheb_init_kernel, dim3((nu + TPB - 1) / TPB), dim3(TPB), 0, c->stream, nu, c->dinvA.p, b, dold, x,
-                     1.0 / theta, 0);
-  const long long nthreads = 8ll * c->nvo;
-  dim3 grid((unsigned)((nthreads + TPB - 1) / TPB));
-  for (int k = 1; k < c->opt.cheb_degree; k++) {
+  std::vector<double> h(2 * 16 + 2, 0.0);
+  h[0] = 1.0 / theta;
+  for (int k = 1; k < c->opt.cheb_degree && k < 16; k++) {
     const double rho_new = 1.0 / (2.0 * sigma - rho);
-    const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    h[2 * k] = rho_new * rho; h[2 * k + 1] = 2.0 * rho_new / delta;
+    rho = rho_new;
+  }
+  HIPCHK(c, c->cheb_coef.alloc(h.size()));
+  HIPCHK(c, hipMemcpyAsync(c->cheb_coef.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // h is a host temporary
+  return 0;
+}
+
+// x = Cheb_k(D^-1 A00) b with zero initial guess; lambda in [lmax/ratio, lmax]
+int k_cheb_a00(cfdh_ctx *c, const double *b, double *x) {
+  const int nu = 2 * c->nvo, deg = c->opt.cheb_degree;
+  double *dold = c->pu1.p, *dnew = c->pu2.p, *r = c->pr.p;
+  if (deg == 1) {
+    hipLaunchKernelGGL(cheb_init_kernel, dim3((nu + TPB - 1) / TPB), dim3(TPB), 0, c->stream, nu, c->dinvA.p, b, dold, x,
+                       0.0, 0, c->cheb_coef.p);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  const long long nthreads = 8ll * c->nvo;
+  dim3 grid((unsigned)((nthreads + TPB - 1) / TPB)), block(TPB);
+  for (int k = 1; k < deg; k++) {
+    const bool first = (k == 1), last = (k == deg - 1);
     prof_begin(c, 3);
-    hipLaunchKernelGGL(cheb_a00_step_kernel, grid, dim3(TPB), 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A00.p,
-                       c->dinvA.p, (k == 1) ? b : r, r, dold, dnew, x, c1, c2);
+#define LAUNCH_A00(F, LST) hipLaunchKernelGGL((cheb_a00_step_kernel<F, LST>), grid, block, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A00.p, c->dinvA.p, first ? b : r, r, dold, dnew, x, c->cheb_coef.p, k)
+    if (first) { if (last) LAUNCH_A00(true, true); else LAUNCH_A00(true, false); }
+    else { if (last) LAUNCH_A00(false, true); else LAUNCH_A00(false, false); }
+#undef LAUNCH_A00
     prof_end(c, 3);
     std::swap(dold, dnew);
-    rho = rho_new;
   }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 
 // ---------------------------------------------------------------- scalar CSR (AMG levels)
-// MODE 0: y = A x; 1: y = b - A x; 2: y += A x
+// MODE 0: y = A x; 1: y = b - A x; 2: y += A x; 3: y = b + A x
 template <int MODE>
 __global__ __launch_bounds__(TPB) void csr_spmv_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                        const double *__restrict__ val, const double *__restrict__ x,
@@ -691,7 +731,8 @@ __global__ __launch_bounds__(TPB) void csr_spmv_kernel(int n, const int *__restr
   if (row < n && l == 0) {
     if (MODE == 0) y[row] = a;
     else if (MODE == 1) y[row] = b[row] - a;
-    else y[row] += a;
+    else if (MODE == 2) y[row] += a;
+    else y[row] = b[row] + a;
   }
 }
 
@@ -700,29 +741,71 @@ int k_csr_spmv(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mod
   dim3 grid((unsigned)((nthreads + TPB - 1) / TPB)), block(TPB);
   if (mode == 0) hipLaunchKernelGGL(csr_spmv_kernel<0>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
   else if (mode == 1) hipLaunchKernelGGL(csr_spmv_kernel<1>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
-  else hipLaunchKernelGGL(csr_spmv_kernel<2>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
+  else if (mode == 2) hipLaunchKernelGGL(csr_spmv_kernel<2>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
+  else hipLaunchKernelGGL(csr_spmv_kernel<3>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 
+// One Chebyshev step on a scalar CSR level:
+//   r_out = r_in - A d_old ; d_new = c1 d_old + c2 D^-1 r_out ; x (+)= ...
+// MODE 0: x += d_new.
+// MODE 1: first step of a zero-guess smoothing fused with its initialisation: d_old = D^-1 r_in / theta
+//         is formed on the fly while gathering (never stored), x = d_old + d_new.
+// MODE 2: first step after csr_resid_init_kernel (which left d_old = D^-1 r / theta unapplied): x += d_old + d_new.
+// LAST: r_out / d_new are not needed any more and are not written.
+template <int MODE, bool LAST>
 __global__ __launch_bounds__(TPB) void cheb_csr_step_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                             const double *__restrict__ val, const double *__restrict__ dinv,
                                                             const double *__restrict__ rin, double *__restrict__ rout,
                                                             const double *__restrict__ dold, double *__restrict__ dnew,
-                                                            double *__restrict__ x, double c1, double c2) {
+                                                            double *__restrict__ x, double c1, double c2, double itheta) {
   const int gid = blockIdx.x * TPB + threadIdx.x;
   const int row = gid >> 3, l = gid & 7;
   double a = 0;
   if (row < n) {
     const int ks = rowptr[row], ke = rowptr[row + 1];
-    for (int k = ks + l; k < ke; k += 8) a += val[k] * dold[col[k]];
+    for (int k = ks + l; k < ke; k += 8) {
+      const int j = col[k];
+      a += val[k] * (MODE == 1 ? dinv[j] * rin[j] * itheta : dold[j]);
+    }
   }
   a = group8_sum(a);
   if (row < n && l == 0) {
-    const double r = rin[row] - a;
-    const double dn = c1 * dold[row] + c2 * dinv[row] * r;
-    rout[row] = r; dnew[row] = dn; x[row] += dn;
+    const double di = dinv[row], ri = rin[row];
+    const double dd = (MODE == 1) ? di * ri * itheta : dold[row];
+    const double r = ri - a;
+    const double dn = c1 * dd + c2 * di * r;
+    if (!LAST) { rout[row] = r; dnew[row] = dn; }
+    if (MODE == 0) x[row] += dn;
+    else if (MODE == 1) x[row] = dd + dn;
+    else x[row] += dd + dn;
   }
+}
+
+// r = b - A x ; d0 = D^-1 r / theta   (residual of a non-zero guess fused with the Chebyshev initialisation)
+__global__ __launch_bounds__(TPB) void csr_resid_init_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                             const double *__restrict__ val, const double *__restrict__ dinv,
+                                                             const double *__restrict__ b, const double *__restrict__ x,
+                                                             double *__restrict__ r, double *__restrict__ d0, double itheta) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  double a = 0;
+  if (row < n) {
+    const int ks = rowptr[row], ke = rowptr[row + 1];
+    for (int k = ks + l; k < ke; k += 8) a += val[k] * x[col[k]];
+  }
+  a = group8_sum(a);
+  if (row < n && l == 0) {
+    const double rr = b[row] - a;
+    r[row] = rr;
+    d0[row] = dinv[row] * rr * itheta;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void add_kernel(int n, const double *__restrict__ d, double *__restrict__ x) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i < n) x[i] += d[i];
 }
 
 // Chebyshev smoothing on level L: zero_guess ? x = S b : x <- x + S (b - A x)
@@ -732,17 +815,33 @@ static int amg_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, bool
   double rho = 1.0 / sigma;
   double *dold = L->d0.p, *dnew = L->d1.p, *r = L->r.p;
   const double *rin = b;
-  if (!zero_guess) { CHK(k_csr_spmv(c, L->A, x, r, 1, b)); rin = r; }
-  hipLaunchKernelGGL(cheb_init_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, L->dinv.p, rin, dold, x,
-                     1.0 / theta, zero_guess ? 0 : 1);
+  const double itheta = 1.0 / theta;
   const long long nthreads = 8ll * n;
-  dim3 grid((unsigned)((nthreads + TPB - 1) / TPB));
+  dim3 grid((unsigned)((nthreads + TPB - 1) / TPB)), block(TPB);
+  const int *rp = L->A.rowptr.p, *cl = L->A.col.p;
+  const double *vl = L->A.val.p, *di = L->dinv.p;
+  if (deg == 1) {  // plain damped Jacobi
+    if (!zero_guess) { CHK(k_csr_spmv(c, L->A, x, r, 1, b)); rin = r; }
+    hipLaunchKernelGGL(cheb_init_kernel, dim3((n + TPB - 1) / TPB), block, 0, c->stream, n, di, rin, dold, x, itheta,
+                       zero_guess ? 0 : 1, (const double *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  if (!zero_guess) {
+    hipLaunchKernelGGL(csr_resid_init_kernel, grid, block, 0, c->stream, n, rp, cl, vl, di, b, x, r, dold, itheta);
+    rin = r;
+  }
   for (int k = 1; k < deg; k++) {
     const double rho_new = 1.0 / (2.0 * sigma - rho);
     const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    const bool last = (k == deg - 1);
+    const int mode = (k == 1) ? (zero_guess ? 1 : 2) : 0;
     if (L == c->amg[0]) prof_begin(c, 4);
-    hipLaunchKernelGGL(cheb_csr_step_kernel, grid, dim3(TPB), 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p,
-                       L->dinv.p, rin, r, dold, dnew, x, c1, c2);
+#define LAUNCH_STEP(M, LST) hipLaunchKernelGGL((cheb_csr_step_kernel<M, LST>), grid, block, 0, c->stream, n, rp, cl, vl, di, rin, r, dold, dnew, x, c1, c2, itheta)
+    if (mode == 1) { if (last) LAUNCH_STEP(1, true); else LAUNCH_STEP(1, false); }
+    else if (mode == 2) { if (last) LAUNCH_STEP(2, true); else LAUNCH_STEP(2, false); }
+    else { if (last) LAUNCH_STEP(0, true); else LAUNCH_STEP(0, false); }
+#undef LAUNCH_STEP
     if (L == c->amg[0]) prof_end(c, 4);
     rin = r;
     std::swap(dold, dnew);
@@ -762,6 +861,42 @@ __global__ __launch_bounds__(64) void dense_mv_kernel(int n, const double *__res
   if (l == 0) y[row] = a;
 }
 
+// damped-Jacobi V-cycle building blocks (amg_smooth_degree == 1): each touches the level matrix once
+//   pre : xa = D^-1 b / theta (formed while gathering) ; r = b - A xa
+//   post: x_out = x_in + D^-1 (b - A x_in) / theta
+__global__ __launch_bounds__(TPB) void jacobi_pre_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                         const double *__restrict__ val, const double *__restrict__ dinv,
+                                                         const double *__restrict__ b, double *__restrict__ xa,
+                                                         double *__restrict__ r, double itheta) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  double a = 0;
+  if (row < n) {
+    const int ks = rowptr[row], ke = rowptr[row + 1];
+    for (int k = ks + l; k < ke; k += 8) { const int j = col[k]; a += val[k] * (dinv[j] * b[j] * itheta); }
+  }
+  a = group8_sum(a);
+  if (row < n && l == 0) {
+    const double bi = b[row];
+    xa[row] = dinv[row] * bi * itheta;
+    r[row] = bi - a;
+  }
+}
+__global__ __launch_bounds__(TPB) void jacobi_post_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                          const double *__restrict__ val, const double *__restrict__ dinv,
+                                                          const double *__restrict__ b, const double *__restrict__ xin,
+                                                          double *__restrict__ xout, double itheta) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  double a = 0;
+  if (row < n) {
+    const int ks = rowptr[row], ke = rowptr[row + 1];
+    for (int k = ks + l; k < ke; k += 8) a += val[k] * xin[col[k]];
+  }
+  a = group8_sum(a);
+  if (row < n && l == 0) xout[row] = xin[row] + dinv[row] * (b[row] - a) * itheta;
+}
+
 static int amg_cycle(cfdh_ctx *c, size_t lev, const double *b, double *x) {
   AmgLevel *L = c->amg[lev];
   if (lev + 1 == c->amg.size()) {
@@ -770,6 +905,24 @@ static int amg_cycle(cfdh_ctx *c, size_t lev, const double *b, double *x) {
     return 0;
   }
   AmgLevel *N = c->amg[lev + 1];
+  if (c->opt.amg_smooth_degree == 1) {
+    const int n = L->n;
+    const double itheta = 2.0 / (L->lmax + L->lmin);
+    dim3 grid((unsigned)((8ll * n + TPB - 1) / TPB)), block(TPB);
+    if (lev == 0) prof_begin(c, 4);
+    hipLaunchKernelGGL(jacobi_pre_kernel, grid, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->dinv.p, b,
+                       L->d0.p, L->r.p, itheta);
+    if (lev == 0) prof_end(c, 4);
+    CHK(k_csr_spmv(c, L->R, L->r.p, N->b.p, 0, nullptr));     // b_c = R r
+    CHK(amg_cycle(c, lev + 1, N->b.p, N->x.p));
+    CHK(k_csr_spmv(c, L->P, N->x.p, L->d1.p, 3, L->d0.p));    // x1 = xa + P x_c
+    if (lev == 0) prof_begin(c, 4);
+    hipLaunchKernelGGL(jacobi_post_kernel, grid, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->dinv.p, b,
+                       L->d1.p, x, itheta);
+    if (lev == 0) prof_end(c, 4);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   CHK(amg_smooth(c, L, b, x, true));
   CHK(k_csr_spmv(c, L->A, x, L->r.p, 1, b));     // r = b - A x
   CHK(k_csr_spmv(c, L->R, L->r.p, N->b.p, 0, nullptr));  // b_c = R r
@@ -849,7 +1002,7 @@ __global__ __launch_bounds__(TPB) void reduce_final_kernel(int nblk, int stride,
   double a = 0;
   for (int i = threadIdx.x; i < nblk; i += TPB) a = (OP == 1) ? fmax(a, pp[i]) : a + pp[i];
   a = (OP == 1) ? block_max(a, sh) : block_sum(a, sh);
-  if (threadIdx.x == 0) out[blockIdx.x] = a;
+  if (threadIdx.x == 0) out[blockIdx.x] = (OP == 2) ? sqrt(a) : a;
 }
 
 static int read_scalars(cfdh_ctx *c, const double *dev, int n, double *host) {
@@ -921,35 +1074,73 @@ int v_sub_mean(cfdh_ctx *c, int n, double *p) {
 }
 
 // ---- Gram-Schmidt building blocks: h_i = V_i . w for i < nvec (V column-major, leading dim ld)
+#define MD_G 8     // vectors reduced together: one pass over the w chunk feeds 8 dot products
+#define MD_NB 1024 // blocks: 4 per CU, each owning a contiguous chunk (w stays L1/L2 resident across groups)
 __global__ __launch_bounds__(TPB) void multidot_kernel(int n, const double *__restrict__ V, size_t ld, int nvec,
-                                                       const double *__restrict__ w, double *__restrict__ partial, int nblk) {
-  __shared__ double sh[4];
-  // each block owns a contiguous chunk so that w stays in registers across the nvec passes
-  const int per = (n + nblk - 1) / nblk;
+                                                       const double *__restrict__ w, double *__restrict__ partial, int nblk,
+                                                       int with_ww) {
+  __shared__ double sh[4][MD_G];
+  const int nout = nvec + with_ww;
+  const int per = (((n + nblk - 1) / nblk) + 1) & ~1;
   const int lo = blockIdx.x * per, hi = min(n, lo + per);
-  for (int v = 0; v < nvec; v++) {
-    const double *vv = V + (size_t)v * ld;
-    double a = 0;
-    for (int i = lo + threadIdx.x; i < hi; i += TPB) a += vv[i] * w[i];
-    a = block_sum(a, sh);
-    if (threadIdx.x == 0) partial[(size_t)v * nblk + blockIdx.x] = a;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int g0 = 0; g0 < nout; g0 += MD_G) {
+    const double *ptr[MD_G];
+    double acc[MD_G];
+#pragma unroll
+    for (int q = 0; q < MD_G; q++) {
+      const int v = g0 + q;
+      ptr[q] = (v < nvec) ? V + (size_t)v * ld : w;  // v == nvec: w.w ; v > nvec: dummy (discarded)
+      acc[q] = 0.0;
+    }
+    for (int i = lo + threadIdx.x; i < hi; i += TPB) {
+      const double wi = w[i];
+#pragma unroll
+      for (int q = 0; q < MD_G; q++) acc[q] += ptr[q][i] * wi;
+    }
+#pragma unroll
+    for (int q = 0; q < MD_G; q++) {
+      const double r = wave_sum(acc[q]);
+      if (lane == 0) sh[wv][q] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < MD_G && g0 + (int)threadIdx.x < nout)
+      partial[(size_t)(g0 + threadIdx.x) * nblk + blockIdx.x] =
+          (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    __syncthreads();
   }
 }
-int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev) {
-  const int nb = 256;
-  if ((size_t)nvec * nb > c->red_partial.n) return cfdh_fail(c, CFDH_E_STATE, "multidot workspace too small");
-  hipLaunchKernelGGL(multidot_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, w, c->red_partial.p, nb);
-  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(nvec), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, h_dev);
+// h_dev[0..nvec) = V^T w (and h_dev[nvec] = w.w when with_ww), reduced over all ranks
+int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww) {
+  const int nb = MD_NB, nout = nvec + (with_ww ? 1 : 0);
+  if ((size_t)nout * nb > c->red_partial.n) return cfdh_fail(c, CFDH_E_STATE, "multidot workspace too small");
+  hipLaunchKernelGGL(multidot_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, w, c->red_partial.p, nb,
+                     with_ww ? 1 : 0);
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(nout), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, h_dev);
   HIPCHK(c, hipGetLastError());
-  return comm_allreduce_dev(c, h_dev, nvec, 0);
+  return comm_allreduce_dev(c, h_dev, nout, 0);
+}
+__global__ __launch_bounds__(TPB) void scale_to_kernel(int n, double a, const double *__restrict__ x, double *__restrict__ y) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) y[i] = a * x[i];
+}
+int v_scale_to(cfdh_ctx *c, int n, double a, const double *x, double *y) {
+  hipLaunchKernelGGL(scale_to_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, a, x, y);
+  HIPCHK(c, hipGetLastError());
+  return 0;
 }
 // w -= sum_i h_i V_i
 __global__ __launch_bounds__(TPB) void multiaxpy_kernel(int n, const double *__restrict__ V, size_t ld, int nvec,
                                                         const double *__restrict__ h, double *__restrict__ w, double sign) {
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-    double a = w[i];
-    for (int v = 0; v < nvec; v++) a += sign * h[v] * V[(size_t)v * ld + i];
-    w[i] = a;
+    double a0 = w[i], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int v = 0;
+    for (; v + 4 <= nvec; v += 4) {  // four independent streams in flight
+      const double x0 = V[(size_t)v * ld + i], x1 = V[(size_t)(v + 1) * ld + i], x2 = V[(size_t)(v + 2) * ld + i],
+                   x3 = V[(size_t)(v + 3) * ld + i];
+      a0 += sign * h[v] * x0; a1 += sign * h[v + 1] * x1; a2 += sign * h[v + 2] * x2; a3 += sign * h[v + 3] * x3;
+    }
+    for (; v < nvec; v++) a0 += sign * h[v] * V[(size_t)v * ld + i];
+    w[i] = (a0 + a1) + (a2 + a3);
   }
 }
 int v_multiaxpy(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, double *w) {

@@ -1139,7 +1139,7 @@ void orc_default_opts(orc_opts *o) {
   o->ksp_rtol = 1e-5; o->ksp_atol = 1e-50; o->ksp_max_it = 1000; o->ksp_restart = 200;
   o->sub_rtol = 1e-5; o->sub_max_it = 10000; o->sub_restart = 30;
   o->remove_p_mean = 1; o->verbose = 0;
-  o->pc_kind = 0; o->cheb_degree = 3; o->cheb_ratio = 10.0; o->amg_smooth_degree = 2; o->amg_smooth_ratio = 8.0;
+  o->pc_kind = 0; o->cheb_degree = 3; o->cheb_ratio = 10.0; o->amg_smooth_degree = 1; o->amg_smooth_ratio = 8.0;
   o->amg_theta = 0.08; o->amg_max_coarse = 300;
 }
 

@@ -274,4 +274,4 @@ def test_full_size_steps_converge_and_are_consistent(big):
         res.append((ctx.functional(0, 5), ctx.functional(2), st.fnorm))
     assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
     assert abs(res[0][1] - res[1][1]) <= 1e-7 * res[1][1]
-    assert res[1][2] < 1e-9
+    assert res[1][2] < 1e-8  # |F| after the tight solve, from |F0| ~ 3e2
