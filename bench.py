@@ -50,8 +50,8 @@ def kernel_bytes(ctx):
         2: ("tau_moments", 12.0 * nc + 32.0 * nvo + 64.0 * nc),
         # Chebyshev step on A00: values 32 B + column 4 B per entry; rowptr 4 + 7 vectors x 16 B per row
         3: ("cheb_step_A00", 36.0 * nnzv + 116.0 * nvo),
-        # Chebyshev step on Sp (scalar CSR): 12 B per entry; rowptr 4 + 7 vectors x 8 B per row
-        4: ("cheb_step_Sp", 12.0 * spnnz + 60.0 * nvo),
+        # level-0 smoother sweep on Sp (scalar CSR): 12 B per entry; rowptr 4 + 5 vectors x 8 B per row
+        4: ("cheb_step_Sp", 12.0 * spnnz + 44.0 * nvo),
     }
 
 
@@ -161,7 +161,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(d["kernel"])
+                traffic = json.load(open(pmc)).get("per_launch_bytes", {}).get(d["kernel"])
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "kernel": d["kernel"], "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

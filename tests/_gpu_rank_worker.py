@@ -1,0 +1,37 @@
+"""Worker of tests/test_gpu_multirank.py: one rank of an N-process job whose ranks all use GPU 0
+(the test box has one GPU), exchanging halos and dot products through the host-staged gloo path.
+Same kernels, same partition/halo plan and the same Krylov code as the RCCL path; only the
+transport of the two exchanges differs."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from cfd_hemodynamic_amd.parallel import PartComm  # noqa: E402
+from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    out = sys.argv[1]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = PartComm(rank, world, "host")
+    tight = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
+    sc = DFG1Benchmark("stabilized_schur", 0.01, 0.05, m=16, quiet=True, device=0, comm=comm, options=tight)
+    sc.solve(None)
+    u = sc.solver.u_sol.x.array.copy()   # gathers the owned slices of every rank
+    p = sc.solver.p_sol.x.array.copy()
+    if rank == 0:
+        np.savez(out, u=u, p=p, drag=sc.drag, lift=sc.lift, norm_v=sc.norm_v, norm_p=sc.norm_p, steps=sc.num_steps,
+                 krylov=sum(s.krylov_its for _, s in sc.step_stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
