@@ -12,7 +12,9 @@
 #include "cfdh.h"
 
 #define CFDH_MAX_INC 256   // incidences (= threads) per assembly workgroup
-#define CFDH_MAX_SLOTS 448 // vertex-graph slots per assembly workgroup (LDS 72 B each)
+#define CFDH_MAX_SLOTS 320 // vertex-graph slots per assembly workgroup (LDS 72 B each)
+#define CFDH_MAX_BV 192    // distinct vertices staged in LDS per assembly workgroup (8-bit local index)
+#define CFDH_MAX_BC 192    // distinct cells staged in LDS per assembly workgroup
 #define CFDH_MAX_ROWS 128  // rows per assembly workgroup
 
 template <class T>
@@ -114,6 +116,9 @@ struct cfdh_ctx {
   dbuf<unsigned> inc_rank;   // 3 x 8 bit: accumulation round of block b'
   dbuf<int> blk_row;         // [nblk+1]
   dbuf<int> blk_inc;         // [nblk+1] first incidence of the block
+  dbuf<int> blk_vptr, blk_vlist;  // per-block list of the vertices its cells touch
+  dbuf<int> blk_cptr, blk_clist;  // per-block list of distinct cells
+  dbuf<unsigned> inc_loc;    // lcell | lv0<<8 | lv1<<16 | lv2<<24: block-local indices, rotated
   dbuf<int> blk_maxrank;     // [nblk]
 
   // Dirichlet data (host master copies in internal numbering)

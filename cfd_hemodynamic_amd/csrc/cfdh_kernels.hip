@@ -172,8 +172,8 @@ int k_moments(cfdh_ctx *c) {
 // ---------------------------------------------------------------- fused assembly
 struct AsmArgs {
   const double *coords, *mom, *x, *un, *bcval, *bcmult;
-  const int *cells, *vptr, *vdiag, *inc_cell, *inc_row, *blk_row, *blk_inc, *blk_maxrank;
-  const unsigned *inc_slot, *inc_rank;
+  const int *vptr, *vdiag, *inc_cell, *blk_row, *blk_inc, *blk_maxrank, *blk_vptr, *blk_vlist, *blk_cptr, *blk_clist;
+  const unsigned *inc_slot, *inc_rank, *inc_loc;
   const unsigned char *cflag, *bcflag;
   double *A00, *A01, *A10, *A11, *F;
   int nvo;
@@ -181,8 +181,14 @@ struct AsmArgs {
 };
 
 // MODE 0: residual only; 1: residual + Jacobian; 2: residual with lifting (Jacobian in registers only)
-template <int MODE>
-__global__ __launch_bounds__(CFDH_MAX_INC) void asm_kernel(AsmArgs p) {
+//
+// Workgroup = a run of whole matrix rows.  Prologue: the vertices and cells the block touches
+// (compact per-block lists built at setup) are loaded ONCE, coalesced, into LDS -- nodal
+// coordinates, iterate, u_prev, Dirichlet flags, and the 64-B tau-moment records; every lane then
+// gathers its element from LDS only (a per-lane gather from global memory costs one L1 line
+// per lane per load and made the first version of this kernel L1/TA-bound).
+template <int MODE, int OCC = 3, bool ATOMIC = false>
+__global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
   constexpr bool JAC = (MODE != 0);
   constexpr bool WJ = (MODE == 1);
   __shared__ double sA00[WJ ? CFDH_MAX_SLOTS * 4 : 1];
@@ -190,6 +196,13 @@ __global__ __launch_bounds__(CFDH_MAX_INC) void asm_kernel(AsmArgs p) {
   __shared__ double sA10[WJ ? CFDH_MAX_SLOTS * 2 : 1];
   __shared__ double sA11[WJ ? CFDH_MAX_SLOTS : 1];
   __shared__ double sF[CFDH_MAX_ROWS * 3];
+  __shared__ double2 sX[CFDH_MAX_BV], sU[CFDH_MAX_BV], sUn[CFDH_MAX_BV];
+  __shared__ double sP[CFDH_MAX_BV];
+  __shared__ int sVid[CFDH_MAX_BV];
+  __shared__ unsigned char sFl[CFDH_MAX_BV];
+  __shared__ double2 sMom[CFDH_MAX_BC * 4];
+  __shared__ unsigned char sCf[CFDH_MAX_BC];
+  __shared__ int sRow[CFDH_MAX_ROWS + 1];
   const int t = threadIdx.x, blk = blockIdx.x;
   const int row0 = p.blk_row[blk], row1 = p.blk_row[blk + 1];
   const int inc0 = p.blk_inc[blk], ninc = p.blk_inc[blk + 1] - inc0;
@@ -197,12 +210,33 @@ __global__ __launch_bounds__(CFDH_MAX_INC) void asm_kernel(AsmArgs p) {
   const int nrows = row1 - row0;
   const int maxr = p.blk_maxrank[blk];
   const int nvo = p.nvo;
+  {
+    const int v0 = p.blk_vptr[blk], nvl = p.blk_vptr[blk + 1] - v0;
+    for (int i = t; i < nvl; i += CFDH_MAX_INC) {
+      const int vid = p.blk_vlist[v0 + i];
+      const int uo = uoff(vid, nvo), po = poff(vid, nvo);
+      sVid[i] = vid;
+      sX[i] = *(const double2 *)(p.coords + 2 * (size_t)vid);
+      sU[i] = make_double2(p.x[uo], p.x[uo + 1]);
+      sP[i] = p.x[po];
+      sUn[i] = make_double2(p.un[uo], p.un[uo + 1]);
+      sFl[i] = p.bcflag[vid];
+    }
+    const int c0 = p.blk_cptr[blk], ncl = p.blk_cptr[blk + 1] - c0;
+    for (int i = t; i < 4 * ncl; i += CFDH_MAX_INC) {  // 4 x 16 B per cell record, consecutive lanes
+      const int cid = p.blk_clist[c0 + (i >> 2)];
+      sMom[i] = *(const double2 *)(p.mom + 8 * (size_t)cid + 2 * (i & 3));
+    }
+    for (int i = t; i < ncl; i += CFDH_MAX_INC) sCf[i] = p.cflag[p.blk_clist[c0 + i]];
+    for (int i = t; i <= nrows; i += CFDH_MAX_INC) sRow[i] = p.vptr[row0 + i] - s0;
+  }
   if (WJ) {
     for (int i = t; i < nslots * 4; i += CFDH_MAX_INC) sA00[i] = 0.0;
     for (int i = t; i < nslots * 2; i += CFDH_MAX_INC) { sA01[i] = 0.0; sA10[i] = 0.0; }
     for (int i = t; i < nslots; i += CFDH_MAX_INC) sA11[i] = 0.0;
   }
   for (int i = t; i < nrows * 3; i += CFDH_MAX_INC) sF[i] = 0.0;
+  __syncthreads();
 
   const bool active = t < ninc;
   double Fr[3] = {0, 0, 0};
@@ -210,25 +244,21 @@ __global__ __launch_bounds__(CFDH_MAX_INC) void asm_kernel(AsmArgs p) {
   int sl[3] = {0, 0, 0}, rk[3] = {0, 0, 0}, rloc = 0;
   if (active) {
     const int k = inc0 + t;
-    const int ce = p.inc_cell[k];
-    const int e = ce >> 2, a = ce & 3;
-    const int row = p.inc_row[k];
-    const unsigned slots = p.inc_slot[k], ranks = p.inc_rank[k];
-    rloc = row - row0;
-    const int sbase = p.vptr[row] - s0;
+    const int a = p.inc_cell[k] & 3;
+    const unsigned slots = p.inc_slot[k], ranks = p.inc_rank[k], loc = p.inc_loc[k];
+    const int lc = loc & 255;
+    const int lv[3] = {(int)((loc >> 8) & 255), (int)((loc >> 16) & 255), (int)((loc >> 24) & 255)};
+    const int vv[3] = {sVid[lv[0]], sVid[lv[1]], sVid[lv[2]]};
+    const int v0 = vv[0], v1 = vv[1], v2 = vv[2];
+    rloc = v0 - row0;
+    const int sbase = sRow[rloc];
     sl[0] = sbase + (slots & 255); sl[1] = sbase + ((slots >> 8) & 255); sl[2] = sbase + ((slots >> 16) & 255);
     rk[0] = ranks & 255; rk[1] = (ranks >> 8) & 255; rk[2] = (ranks >> 16) & 255;
-    const int c0 = p.cells[3 * e], c1 = p.cells[3 * e + 1], c2 = p.cells[3 * e + 2];
-    const int v0 = a == 0 ? c0 : (a == 1 ? c1 : c2);
-    const int v1 = a == 0 ? c1 : (a == 1 ? c2 : c0);
-    const int v2 = a == 0 ? c2 : (a == 1 ? c0 : c1);
-    const int vv[3] = {v0, v1, v2};
-    unsigned cf = p.cflag[e];
+    unsigned cf = sCf[lc];
     cf = ((cf >> a) | (cf << (3 - a))) & 7u;
     // moments, rotated
-    const double4 q0 = *(const double4 *)(p.mom + 8 * (size_t)e);
-    const double4 q1 = *(const double4 *)(p.mom + 8 * (size_t)e + 4);
-    const double o00 = q0.x, o01 = q0.y, o02 = q0.z, o11 = q0.w, o12 = q1.x, o22 = q1.y, Lm = q1.z;
+    const double2 m0 = sMom[4 * lc], m1 = sMom[4 * lc + 1], m2 = sMom[4 * lc + 2], m3 = sMom[4 * lc + 3];
+    const double o00 = m0.x, o01 = m0.y, o02 = m1.x, o11 = m1.y, o12 = m2.x, o22 = m2.y, Lm = m3.x;
     double M[3][3];
     M[0][0] = a == 0 ? o00 : (a == 1 ? o11 : o22);
     M[1][1] = a == 0 ? o11 : (a == 1 ? o22 : o00);
@@ -236,15 +266,14 @@ __global__ __launch_bounds__(CFDH_MAX_INC) void asm_kernel(AsmArgs p) {
     M[0][1] = M[1][0] = a == 0 ? o01 : (a == 1 ? o12 : o02);
     M[0][2] = M[2][0] = a == 0 ? o02 : (a == 1 ? o01 : o12);
     M[1][2] = M[2][1] = a == 0 ? o12 : (a == 1 ? o02 : o01);
-    // geometry
+    // geometry and nodal values from LDS
     double X[3][2], ue[3][2], une[3][2], pe[3];
 #pragma unroll
     for (int b = 0; b < 3; b++) {
-      const double2 xx = *(const double2 *)(p.coords + 2 * vv[b]);
+      const double2 xx = sX[lv[b]], uu = sU[lv[b]], un2 = sUn[lv[b]];
       X[b][0] = xx.x; X[b][1] = xx.y;
-      const int uo = uoff(vv[b], nvo), po = poff(vv[b], nvo);
-      ue[b][0] = p.x[uo]; ue[b][1] = p.x[uo + 1]; pe[b] = p.x[po];
-      une[b][0] = p.un[uo]; une[b][1] = p.un[uo + 1];
+      ue[b][0] = uu.x; ue[b][1] = uu.y; pe[b] = sP[lv[b]];
+      une[b][0] = un2.x; une[b][1] = un2.y;
     }
     const double det = (X[1][0] - X[0][0]) * (X[2][1] - X[0][1]) - (X[1][1] - X[0][1]) * (X[2][0] - X[0][0]);
     const double idet = 1.0 / det;
@@ -375,7 +404,8 @@ __global__ __launch_bounds__(CFDH_MAX_INC) void asm_kernel(AsmArgs p) {
       }
     }
     // ---- Dirichlet: lifting F += J[:,bc](g - x), zero bc columns and rows
-    const unsigned fl0 = p.bcflag[v0], fl1 = p.bcflag[v1], fl2 = p.bcflag[v2];
+    const unsigned fl0 = sFl[lv[0]], fl1 = sFl[lv[1]], fl2 = sFl[lv[2]];
+    (void)v1; (void)v2;
     if (fl0 | fl1 | fl2) {
       const unsigned flb[3] = {fl0, fl1, fl2};
 #pragma unroll
@@ -418,7 +448,24 @@ __global__ __launch_bounds__(CFDH_MAX_INC) void asm_kernel(AsmArgs p) {
   }
   __syncthreads();
   // ---- deterministic accumulation: in round r only the r-th contribution of a slot adds
-  for (int r = 0; r < maxr; r++) {
+  if (ATOMIC) {  // experiment: unordered LDS atomics (not bitwise reproducible)
+    if (active) {
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        if (WJ) {
+          const int s = sl[b];
+          atomicAdd(&sA00[4 * s + 0], J00[b][0][0]); atomicAdd(&sA00[4 * s + 1], J00[b][0][1]);
+          atomicAdd(&sA00[4 * s + 2], J00[b][1][0]); atomicAdd(&sA00[4 * s + 3], J00[b][1][1]);
+          atomicAdd(&sA01[2 * s + 0], J01[b][0]); atomicAdd(&sA01[2 * s + 1], J01[b][1]);
+          atomicAdd(&sA10[2 * s + 0], J10[b][0]); atomicAdd(&sA10[2 * s + 1], J10[b][1]);
+          atomicAdd(&sA11[s], J11[b]);
+        }
+        if (b == 0) { atomicAdd(&sF[3 * rloc], Fr[0]); atomicAdd(&sF[3 * rloc + 1], Fr[1]); atomicAdd(&sF[3 * rloc + 2], Fr[2]); }
+      }
+    }
+    __syncthreads();
+  }
+  for (int r = 0; r < (ATOMIC ? 0 : maxr); r++) {
     if (active) {
 #pragma unroll
       for (int b = 0; b < 3; b++) {
@@ -470,13 +517,20 @@ __global__ __launch_bounds__(CFDH_MAX_INC) void asm_kernel(AsmArgs p) {
 int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
   AsmArgs a;
   a.coords = c->coords.p; a.mom = c->mom.p; a.x = xstate; a.un = c->xprev.p; a.bcval = c->bcval.p; a.bcmult = c->bcmult.p;
-  a.cells = c->cells.p; a.vptr = c->vptr.p; a.vdiag = c->vdiag.p; a.inc_cell = c->inc_cell.p; a.inc_row = c->inc_row.p;
+  a.vptr = c->vptr.p; a.vdiag = c->vdiag.p; a.inc_cell = c->inc_cell.p;
+  a.blk_vptr = c->blk_vptr.p; a.blk_vlist = c->blk_vlist.p; a.blk_cptr = c->blk_cptr.p; a.blk_clist = c->blk_clist.p; a.inc_loc = c->inc_loc.p;
   a.blk_row = c->blk_row.p; a.blk_inc = c->blk_inc.p; a.blk_maxrank = c->blk_maxrank.p;
   a.inc_slot = c->inc_slot.p; a.inc_rank = c->inc_rank.p; a.cflag = c->cflag.p; a.bcflag = c->bcflag.p;
   a.A00 = c->A00.p; a.A01 = c->A01.p; a.A10 = c->A10.p; a.A11 = c->A11.p; a.F = c->F.p;
   a.nvo = c->nvo; a.dt = c->dt; a.rho = c->rho; a.mu = c->mu; a.muf = c->muf; a.fx = c->f[0]; a.fy = c->f[1];
   prof_begin(c, 0);
-  if (mode == 1) hipLaunchKernelGGL(asm_kernel<1>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
+  static int variant = -1;
+  if (variant < 0) { const char *e = getenv("CFDH_ASM_VARIANT"); variant = e ? atoi(e) : 0; }
+  if (mode == 1 && variant == 1) hipLaunchKernelGGL((asm_kernel<1, 3, false>), dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
+  else if (mode == 1 && variant == 2) hipLaunchKernelGGL((asm_kernel<1, 2, true>), dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
+  else if (mode == 1 && variant == 3) hipLaunchKernelGGL((asm_kernel<1, 3, true>), dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
+  else if (mode == 1 && variant == 4) hipLaunchKernelGGL((asm_kernel<1, 4, false>), dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
+  else if (mode == 1) hipLaunchKernelGGL(asm_kernel<1>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
   else if (mode == 2) hipLaunchKernelGGL(asm_kernel<2>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
   else hipLaunchKernelGGL(asm_kernel<0>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
   prof_end(c, 0);

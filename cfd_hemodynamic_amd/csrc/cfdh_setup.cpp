@@ -169,20 +169,51 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
       }
     }
   }
-  // ---- workgroup blocks of whole rows
-  std::vector<int> blk_row(1, 0), blk_maxrank, blk_inc(1, 0);
+  // ---- workgroup blocks of whole rows, each with its own compact vertex and cell lists:
+  // the kernel stages those (coalesced) in LDS and every lane gathers from LDS only
+  std::vector<int> blk_row(1, 0), blk_maxrank, blk_inc(1, 0), blk_vptr(1, 0), blk_cptr(1, 0), blk_vlist, blk_clist;
+  std::vector<unsigned> inc_loc(ninc);  // lcell | lv0<<8 | lv1<<16 | lv2<<24 (block-local indices, rotated)
   {
-    int r0 = 0;
+    std::vector<int> vmark(nv, -1), vloc(nv, 0), cmark(nc, -1), cloc(nc, 0);
+    int r0 = 0, bid = 0;
     while (r0 < nvo) {
-      int r1 = r0, inc = 0, slots = 0, mr = 2;
+      int r1 = r0, inc = 0, slots = 0, mr = 2, nvl = 0, ncl = 0;
+      const size_t v_begin = blk_vlist.size(), c_begin = blk_clist.size();
       while (r1 < nvo) {
-        int di = vcptr[r1 + 1] - vcptr[r1], ds = c->h_vptr[r1 + 1] - c->h_vptr[r1];
+        const int di = vcptr[r1 + 1] - vcptr[r1], ds = c->h_vptr[r1 + 1] - c->h_vptr[r1];
         if (di > CFDH_MAX_INC || ds > CFDH_MAX_SLOTS) return cfdh_fail(c, CFDH_E_ARG, "vertex valence too large");
         if (inc + di > CFDH_MAX_INC || slots + ds > CFDH_MAX_SLOTS || r1 - r0 >= CFDH_MAX_ROWS) break;
+        // vertices / cells this row would add
+        int addv = 0, addc = 0;
+        for (int k = vcptr[r1]; k < vcptr[r1 + 1]; k++) {
+          const int e = vcell[k] >> 2;
+          if (cmark[e] != bid) { cmark[e] = bid; cloc[e] = -1; addc++; }
+          for (int q = 0; q < 3; q++) { const int w = c->h_cells[3 * e + q]; if (vmark[w] != bid) { vmark[w] = bid; vloc[w] = -1; addv++; } }
+        }
+        if (nvl + addv > CFDH_MAX_BV || ncl + addc > CFDH_MAX_BC) {
+          if (r1 == r0) return cfdh_fail(c, CFDH_E_ARG, "vertex patch too large for one workgroup");
+          // undo the marks of this row (entries with loc == -1 were added by it)
+          for (int k = vcptr[r1]; k < vcptr[r1 + 1]; k++) {
+            const int e = vcell[k] >> 2;
+            if (cmark[e] == bid && cloc[e] == -1) cmark[e] = -1;
+            for (int q = 0; q < 3; q++) { const int w = c->h_cells[3 * e + q]; if (vmark[w] == bid && vloc[w] == -1) vmark[w] = -1; }
+          }
+          break;
+        }
+        for (int k = vcptr[r1]; k < vcptr[r1 + 1]; k++) {
+          const int e = vcell[k] >> 2, a = vcell[k] & 3;
+          if (cloc[e] == -1) { cloc[e] = ncl++; blk_clist.push_back(e); }
+          for (int q = 0; q < 3; q++) { const int w = c->h_cells[3 * e + q]; if (vloc[w] == -1) { vloc[w] = nvl++; blk_vlist.push_back(w); } }
+          unsigned loc = (unsigned)cloc[e];
+          for (int q = 0; q < 3; q++) loc |= (unsigned)vloc[c->h_cells[3 * e + (a + q) % 3]] << (8 * (q + 1));
+          inc_loc[k] = loc;
+        }
         inc += di; slots += ds; mr = std::max(mr, di); r1++;
       }
+      (void)v_begin; (void)c_begin;
       blk_row.push_back(r1); blk_maxrank.push_back(mr); blk_inc.push_back(vcptr[r1]);
-      r0 = r1;
+      blk_vptr.push_back((int)blk_vlist.size()); blk_cptr.push_back((int)blk_clist.size());
+      r0 = r1; bid++;
     }
   }
   c->nblk = (int)blk_maxrank.size();
@@ -209,6 +240,9 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
   HIPCHK(c, c->blk_row.upload(blk_row, s));
   HIPCHK(c, c->blk_maxrank.upload(blk_maxrank, s));
   HIPCHK(c, c->blk_inc.upload(blk_inc, s));
+  HIPCHK(c, c->blk_vptr.upload(blk_vptr, s)); HIPCHK(c, c->blk_cptr.upload(blk_cptr, s));
+  HIPCHK(c, c->blk_vlist.upload(blk_vlist, s)); HIPCHK(c, c->blk_clist.upload(blk_clist, s));
+  HIPCHK(c, c->inc_loc.upload(inc_loc, s));
   {
     std::vector<unsigned char> cown(nc);
     for (int k = 0; k < nc; k++) cown[k] = cells[3 * c->cell_user[k]] < nvo ? 1 : 0;
