@@ -29,7 +29,7 @@ int cfdh_default_options(cfdh_options *o) {
   o->ksp_rtol = 1e-5; o->ksp_atol = 1e-50; o->ksp_max_it = 1000; o->ksp_restart = 200;
   o->cheb_degree = 3; o->cheb_ratio = 10.0; o->schur_full = 1;
   o->amg_smooth_degree = 1; o->amg_smooth_ratio = 8.0; o->amg_theta = 0.08; o->amg_max_coarse = 300;
-  o->pc_refresh = 0; o->remove_p_mean = 1; o->verbose = 0;
+  o->pc_refresh = 0; o->remove_p_mean = 1; o->verbose = 0; o->pc_type = 1;
   return 0;
 }
 
@@ -73,8 +73,7 @@ void cfdh_destroy(cfdh_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   comm_finalize(c);
-  for (AmgLevel *l : c->amg) delete l;
-  c->amg.clear();
+  c->hS.clear(); c->hL.clear(); c->hA.clear();
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto &e : c->pc_graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -100,7 +99,7 @@ int cfdh_set_options(cfdh_ctx *c, const cfdh_options *o) {
       !(o->amg_smooth_ratio > 1) || o->amg_max_coarse < 8 || o->amg_max_coarse > 2000)
     return cfdh_fail(c, CFDH_E_ARG, "option out of range");
   const bool pc_changed = o->amg_theta != c->opt.amg_theta || o->amg_max_coarse != c->opt.amg_max_coarse ||
-                          o->amg_smooth_ratio != c->opt.amg_smooth_ratio;
+                          o->amg_smooth_ratio != c->opt.amg_smooth_ratio || o->pc_type != c->opt.pc_type;
   c->opt = *o;
   if (pc_changed) c->pc_valid = false;
   c->pc_graph_valid = false;  // degrees / schur_full are baked into the captured graph
@@ -114,6 +113,7 @@ int cfdh_clear_dirichlet(cfdh_ctx *c) {
   std::fill(c->h_bcmult.begin(), c->h_bcmult.end(), 0.0);
   c->n_pbc = 0;
   c->bc_dirty = true;
+  c->bc_version++;
   return 0;
 }
 
@@ -336,9 +336,9 @@ int64_t cfdh_info(const cfdh_ctx *c, int what) {
     case 1: return c->nv;
     case 2: return c->nc;
     case 3: return c->nnzv;
-    case 4: return c->sp_nnz;
+    case 4: return c->opt.pc_type == 1 ? c->hL.fine_nnz : c->hS.fine_nnz;
     case 5: return c->ninc;
-    case 6: return (int64_t)c->amg.size();
+    case 6: return (int64_t)(c->opt.pc_type == 1 ? c->hL.lev.size() : c->hS.lev.size());
     case 7: return c->nblk;
     default: return -1;
   }

@@ -62,8 +62,24 @@ struct CsrDev {
 struct AmgLevel {
   int n = 0;
   CsrDev A, P, R;
-  dbuf<double> dinv, x, b, r, d0, d1;
+  dbuf<double> dinv, wdinv, x, b, r, d0, d1;  // wdinv: Jacobi weight (1/theta, or 1 on diagonal-only rows) * dinv; work vectors hold ncol values per row
   double lmax = 0, lmin = 0;
+};
+
+// One smoothed-aggregation hierarchy.  ncol = 2 applies the same scalar operators to two
+// right-hand sides at once (the interleaved velocity components), halving matrix traffic.
+struct AmgHier {
+  std::vector<AmgLevel *> lev;
+  dbuf<double> coarse_inv;  // dense inverse of the coarsest operator
+  int coarse_n = 0, ncol = 1;
+  long long fine_nnz = 0;
+  bool valid = false;
+  void clear() {
+    for (AmgLevel *l : lev) delete l;
+    lev.clear();
+    valid = false;
+  }
+  ~AmgHier() { clear(); }
 };
 
 struct ProfSlot {
@@ -156,14 +172,21 @@ struct cfdh_ctx {
   struct PcGraph { const double *r; double *z; hipGraphExec_t exec; };
   std::vector<PcGraph> pc_graphs;            // one captured preconditioner application per Krylov slot
   bool pc_graph_valid = false, capturing = false, use_graph = true;
-  std::vector<AmgLevel *> amg;
-  dbuf<double> coarse_inv;  // dense inverse of the coarsest operator
-  int coarse_n = 0;
+  AmgHier hS;               // SELFP Schur matrix Sp (pc_type 0)
+  AmgHier hL;               // pressure Laplacian (pc_type 1), built once per Dirichlet set
+  AmgHier hA;               // scalar proxy of A00 applied to both velocity components (pc_type 1)
+  AmgLevel Hlev;            // H = (I + a'T) M_l + b' A11 of the Cahouet-Chabard Schur approximation
+  dbuf<double> ccMl;        // lumped pressure mass (0 on pressure-Dirichlet rows)
+  dbuf<unsigned char> ccPbc;
+  double cc_alpha = 0, cc_beta = 0;
+  std::vector<double> h_Lval, h_Ml;  // P1 stiffness on the vertex graph, lumped mass (geometry only)
+  long long bc_version = 0;
+  std::vector<unsigned char> hL_pbc;  // Dirichlet set hL was built for
+  int hL_singular = -1;
   bool pc_valid = false;
   int pc_its_ref = 0;       // FGMRES iterations right after the last refresh
   int steps_since_refresh = 0;
   int singular = 0;         // constant pressure in the null space (tested per step)
-  long long sp_nnz = 0;
 
   // halo / comm
   int nnbr = 0;
@@ -207,7 +230,8 @@ int cfdh_fail(cfdh_ctx *c, int code, const char *fmt, ...);
 // ---- setup (cfdh_setup.cpp) ------------------------------------------------------
 int cfdh_build_mesh(cfdh_ctx *c, int64_t nv, int64_t nvo, int64_t nc, const int32_t *cells, const double *coords,
                     int64_t nfac, const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker);
-int cfdh_amg_setup(cfdh_ctx *c, const CsrHost &Sp);  // builds c->amg from the host Schur matrix
+int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A, bool singular, int ncol);
+int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol);
 
 // ---- kernels (cfdh_kernels.hip) ----------------------------------------------------
 void prof_begin(cfdh_ctx *c, int kind);
@@ -225,7 +249,10 @@ int k_extract_diag(cfdh_ctx *c);
 int k_cheb_a00(cfdh_ctx *c, const double *b, double *x);
 int k_cheb_a00_coeffs(cfdh_ctx *c);  // x = Cheb_k(A00) b, zero initial guess
 int k_csr_spmv(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mode, const double *b);  // mode 0: y=Ax, 1: y=b-Ax, 2: y+=Ax
-int k_amg_vcycle(cfdh_ctx *c, const double *b, double *x);
+int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x);
+int k_level_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, int degree);
+int k_cc_scale(cfdh_ctx *c, int n, const double *ml, const double *z, double *y);
+int k_cc_combine(cfdh_ctx *c, int n, double alpha, double beta, const double *t, const double *z, const double *r, const unsigned char *pbc, double *out);
 int k_nullspace_test(cfdh_ctx *c, double *nrm);
 
 // vector ops on [0,n)

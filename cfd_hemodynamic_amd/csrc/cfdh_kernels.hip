@@ -768,40 +768,61 @@ int k_cheb_a00(cfdh_ctx *c, const double *b, double *x) {
   return 0;
 }
 
-// ---------------------------------------------------------------- scalar CSR (AMG levels)
+// ---------------------------------------------------------------- scalar CSR operators (AMG levels)
+// All level kernels are templated on the vector element T: double (one right-hand side) or
+// double2 (two right-hand sides sharing one scalar operator: the two velocity components).
+__device__ __forceinline__ double vzero(const double *) { return 0.0; }
+__device__ __forceinline__ double2 vzero(const double2 *) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ double vfma(double a, double x, double acc) { return acc + a * x; }
+__device__ __forceinline__ double2 vfma(double a, double2 x, double2 acc) { return make_double2(acc.x + a * x.x, acc.y + a * x.y); }
+__device__ __forceinline__ double vsub(double a, double b) { return a - b; }
+__device__ __forceinline__ double2 vsub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double vadd(double a, double b) { return a + b; }
+__device__ __forceinline__ double2 vadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double vscale(double a, double x) { return a * x; }
+__device__ __forceinline__ double2 vscale(double a, double2 x) { return make_double2(a * x.x, a * x.y); }
+__device__ __forceinline__ double g8(double v) { return group8_sum(v); }
+__device__ __forceinline__ double2 g8(double2 v) { return make_double2(group8_sum(v.x), group8_sum(v.y)); }
+__device__ __forceinline__ double wsum(double v) { return wave_sum(v); }
+__device__ __forceinline__ double2 wsum(double2 v) { return make_double2(wave_sum(v.x), wave_sum(v.y)); }
+
 // MODE 0: y = A x; 1: y = b - A x; 2: y += A x; 3: y = b + A x
-template <int MODE>
+template <int MODE, typename T>
 __global__ __launch_bounds__(TPB) void csr_spmv_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                       const double *__restrict__ val, const double *__restrict__ x,
-                                                       double *__restrict__ y, const double *__restrict__ b) {
+                                                       const double *__restrict__ val, const T *__restrict__ x,
+                                                       T *__restrict__ y, const T *__restrict__ b) {
   const int gid = blockIdx.x * TPB + threadIdx.x;
   const int row = gid >> 3, l = gid & 7;
-  double a = 0;
+  T a = vzero((const T *)nullptr);
   if (row < n) {
     const int ks = rowptr[row], ke = rowptr[row + 1];
-    for (int k = ks + l; k < ke; k += 8) a += val[k] * x[col[k]];
+    for (int k = ks + l; k < ke; k += 8) a = vfma(val[k], x[col[k]], a);
   }
-  a = group8_sum(a);
+  a = g8(a);
   if (row < n && l == 0) {
     if (MODE == 0) y[row] = a;
-    else if (MODE == 1) y[row] = b[row] - a;
-    else if (MODE == 2) y[row] += a;
-    else y[row] = b[row] + a;
+    else if (MODE == 1) y[row] = vsub(b[row], a);
+    else if (MODE == 2) y[row] = vadd(y[row], a);
+    else y[row] = vadd(b[row], a);
   }
 }
 
-int k_csr_spmv(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mode, const double *b) {
+template <typename T>
+static int csr_spmv_t(cfdh_ctx *c, const CsrDev &A, const T *x, T *y, int mode, const T *b) {
   const long long nthreads = 8ll * A.n;
   dim3 grid((unsigned)((nthreads + TPB - 1) / TPB)), block(TPB);
-  if (mode == 0) hipLaunchKernelGGL(csr_spmv_kernel<0>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
-  else if (mode == 1) hipLaunchKernelGGL(csr_spmv_kernel<1>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
-  else if (mode == 2) hipLaunchKernelGGL(csr_spmv_kernel<2>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
-  else hipLaunchKernelGGL(csr_spmv_kernel<3>, grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
+  if (mode == 0) hipLaunchKernelGGL((csr_spmv_kernel<0, T>), grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
+  else if (mode == 1) hipLaunchKernelGGL((csr_spmv_kernel<1, T>), grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
+  else if (mode == 2) hipLaunchKernelGGL((csr_spmv_kernel<2, T>), grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
+  else hipLaunchKernelGGL((csr_spmv_kernel<3, T>), grid, block, 0, c->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y, b);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+int k_csr_spmv(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mode, const double *b) {
+  return csr_spmv_t<double>(c, A, x, y, mode, b);
+}
 
-// One Chebyshev step on a scalar CSR level:
+// One Chebyshev step on a scalar CSR level (single right-hand side):
 //   r_out = r_in - A d_old ; d_new = c1 d_old + c2 D^-1 r_out ; x (+)= ...
 // MODE 0: x += d_new.
 // MODE 1: first step of a zero-guess smoothing fused with its initialisation: d_old = D^-1 r_in / theta
@@ -857,14 +878,9 @@ __global__ __launch_bounds__(TPB) void csr_resid_init_kernel(int n, const int *_
   }
 }
 
-__global__ __launch_bounds__(TPB) void add_kernel(int n, const double *__restrict__ d, double *__restrict__ x) {
-  const int i = blockIdx.x * TPB + threadIdx.x;
-  if (i < n) x[i] += d[i];
-}
-
-// Chebyshev smoothing on level L: zero_guess ? x = S b : x <- x + S (b - A x)
-static int amg_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, bool zero_guess) {
-  const int n = L->n, deg = c->opt.amg_smooth_degree;
+// Chebyshev smoothing with the level operator (ncol = 1): zero_guess ? x = S b : x <- x + S (b - A x)
+static int level_cheb(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, bool zero_guess, int deg, bool prof) {
+  const int n = L->n;
   const double theta = 0.5 * (L->lmax + L->lmin), delta = 0.5 * (L->lmax - L->lmin), sigma = theta / delta;
   double rho = 1.0 / sigma;
   double *dold = L->d0.p, *dnew = L->d1.p, *r = L->r.p;
@@ -890,13 +906,13 @@ static int amg_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, bool
     const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
     const bool last = (k == deg - 1);
     const int mode = (k == 1) ? (zero_guess ? 1 : 2) : 0;
-    if (L == c->amg[0]) prof_begin(c, 4);
+    if (prof) prof_begin(c, 4);
 #define LAUNCH_STEP(M, LST) hipLaunchKernelGGL((cheb_csr_step_kernel<M, LST>), grid, block, 0, c->stream, n, rp, cl, vl, di, rin, r, dold, dnew, x, c1, c2, itheta)
     if (mode == 1) { if (last) LAUNCH_STEP(1, true); else LAUNCH_STEP(1, false); }
     else if (mode == 2) { if (last) LAUNCH_STEP(2, true); else LAUNCH_STEP(2, false); }
     else { if (last) LAUNCH_STEP(0, true); else LAUNCH_STEP(0, false); }
 #undef LAUNCH_STEP
-    if (L == c->amg[0]) prof_end(c, 4);
+    if (prof) prof_end(c, 4);
     rin = r;
     std::swap(dold, dnew);
     rho = rho_new;
@@ -904,89 +920,139 @@ static int amg_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, bool
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+int k_level_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, int degree) { return level_cheb(c, L, b, x, true, degree, false); }
 
 // y = Minv b for the dense coarsest inverse: one wave per row
-__global__ __launch_bounds__(64) void dense_mv_kernel(int n, const double *__restrict__ Minv, const double *__restrict__ b,
-                                                      double *__restrict__ y) {
+template <typename T>
+__global__ __launch_bounds__(64) void dense_mv_kernel(int n, const double *__restrict__ Minv, const T *__restrict__ b,
+                                                      T *__restrict__ y) {
   const int row = blockIdx.x, l = threadIdx.x;
-  double a = 0;
-  for (int k = l; k < n; k += 64) a += Minv[(size_t)row * n + k] * b[k];
-  a = wave_sum(a);
+  T a = vzero((const T *)nullptr);
+  for (int k = l; k < n; k += 64) a = vfma(Minv[(size_t)row * n + k], b[k], a);
+  a = wsum(a);
   if (l == 0) y[row] = a;
 }
 
-// damped-Jacobi V-cycle building blocks (amg_smooth_degree == 1): each touches the level matrix once
-//   pre : xa = D^-1 b / theta (formed while gathering) ; r = b - A xa
-//   post: x_out = x_in + D^-1 (b - A x_in) / theta
+// damped-Jacobi V-cycle building blocks: each touches the level matrix once.  A row whose only entry is
+// its diagonal (Dirichlet row, isolated unknown) is solved exactly (weight 1 instead of 1/theta).
+//   pre : xa = w D^-1 b (formed while gathering) ; r = b - A xa
+//   post: x_out = x_in + w D^-1 (b - A x_in)
+template <typename T>
 __global__ __launch_bounds__(TPB) void jacobi_pre_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                         const double *__restrict__ val, const double *__restrict__ dinv,
-                                                         const double *__restrict__ b, double *__restrict__ xa,
-                                                         double *__restrict__ r, double itheta) {
+                                                         const double *__restrict__ val, const double *__restrict__ wdinv,
+                                                         const T *__restrict__ b, T *__restrict__ xa, T *__restrict__ r) {
   const int gid = blockIdx.x * TPB + threadIdx.x;
   const int row = gid >> 3, l = gid & 7;
-  double a = 0;
+  T a = vzero((const T *)nullptr);
   if (row < n) {
     const int ks = rowptr[row], ke = rowptr[row + 1];
-    for (int k = ks + l; k < ke; k += 8) { const int j = col[k]; a += val[k] * (dinv[j] * b[j] * itheta); }
+    for (int k = ks + l; k < ke; k += 8) {
+      const int j = col[k];
+      a = vfma(val[k] * wdinv[j], b[j], a);
+    }
   }
-  a = group8_sum(a);
+  a = g8(a);
   if (row < n && l == 0) {
-    const double bi = b[row];
-    xa[row] = dinv[row] * bi * itheta;
-    r[row] = bi - a;
+    const T bi = b[row];
+    xa[row] = vscale(wdinv[row], bi);
+    r[row] = vsub(bi, a);
   }
 }
+template <typename T>
 __global__ __launch_bounds__(TPB) void jacobi_post_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                          const double *__restrict__ val, const double *__restrict__ dinv,
-                                                          const double *__restrict__ b, const double *__restrict__ xin,
-                                                          double *__restrict__ xout, double itheta) {
+                                                          const double *__restrict__ val, const double *__restrict__ wdinv,
+                                                          const T *__restrict__ b, const T *__restrict__ xin,
+                                                          T *__restrict__ xout) {
   const int gid = blockIdx.x * TPB + threadIdx.x;
   const int row = gid >> 3, l = gid & 7;
-  double a = 0;
+  T a = vzero((const T *)nullptr);
   if (row < n) {
     const int ks = rowptr[row], ke = rowptr[row + 1];
-    for (int k = ks + l; k < ke; k += 8) a += val[k] * xin[col[k]];
+    for (int k = ks + l; k < ke; k += 8) a = vfma(val[k], xin[col[k]], a);
   }
-  a = group8_sum(a);
-  if (row < n && l == 0) xout[row] = xin[row] + dinv[row] * (b[row] - a) * itheta;
+  a = g8(a);
+  if (row < n && l == 0) {
+    xout[row] = vadd(xin[row], vscale(wdinv[row], vsub(b[row], a)));
+  }
 }
 
-static int amg_cycle(cfdh_ctx *c, size_t lev, const double *b, double *x) {
-  AmgLevel *L = c->amg[lev];
-  if (lev + 1 == c->amg.size()) {
-    hipLaunchKernelGGL(dense_mv_kernel, dim3(c->coarse_n), dim3(64), 0, c->stream, c->coarse_n, c->coarse_inv.p, b, x);
+template <typename T>
+static int amg_cycle_jacobi(cfdh_ctx *c, AmgHier &H, size_t lev, const T *b, T *x, bool prof) {
+  AmgLevel *L = H.lev[lev];
+  if (lev + 1 == H.lev.size()) {
+    hipLaunchKernelGGL((dense_mv_kernel<T>), dim3(H.coarse_n), dim3(64), 0, c->stream, H.coarse_n, H.coarse_inv.p, b, x);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
-  AmgLevel *N = c->amg[lev + 1];
-  if (c->opt.amg_smooth_degree == 1) {
-    const int n = L->n;
-    const double itheta = 2.0 / (L->lmax + L->lmin);
-    dim3 grid((unsigned)((8ll * n + TPB - 1) / TPB)), block(TPB);
-    if (lev == 0) prof_begin(c, 4);
-    hipLaunchKernelGGL(jacobi_pre_kernel, grid, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->dinv.p, b,
-                       L->d0.p, L->r.p, itheta);
-    if (lev == 0) prof_end(c, 4);
-    CHK(k_csr_spmv(c, L->R, L->r.p, N->b.p, 0, nullptr));     // b_c = R r
-    CHK(amg_cycle(c, lev + 1, N->b.p, N->x.p));
-    CHK(k_csr_spmv(c, L->P, N->x.p, L->d1.p, 3, L->d0.p));    // x1 = xa + P x_c
-    if (lev == 0) prof_begin(c, 4);
-    hipLaunchKernelGGL(jacobi_post_kernel, grid, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->dinv.p, b,
-                       L->d1.p, x, itheta);
-    if (lev == 0) prof_end(c, 4);
-    HIPCHK(c, hipGetLastError());
-    return 0;
-  }
-  CHK(amg_smooth(c, L, b, x, true));
-  CHK(k_csr_spmv(c, L->A, x, L->r.p, 1, b));     // r = b - A x
-  CHK(k_csr_spmv(c, L->R, L->r.p, N->b.p, 0, nullptr));  // b_c = R r
-  CHK(amg_cycle(c, lev + 1, N->b.p, N->x.p));
-  CHK(k_csr_spmv(c, L->P, N->x.p, x, 2, nullptr));  // x += P x_c
-  CHK(amg_smooth(c, L, b, x, false));
+  AmgLevel *N = H.lev[lev + 1];
+  const int n = L->n;
+  dim3 grid((unsigned)((8ll * n + TPB - 1) / TPB)), block(TPB);
+  T *xa = (T *)L->d0.p, *x1 = (T *)L->d1.p, *r = (T *)L->r.p;
+  if (prof && lev == 0) prof_begin(c, 4);
+  hipLaunchKernelGGL((jacobi_pre_kernel<T>), grid, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->wdinv.p, b,
+                     xa, r);
+  if (prof && lev == 0) prof_end(c, 4);
+  CHK(csr_spmv_t<T>(c, L->R, r, (T *)N->b.p, 0, (const T *)nullptr));   // b_c = R r
+  CHK(amg_cycle_jacobi<T>(c, H, lev + 1, (const T *)N->b.p, (T *)N->x.p, prof));
+  CHK(csr_spmv_t<T>(c, L->P, (const T *)N->x.p, x1, 3, xa));            // x1 = xa + P x_c
+  if (prof && lev == 0) prof_begin(c, 4);
+  hipLaunchKernelGGL((jacobi_post_kernel<T>), grid, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->wdinv.p, b,
+                     x1, x);
+  if (prof && lev == 0) prof_end(c, 4);
+  HIPCHK(c, hipGetLastError());
   return 0;
 }
 
-int k_amg_vcycle(cfdh_ctx *c, const double *b, double *x) { return amg_cycle(c, 0, b, x); }
+// V-cycle with Chebyshev smoothing of degree >= 2 (single right-hand side)
+static int amg_cycle_cheb(cfdh_ctx *c, AmgHier &H, size_t lev, const double *b, double *x, bool prof) {
+  AmgLevel *L = H.lev[lev];
+  if (lev + 1 == H.lev.size()) {
+    hipLaunchKernelGGL((dense_mv_kernel<double>), dim3(H.coarse_n), dim3(64), 0, c->stream, H.coarse_n, H.coarse_inv.p, b, x);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  AmgLevel *N = H.lev[lev + 1];
+  const int deg = c->opt.amg_smooth_degree;
+  CHK(level_cheb(c, L, b, x, true, deg, prof && lev == 0));
+  CHK(k_csr_spmv(c, L->A, x, L->r.p, 1, b));     // r = b - A x
+  CHK(k_csr_spmv(c, L->R, L->r.p, N->b.p, 0, nullptr));  // b_c = R r
+  CHK(amg_cycle_cheb(c, H, lev + 1, N->b.p, N->x.p, prof));
+  CHK(k_csr_spmv(c, L->P, N->x.p, x, 2, nullptr));  // x += P x_c
+  CHK(level_cheb(c, L, b, x, false, deg, prof && lev == 0));
+  return 0;
+}
+
+// x = V(H) b; for ncol == 2 b and x hold interleaved pairs
+int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x) {
+  if (!H.valid || H.lev.empty()) return cfdh_fail(c, CFDH_E_STATE, "AMG hierarchy not built");
+  const bool prof = (&H == &c->hS) || (&H == &c->hL);
+  if (H.ncol == 2) return amg_cycle_jacobi<double2>(c, H, 0, (const double2 *)b, (double2 *)x, false);
+  if (c->opt.amg_smooth_degree == 1) return amg_cycle_jacobi<double>(c, H, 0, b, x, prof);
+  return amg_cycle_cheb(c, H, 0, b, x, prof);
+}
+
+// Cahouet-Chabard combination: y = M_l z (0 on Dirichlet rows) ; out = alpha t + beta z, out = r on Dirichlet rows
+__global__ __launch_bounds__(TPB) void cc_scale_kernel(int n, const double *__restrict__ ml, const double *__restrict__ z, double *__restrict__ y) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i < n) y[i] = ml[i] * z[i];
+}
+__global__ __launch_bounds__(TPB) void cc_combine_kernel(int n, double alpha, double beta, const double *__restrict__ t,
+                                                         const double *__restrict__ z, const double *__restrict__ r,
+                                                         const unsigned char *__restrict__ pbc, double *__restrict__ out) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i < n) out[i] = pbc[i] ? r[i] : alpha * t[i] + beta * z[i];
+}
+int k_cc_scale(cfdh_ctx *c, int n, const double *ml, const double *z, double *y) {
+  hipLaunchKernelGGL(cc_scale_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, ml, z, y);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int k_cc_combine(cfdh_ctx *c, int n, double alpha, double beta, const double *t, const double *z, const double *r,
+                 const unsigned char *pbc, double *out) {
+  hipLaunchKernelGGL(cc_combine_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, alpha, beta, t, z, r, pbc, out);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 
 // ---------------------------------------------------------------- vector kernels
 __global__ __launch_bounds__(TPB) void axpy_kernel(int n, double a, const double *__restrict__ x, double *__restrict__ y) {

@@ -145,6 +145,27 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
   }
   c->nnzv = (int)c->h_vcol.size();
   c->ninc = ninc;
+  // P1 stiffness (grad l_a . grad l_b) on the vertex graph and lumped mass of the owned rows: geometry only,
+  // used by the Cahouet-Chabard Schur approximation (pc_type 1)
+  c->h_Lval.assign(c->nnzv, 0.0);
+  c->h_Ml.assign(nvo, 0.0);
+  for (int e = 0; e < nc; e++) {
+    const int *v = &c->h_cells[3 * e];
+    const double *X = c->h_coords.data();
+    const double x0 = X[2 * v[0]], y0 = X[2 * v[0] + 1], x1 = X[2 * v[1]], y1 = X[2 * v[1] + 1], x2 = X[2 * v[2]], y2 = X[2 * v[2] + 1];
+    const double det = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0), area = 0.5 * std::fabs(det);
+    const double g[3][2] = {{(y1 - y2) / det, (x2 - x1) / det}, {(y2 - y0) / det, (x0 - x2) / det}, {(y0 - y1) / det, (x1 - x0) / det}};
+    for (int a = 0; a < 3; a++) {
+      if (v[a] >= nvo) continue;
+      c->h_Ml[v[a]] += area / 3.0;
+      const int *nb = &c->h_vcol[c->h_vptr[v[a]]];
+      const int deg = c->h_vptr[v[a] + 1] - c->h_vptr[v[a]];
+      for (int b = 0; b < 3; b++) {
+        const int sidx = (int)(std::lower_bound(nb, nb + deg, v[b]) - nb);
+        c->h_Lval[c->h_vptr[v[a]] + sidx] += area * (g[a][0] * g[b][0] + g[a][1] * g[b][1]);
+      }
+    }
+  }
 
   // ---- incidence metadata (rotated so that the row vertex is local 0)
   std::vector<int> inc_cell(ninc), inc_row(ninc);
@@ -346,6 +367,7 @@ static int aggregate_host(const CsrHost &A, double theta, std::vector<int> &agg)
   agg.swap(agg2);
   for (int i = 0; i < n; i++) {
     if (agg[i] >= 0) continue;
+    if (sptr[i + 1] == sptr[i]) continue;  // isolated unknown (e.g. Dirichlet row): no coarse correction
     agg[i] = na;
     for (int k = sptr[i]; k < sptr[i + 1]; k++) if (agg[scol[k]] < 0) agg[scol[k]] = na;
     na++;
@@ -432,50 +454,76 @@ static bool dense_inverse(std::vector<double> &a, int n) {
   return true;
 }
 
-int cfdh_amg_setup(cfdh_ctx *c, const CsrHost &Sp) {
-  for (AmgLevel *l : c->amg) delete l;
-  c->amg.clear();
+// device copy of one operator with its Jacobi diagonal, spectral bound and work vectors
+int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol) {
+  L.n = A.n;
+  std::vector<double> dinv(A.n, 1.0);
+  for (int i = 0; i < A.n; i++)
+    for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++)
+      if (A.col[k] == i && A.val[k] != 0.0) dinv[i] = 1.0 / A.val[k];
+  const double lm = lam_max_host(A, dinv, 15);
+  L.lmax = 1.1 * lm;
+  L.lmin = L.lmax / ratio;
+  CHK(upload_csr(c, A, L.A));
+  HIPCHK(c, L.dinv.upload(dinv, c->stream));
+  {
+    // damped-Jacobi weights: 1/theta, theta = (lmax+lmin)/2; rows that are diagonal-only are solved exactly
+    std::vector<double> w(A.n);
+    const double itheta = 2.0 / (L.lmax + L.lmin);
+    for (int i = 0; i < A.n; i++) {
+      int offd = 0;
+      for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] != i && A.val[k] != 0.0) offd++;
+      w[i] = dinv[i] * (offd == 0 ? 1.0 : itheta);
+    }
+    HIPCHK(c, L.wdinv.upload(w, c->stream));
+  }
+  const size_t nn = (size_t)A.n * ncol;
+  HIPCHK(c, L.x.alloc(nn)); HIPCHK(c, L.b.alloc(nn)); HIPCHK(c, L.r.alloc(nn));
+  HIPCHK(c, L.d0.alloc(nn)); HIPCHK(c, L.d1.alloc(nn));
+  return 0;
+}
+
+int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, int ncol) {
+  H.clear();
+  H.ncol = ncol;
   const cfdh_options &o = c->opt;
-  CsrHost A = Sp;
+  CsrHost A = A0;
   const int maxlev = 16;
   for (;;) {
     AmgLevel *L = new AmgLevel();
-    c->amg.push_back(L);
-    L->n = A.n;
+    H.lev.push_back(L);
+    CHK(cfdh_level_setup(c, *L, A, o.amg_smooth_ratio, ncol));
+    const double lm = L->lmax / 1.1;
+    if (A.n <= o.amg_max_coarse || (int)H.lev.size() >= maxlev) break;
+    std::vector<int> agg;
+    int na = aggregate_host(A, o.amg_theta, agg);
+    if (na >= A.n || na < 1) break;  // no coarsening possible
     std::vector<double> dinv(A.n, 1.0);
     for (int i = 0; i < A.n; i++)
       for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++)
         if (A.col[k] == i && A.val[k] != 0.0) dinv[i] = 1.0 / A.val[k];
-    double lm = lam_max_host(A, dinv, 15);
-    L->lmax = 1.1 * lm;
-    L->lmin = L->lmax / o.amg_smooth_ratio;
-    CHK(upload_csr(c, A, L->A));
-    HIPCHK(c, L->dinv.upload(dinv, c->stream));
-    HIPCHK(c, L->x.alloc(A.n)); HIPCHK(c, L->b.alloc(A.n)); HIPCHK(c, L->r.alloc(A.n));
-    HIPCHK(c, L->d0.alloc(A.n)); HIPCHK(c, L->d1.alloc(A.n));
-    if (A.n <= o.amg_max_coarse || (int)c->amg.size() >= maxlev) break;
-    std::vector<int> agg;
-    int na = aggregate_host(A, o.amg_theta, agg);
-    if (na >= A.n || na < 1) break;  // no coarsening possible
-    // P = (I - omega D^-1 A) P0,  P0 = piecewise constant
+    // P = (I - omega D^-1 A) P0,  P0 = piecewise constant; rows of isolated (diagonal-only) unknowns
+    // carry no coarse correction (agg = -1): the smoother solves them exactly
     CsrHost P0;
     P0.n = A.n; P0.m = na;
-    P0.rowptr.resize(A.n + 1);
-    P0.col.resize(A.n); P0.val.assign(A.n, 1.0);
-    for (int i = 0; i <= A.n; i++) P0.rowptr[i] = i;
-    for (int i = 0; i < A.n; i++) P0.col[i] = agg[i];
+    P0.rowptr.assign(A.n + 1, 0);
+    for (int i = 0; i < A.n; i++) P0.rowptr[i + 1] = P0.rowptr[i] + (agg[i] >= 0 ? 1 : 0);
+    P0.col.resize(P0.rowptr[A.n]); P0.val.assign(P0.rowptr[A.n], 1.0);
+    for (int i = 0; i < A.n; i++) if (agg[i] >= 0) P0.col[P0.rowptr[i]] = agg[i];
     CsrHost AP0, P;
     spgemm_host(A, P0, AP0);
-    double omega = 4.0 / 3.0 / lm;
+    const double omega = 4.0 / 3.0 / lm;
     P.n = A.n; P.m = na;
     P.rowptr.assign(A.n + 1, 0);
     for (int i = 0; i < A.n; i++) {
+      if (agg[i] < 0) { P.rowptr[i + 1] = P.rowptr[i]; continue; }
       bool has = false;
       for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; k++) if (AP0.col[k] == agg[i]) has = true;
       P.rowptr[i + 1] = P.rowptr[i] + (AP0.rowptr[i + 1] - AP0.rowptr[i]) + (has ? 0 : 1);
     }
     P.col.resize(P.rowptr[A.n]); P.val.resize(P.rowptr[A.n]);
     for (int i = 0; i < A.n; i++) {
+      if (agg[i] < 0) continue;
       int p = P.rowptr[i];
       bool placed = false;
       for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; k++) {
@@ -504,19 +552,20 @@ int cfdh_amg_setup(cfdh_ctx *c, const CsrHost &Sp) {
     double tr = 0;
     for (int i = 0; i < n; i++)
       for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) { D[(size_t)i * n + A.col[k]] = A.val[k]; if (A.col[k] == i) tr += std::fabs(A.val[k]); }
-    if (c->singular) {
+    if (singular) {
       double alpha = tr / n / n;
       for (size_t k = 0; k < D.size(); k++) D[k] += alpha;
     }
     if (!dense_inverse(D, n)) return cfdh_fail(c, CFDH_E_STATE, "singular coarsest AMG operator (n=%d)", n);
-    HIPCHK(c, c->coarse_inv.upload(D, c->stream));
-    c->coarse_n = n;
+    HIPCHK(c, H.coarse_inv.upload(D, c->stream));
+    H.coarse_n = n;
   }
-  c->sp_nnz = Sp.nnz();
+  H.fine_nnz = A0.nnz();
+  H.valid = true;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->opt.verbose) {
-    fprintf(stderr, "[cfdh] AMG hierarchy:");
-    for (AmgLevel *l : c->amg) fprintf(stderr, " (%d, nnz %d)", l->n, l->A.nnz);
+    fprintf(stderr, "[cfdh] AMG hierarchy (ncol %d):", ncol);
+    for (AmgLevel *l : H.lev) fprintf(stderr, " (%d, nnz %d)", l->n, l->A.nnz);
     fprintf(stderr, "\n");
   }
   return 0;

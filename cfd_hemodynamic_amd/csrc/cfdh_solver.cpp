@@ -84,11 +84,105 @@ static int build_schur_host(cfdh_ctx *c, CsrHost &S) {
   return 0;
 }
 
+// pc_type 1 -- host side of the Cahouet-Chabard-type preconditioner (all rank-local, owned x owned):
+//   * hA : SA hierarchy of the scalar proxy (A00_xx + A00_yy)/2 of the velocity block, applied to both
+//          components at once (the xy coupling of the symmetric-gradient term is dropped: Korn-equivalent);
+//   * hL : SA hierarchy of the P1 pressure Laplacian (Dirichlet rows where p is prescribed) -- geometry
+//          and Dirichlet set only, so it is built once;
+//   * H  = (I + a'T) M_l + b' A11 with a' = 2 rho/dt, b' = mu, T = diag(A11)/diag(L) (nodal tau/rho):
+//          S^-1 ~ (a' L^-1 + b' M_l^-1) [ (I + a'T) + b' A11 M_l^-1 ]^-1 for
+//          S = A11 + (1/2) B A00^-1 B^T ~ A11 + (a' L^-1 + b' M_l^-1)^-1   (A11 = (tau/rho)-weighted Laplacian).
+static int build_cc_host(cfdh_ctx *c) {
+  std::vector<double> a00, a01, a10, a11;
+  CHK(cfdh_download_blocks(c, a00, a01, a10, a11));
+  const int nvo = c->nvo;
+  const std::vector<int> &vp = c->h_vptr, &vc = c->h_vcol;
+  // --- scalar proxy of A00
+  {
+    CsrHost Ah;
+    Ah.n = Ah.m = nvo;
+    Ah.rowptr.assign(nvo + 1, 0);
+    for (int i = 0; i < nvo; i++) {
+      for (int k = vp[i]; k < vp[i + 1]; k++) {
+        const int w = vc[k];
+        if (w >= nvo) continue;
+        const double v = 0.5 * (a00[4 * (size_t)k] + a00[4 * (size_t)k + 3]);
+        if (v == 0.0 && w != i) continue;
+        Ah.col.push_back(w); Ah.val.push_back(v);
+      }
+      Ah.rowptr[i + 1] = (int)Ah.col.size();
+    }
+    CHK(cfdh_amg_setup(c, c->hA, Ah, false, 2));
+  }
+  // --- pressure Laplacian hierarchy (once per Dirichlet set)
+  std::vector<unsigned char> pbc(nvo);
+  for (int i = 0; i < nvo; i++) pbc[i] = (c->h_bcflag[i] & 4u) ? 1 : 0;
+  if (!c->hL.valid || c->hL_pbc != pbc || c->hL_singular != c->singular) {
+    CsrHost Lh;
+    Lh.n = Lh.m = nvo;
+    Lh.rowptr.assign(nvo + 1, 0);
+    for (int i = 0; i < nvo; i++) {
+      if (pbc[i]) { Lh.col.push_back(i); Lh.val.push_back(1.0); }
+      else
+        for (int k = vp[i]; k < vp[i + 1]; k++) {
+          const int w = vc[k];
+          if (w >= nvo || pbc[w]) continue;
+          Lh.col.push_back(w); Lh.val.push_back(c->h_Lval[k]);
+        }
+      Lh.rowptr[i + 1] = (int)Lh.col.size();
+    }
+    CHK(cfdh_amg_setup(c, c->hL, Lh, c->singular != 0, 1));
+    c->hL_pbc = pbc;
+    c->hL_singular = c->singular;
+    std::vector<double> ml(nvo);
+    for (int i = 0; i < nvo; i++) ml[i] = pbc[i] ? 0.0 : c->h_Ml[i];
+    HIPCHK(c, c->ccMl.upload(ml, c->stream));
+    HIPCHK(c, c->ccPbc.upload(pbc, c->stream));
+  }
+  // --- H
+  c->cc_alpha = 2.0 * c->rho / c->dt;
+  c->cc_beta = c->mu;
+  {
+    CsrHost Hh;
+    Hh.n = Hh.m = nvo;
+    Hh.rowptr.assign(nvo + 1, 0);
+    for (int i = 0; i < nvo; i++) {
+      if (pbc[i]) { Hh.col.push_back(i); Hh.val.push_back(1.0); }
+      else {
+        const size_t kd = (size_t)c->h_vdiag[i];
+        const double T = c->h_Lval[kd] > 0 ? a11[kd] / c->h_Lval[kd] : 0.0;
+        for (int k = vp[i]; k < vp[i + 1]; k++) {
+          const int w = vc[k];
+          if (w >= nvo || pbc[w]) continue;
+          double v = c->cc_beta * a11[k];
+          if (w == i) v += (1.0 + c->cc_alpha * T) * c->h_Ml[i];
+          Hh.col.push_back(w); Hh.val.push_back(v);
+        }
+      }
+      Hh.rowptr[i + 1] = (int)Hh.col.size();
+    }
+    CHK(cfdh_level_setup(c, c->Hlev, Hh, 8.0, 1));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // refresh the parts of the preconditioner that follow the current Jacobian:
 // always the Jacobi diagonal and the spectral bound of D^-1 A00; the Sp
 // hierarchy only when asked (lagged preconditioner)
 int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
   const int nu = 2 * c->nvo;
+  if (c->opt.pc_type == 1) {
+    if (refresh_amg || !c->pc_valid) {
+      c->pc_graph_valid = false;
+      CHK(build_cc_host(c));
+      c->pc_valid = true;
+      c->pc_its_ref = 0;
+      c->steps_since_refresh = 0;
+      c->last_stats.pc_refreshes++;
+    }
+    return 0;
+  }
   CHK(k_extract_diag(c));
   // lambda_max(D^-1 A00) by power iteration from a fixed start vector
   double *v = c->pu0.p, *w = c->pu1.p;
@@ -107,10 +201,14 @@ int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
   c->lmaxA = 1.15 * lam;
   CHK(k_cheb_a00_coeffs(c));
   if (refresh_amg || !c->pc_valid) {
-    c->pc_graph_valid = false;  // the hierarchy's buffers and coefficients are baked into the graph
-    CsrHost S;
-    CHK(build_schur_host(c, S));
-    CHK(cfdh_amg_setup(c, S));
+    c->pc_graph_valid = false;  // the hierarchies' buffers and coefficients are baked into the graphs
+    if (c->opt.pc_type == 1) {
+      CHK(build_cc_host(c));
+    } else {
+      CsrHost S;
+      CHK(build_schur_host(c, S));
+      CHK(cfdh_amg_setup(c, c->hS, S, c->singular != 0, 1));
+    }
     c->pc_valid = true;
     c->pc_its_ref = 0;
     c->steps_since_refresh = 0;
@@ -123,9 +221,21 @@ static int pc_apply_body(cfdh_ctx *c, const double *r, double *z) {
   const int nvo = c->nvo, nu = 2 * nvo;
   const double *ru = r, *rp = r + nu;
   double *zu = z, *zp = z + nu;
+  if (c->opt.pc_type == 1) {
+    CHK(k_amg_vcycle(c, c->hA, ru, c->pu0.p));              // y_u = V(A00~) r_u   (both components at once)
+    CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));     // t_p = r_p - A10 y_u
+    // z_p = S~^-1 t_p : zH = Cheb3(H) t_p ; y = M_l zH ; z_p = a' V(L) y + b' zH
+    CHK(k_level_smooth(c, &c->Hlev, c->pp0.p, c->pp1.p, 3));
+    CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
+    CHK(k_amg_vcycle(c, c->hL, c->pu1.p, c->pu2.p));
+    CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, c->pp0.p, c->ccPbc.p, zp));
+    CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));           // t_u = r_u - A01 z_p
+    CHK(k_amg_vcycle(c, c->hA, c->pu0.p, zu));              // z_u = V(A00~) t_u
+    return 0;
+  }
   CHK(k_cheb_a00(c, ru, c->pu0.p));                       // y_u = C(A00) r_u
   CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));     // t_p = r_p - A10 y_u
-  CHK(k_amg_vcycle(c, c->pp0.p, zp));                     // z_p = V(Sp) t_p
+  CHK(k_amg_vcycle(c, c->hS, c->pp0.p, zp));              // z_p = V(Sp) t_p
   if (c->opt.schur_full) {
     CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));         // t_u = r_u - A01 z_p
     CHK(k_cheb_a00(c, c->pu0.p, zu));                     // z_u = C(A00) t_u
@@ -175,7 +285,7 @@ int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z) {
 static int ensure_krylov(cfdh_ctx *c) {
   const int m = c->opt.ksp_restart;
   if (c->kry_m == m && c->kV.p) return 0;
-  const size_t NL = (size_t)c->NL;
+  const size_t NL = ((size_t)c->NL + 1) & ~(size_t)1;  // even leading dimension: every V_j / Z_j stays 16-B aligned
   c->pc_graph_valid = false;  // captured graphs hold pointers into V / Z
   HIPCHK(c, c->kV.alloc(NL * (m + 1)));
   HIPCHK(c, c->kZ.alloc(NL * m));
@@ -195,7 +305,7 @@ static int ensure_krylov(cfdh_ctx *c) {
 int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reason_out) {
   CHK(ensure_krylov(c));
   const int n = c->NO, m = c->kry_m;
-  const size_t ld = (size_t)c->NL;
+  const size_t ld = ((size_t)c->NL + 1) & ~(size_t)1;
   const cfdh_options &o = c->opt;
   std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hh(2 * (size_t)(m + 1) + 8);
   double bn;

@@ -81,6 +81,8 @@ typedef struct cfdh_options {
   int32_t pc_refresh;       /* 0: adaptive lagging of the Sp hierarchy, n>0: every n steps, -1: every Jacobian */
   int32_t remove_p_mean;    /* nullsp.remove(x_n), stabilized_schur.py:319 */
   int32_t verbose;
+  int32_t pc_type;          /* 0: SELFP Schur matrix + Chebyshev(A00) (the reference's SELFP, :235);
+                             * 1: Cahouet-Chabard Schur approximation + AMG(A00) (mesh-independent) */
 } cfdh_options;
 
 typedef struct cfdh_stats {
