@@ -977,7 +977,7 @@ __global__ __launch_bounds__(TPB) void jacobi_post_kernel(int n, const int *__re
 }
 
 template <typename T>
-static int amg_cycle_jacobi(cfdh_ctx *c, AmgHier &H, size_t lev, const T *b, T *x, bool prof) {
+static int amg_cycle_jacobi(cfdh_ctx *c, AmgHier &H, size_t lev, const T *b, T *x, int prof) {
   AmgLevel *L = H.lev[lev];
   if (lev + 1 == H.lev.size()) {
     hipLaunchKernelGGL((dense_mv_kernel<T>), dim3(H.coarse_n), dim3(64), 0, c->stream, H.coarse_n, H.coarse_inv.p, b, x);
@@ -988,17 +988,17 @@ static int amg_cycle_jacobi(cfdh_ctx *c, AmgHier &H, size_t lev, const T *b, T *
   const int n = L->n;
   dim3 grid((unsigned)((8ll * n + TPB - 1) / TPB)), block(TPB);
   T *xa = (T *)L->d0.p, *x1 = (T *)L->d1.p, *r = (T *)L->r.p;
-  if (prof && lev == 0) prof_begin(c, 4);
+  if (prof && lev == 0) prof_begin(c, prof);
   hipLaunchKernelGGL((jacobi_pre_kernel<T>), grid, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->wdinv.p, b,
                      xa, r);
-  if (prof && lev == 0) prof_end(c, 4);
+  if (prof && lev == 0) prof_end(c, prof);
   CHK(csr_spmv_t<T>(c, L->R, r, (T *)N->b.p, 0, (const T *)nullptr));   // b_c = R r
   CHK(amg_cycle_jacobi<T>(c, H, lev + 1, (const T *)N->b.p, (T *)N->x.p, prof));
   CHK(csr_spmv_t<T>(c, L->P, (const T *)N->x.p, x1, 3, xa));            // x1 = xa + P x_c
-  if (prof && lev == 0) prof_begin(c, 4);
+  if (prof && lev == 0) prof_begin(c, prof);
   hipLaunchKernelGGL((jacobi_post_kernel<T>), grid, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->wdinv.p, b,
                      x1, x);
-  if (prof && lev == 0) prof_end(c, 4);
+  if (prof && lev == 0) prof_end(c, prof);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1026,8 +1026,8 @@ static int amg_cycle_cheb(cfdh_ctx *c, AmgHier &H, size_t lev, const double *b, 
 int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x) {
   if (!H.valid || H.lev.empty()) return cfdh_fail(c, CFDH_E_STATE, "AMG hierarchy not built");
   const bool prof = (&H == &c->hS) || (&H == &c->hL);
-  if (H.ncol == 2) return amg_cycle_jacobi<double2>(c, H, 0, (const double2 *)b, (double2 *)x, false);
-  if (c->opt.amg_smooth_degree == 1) return amg_cycle_jacobi<double>(c, H, 0, b, x, prof);
+  if (H.ncol == 2) return amg_cycle_jacobi<double2>(c, H, 0, (const double2 *)b, (double2 *)x, 5);
+  if (c->opt.amg_smooth_degree == 1) return amg_cycle_jacobi<double>(c, H, 0, b, x, prof ? 4 : 0);
   return amg_cycle_cheb(c, H, 0, b, x, prof);
 }
 

@@ -443,6 +443,7 @@ static bool dense_inverse(std::vector<double> &a, int n) {
       for (int k = 0; k < n; k++) { std::swap(a[(size_t)piv * n + k], a[(size_t)col * n + k]); std::swap(inv[(size_t)piv * n + k], inv[(size_t)col * n + k]); }
     double d = 1.0 / a[(size_t)col * n + col];
     for (int k = 0; k < n; k++) { a[(size_t)col * n + k] *= d; inv[(size_t)col * n + k] *= d; }
+#pragma omp parallel for schedule(static) num_threads(cfdh_host_threads()) if (n > 256)
     for (int r = 0; r < n; r++) {
       if (r == col) continue;
       double f = a[(size_t)r * n + col];

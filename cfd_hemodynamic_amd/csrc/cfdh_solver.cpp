@@ -131,7 +131,10 @@ static int build_cc_host(cfdh_ctx *c) {
         }
       Lh.rowptr[i + 1] = (int)Lh.col.size();
     }
-    CHK(cfdh_amg_setup(c, c->hL, Lh, c->singular != 0, 1));
+    bool any_pbc = false;
+    for (int i = 0; i < nvo; i++) any_pbc |= pbc[i] != 0;
+    // a part without pressure-Dirichlet rows has a pure-Neumann (singular) local Laplacian
+    CHK(cfdh_amg_setup(c, c->hL, Lh, c->singular != 0 || !any_pbc, 1));
     c->hL_pbc = pbc;
     c->hL_singular = c->singular;
     std::vector<double> ml(nvo);
@@ -207,7 +210,9 @@ int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
     } else {
       CsrHost S;
       CHK(build_schur_host(c, S));
-      CHK(cfdh_amg_setup(c, c->hS, S, c->singular != 0, 1));
+      bool any_pbc = false;
+      for (int i = 0; i < c->nvo; i++) any_pbc |= (c->h_bcflag[i] & 4u) != 0;
+      CHK(cfdh_amg_setup(c, c->hS, S, c->singular != 0 || !any_pbc, 1));
     }
     c->pc_valid = true;
     c->pc_its_ref = 0;
@@ -229,8 +234,12 @@ static int pc_apply_body(cfdh_ctx *c, const double *r, double *z) {
     CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
     CHK(k_amg_vcycle(c, c->hL, c->pu1.p, c->pu2.p));
     CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, c->pp0.p, c->ccPbc.p, zp));
-    CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));           // t_u = r_u - A01 z_p
-    CHK(k_amg_vcycle(c, c->hA, c->pu0.p, zu));              // z_u = V(A00~) t_u
+    if (c->opt.schur_full) {
+      CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));         // t_u = r_u - A01 z_p
+      CHK(k_amg_vcycle(c, c->hA, c->pu0.p, zu));            // z_u = V(A00~) t_u
+    } else {
+      CHK(v_copy(c, nu, c->pu0.p, zu));                     // block lower-triangular variant
+    }
     return 0;
   }
   CHK(k_cheb_a00(c, ru, c->pu0.p));                       // y_u = C(A00) r_u

@@ -77,13 +77,16 @@ typedef struct orc_ctx {
   /* solver workspace (lazily allocated) */
   csr_t A00f, Sp;         /* ILU factors */
   int *sp_rowptr, *sp_col;
-  /* pc_kind 1 */
-  struct amg_level *amg;
-  int amg_nlev, amg_valid, amg_its_ref, amg_force;
-  double *amg_cinv;
-  int amg_cn;
+  /* pc_kind 1 / 2 */
+  struct amg_hier *hS, *hL, *hA;
+  struct amg_level *Hlev;
+  int amg_valid, amg_its_ref, amg_force;
   double *dinvA, lmaxA;
   int singular;
+  double *Lval, *Ml;      /* P1 stiffness on the vertex graph, lumped mass (geometry) */
+  double *ccMl, cc_alpha, cc_beta;
+  uint8_t *ccPbc;
+  int hL_singular;
   int nthreads;
   char err[256];
 } orc_ctx;
@@ -624,7 +627,7 @@ static void ilu_solve(const csr_t *m, const double *b, double *x) {
 
 typedef struct amg_level {
   csr_t A, P, R;
-  double *dinv, *x, *b, *r, *d0, *d1;
+  double *dinv, *wdinv, *x, *b, *r, *d0, *d1;
   double lmax, lmin;
   int n;
 } amg_level;
@@ -733,6 +736,7 @@ static int amg_aggregate(const csr_t *A, double theta, int *agg) {
   free(agg2);
   for (int i = 0; i < n; i++) {
     if (agg[i] >= 0) continue;
+    if (sptr[i + 1] == sptr[i]) continue; /* isolated unknown (Dirichlet row): no coarse correction */
     agg[i] = na;
     for (int k = sptr[i]; k < sptr[i + 1]; k++) if (agg[scol[k]] < 0) agg[scol[k]] = na;
     na++;
@@ -740,14 +744,29 @@ static int amg_aggregate(const csr_t *A, double theta, int *agg) {
   free(d); free(sptr); free(scol);
   return na;
 }
+typedef struct amg_hier {
+  amg_level lev[16];
+  int nlev;
+  double *cinv;
+  int cn;
+} amg_hier;
+static void level_free(amg_level *L) {
+  free_csr(&L->A); free_csr(&L->P); free_csr(&L->R);
+  free(L->dinv); free(L->wdinv); free(L->x); free(L->b); free(L->r); free(L->d0); free(L->d1);
+  memset(L, 0, sizeof *L);
+}
+static void hier_free(amg_hier *H) {
+  if (!H) return;
+  for (int l = 0; l < H->nlev; l++) level_free(&H->lev[l]);
+  free(H->cinv);
+  memset(H, 0, sizeof *H);
+}
 static void amg_free(orc_ctx *c) {
-  for (int l = 0; l < c->amg_nlev; l++) {
-    amg_level *L = &c->amg[l];
-    free_csr(&L->A); free_csr(&L->P); free_csr(&L->R);
-    free(L->dinv); free(L->x); free(L->b); free(L->r); free(L->d0); free(L->d1);
-  }
-  free(c->amg); c->amg = NULL; c->amg_nlev = 0;
-  free(c->amg_cinv); c->amg_cinv = NULL;
+  hier_free(c->hS); hier_free(c->hL); hier_free(c->hA);
+  free(c->hS); free(c->hL); free(c->hA); c->hS = c->hL = c->hA = NULL;
+  if (c->Hlev) { level_free(c->Hlev); free(c->Hlev); c->Hlev = NULL; }
+  free(c->Lval); free(c->Ml); free(c->ccMl); free(c->ccPbc);
+  c->Lval = c->Ml = c->ccMl = NULL; c->ccPbc = NULL;
 }
 static int dense_inv(double *a, int n) {
   double *inv = (double *)calloc((size_t)n * n, sizeof(double));
@@ -775,43 +794,66 @@ static int dense_inv(double *a, int n) {
   free(inv);
   return 0;
 }
-/* smoothed aggregation hierarchy of S (copied) */
-static int amg_setup(orc_ctx *c, const csr_t *S, const orc_opts *o) {
-  amg_free(c);
-  c->amg = (amg_level *)calloc(16, sizeof(amg_level));
+/* operator copy + Jacobi diagonal + spectral bound + work vectors */
+static void level_setup(amg_level *L, csr_t A, double ratio) {
+  int n = A.n;
+  L->n = n; L->A = A;
+  L->dinv = (double *)malloc(sizeof(double) * n); L->wdinv = (double *)malloc(sizeof(double) * n);
+  for (int i = 0; i < n; i++) {
+    L->dinv[i] = 1.0;
+    for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] == i && A.val[k] != 0.0) L->dinv[i] = 1.0 / A.val[k];
+  }
+  double lm = power_lmax(&A, L->dinv, 15);
+  L->lmax = 1.1 * lm; L->lmin = L->lmax / ratio;
+  double itheta = 2.0 / (L->lmax + L->lmin);
+  for (int i = 0; i < n; i++) {
+    int offd = 0;
+    for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] != i && A.val[k] != 0.0) offd++;
+    L->wdinv[i] = L->dinv[i] * (offd == 0 ? 1.0 : itheta); /* diagonal-only rows are solved exactly */
+  }
+  L->x = (double *)calloc(n, sizeof(double)); L->b = (double *)calloc(n, sizeof(double)); L->r = (double *)calloc(n, sizeof(double));
+  L->d0 = (double *)calloc(n, sizeof(double)); L->d1 = (double *)calloc(n, sizeof(double));
+}
+static csr_t csr_copy(const csr_t *S) {
   csr_t A;
   int nnz = S->rowptr[S->n];
   csr_alloc(&A, S->n, nnz);
   memcpy(A.rowptr, S->rowptr, sizeof(int) * (S->n + 1)); memcpy(A.col, S->col, sizeof(int) * nnz); memcpy(A.val, S->val, sizeof(double) * nnz);
+  return A;
+}
+/* smoothed aggregation hierarchy of S (copied) */
+static int amg_setup(orc_ctx *c, amg_hier *H, const csr_t *S, const orc_opts *o, int singular) {
+  hier_free(H);
+  csr_t A = csr_copy(S);
   for (;;) {
-    amg_level *L = &c->amg[c->amg_nlev++];
+    amg_level *L = &H->lev[H->nlev++];
     int n = A.n;
-    L->n = n; L->A = A;
-    L->dinv = (double *)malloc(sizeof(double) * n);
-    for (int i = 0; i < n; i++) {
-      L->dinv[i] = 1.0;
-      for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] == i && A.val[k] != 0.0) L->dinv[i] = 1.0 / A.val[k];
-    }
-    double lm = power_lmax(&A, L->dinv, 15);
-    L->lmax = 1.1 * lm; L->lmin = L->lmax / o->amg_smooth_ratio;
-    L->x = (double *)calloc(n, sizeof(double)); L->b = (double *)calloc(n, sizeof(double)); L->r = (double *)calloc(n, sizeof(double));
-    L->d0 = (double *)calloc(n, sizeof(double)); L->d1 = (double *)calloc(n, sizeof(double));
-    if (n <= o->amg_max_coarse || c->amg_nlev >= 16) break;
+    level_setup(L, A, o->amg_smooth_ratio);
+    double lm = L->lmax / 1.1;
+    if (n <= o->amg_max_coarse || H->nlev >= 16) break;
     int *agg = (int *)malloc(sizeof(int) * n);
     int na = amg_aggregate(&A, o->amg_theta, agg);
     if (na >= n || na < 1) { free(agg); break; }
     csr_t P0, AP0, P, R, AP, Ac;
     csr_alloc(&P0, n, n);
-    for (int i = 0; i <= n; i++) P0.rowptr[i] = i;
-    for (int i = 0; i < n; i++) { P0.col[i] = agg[i]; P0.val[i] = 1.0; }
+    int np0 = 0;
+    for (int i = 0; i < n; i++) { P0.rowptr[i] = np0; if (agg[i] >= 0) { P0.col[np0] = agg[i]; P0.val[np0] = 1.0; np0++; } }
+    P0.rowptr[n] = np0;
     csr_spgemm(&A, &P0, na, &AP0);
     double omega = 4.0 / 3.0 / lm;
-    /* P = P0 - omega D^-1 A P0 (A has a diagonal, so AP0 contains column agg[i]) */
+    /* P = P0 - omega D^-1 A P0 on aggregated rows (A P0 contains column agg[i] there); empty rows for isolated unknowns */
     csr_alloc(&P, n, AP0.rowptr[n]);
-    memcpy(P.rowptr, AP0.rowptr, sizeof(int) * (n + 1)); memcpy(P.col, AP0.col, sizeof(int) * AP0.rowptr[n]);
-    for (int i = 0; i < n; i++)
-      for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; k++)
-        P.val[k] = -omega * L->dinv[i] * AP0.val[k] + (AP0.col[k] == agg[i] ? 1.0 : 0.0);
+    int np = 0;
+    for (int i = 0; i < n; i++) {
+      P.rowptr[i] = np;
+      if (agg[i] < 0) continue;
+      for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; k++) {
+        P.col[np] = AP0.col[k];
+        P.val[np] = -omega * L->dinv[i] * AP0.val[k] + (AP0.col[k] == agg[i] ? 1.0 : 0.0);
+        np++;
+      }
+    }
+    P.rowptr[n] = np;
     csr_transpose(&P, na, &R);
     csr_spgemm(&A, &P, na, &AP);
     csr_spgemm(&R, &AP, na, &Ac);
@@ -824,9 +866,9 @@ static int amg_setup(orc_ctx *c, const csr_t *S, const orc_opts *o) {
     double *D = (double *)calloc((size_t)n * n, sizeof(double)), tr = 0;
     for (int i = 0; i < n; i++)
       for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) { D[(size_t)i * n + A.col[k]] = A.val[k]; if (A.col[k] == i) tr += fabs(A.val[k]); }
-    if (c->singular) { double al = tr / n / n; for (size_t k = 0; k < (size_t)n * n; k++) D[k] += al; }
+    if (singular) { double al = tr / n / n; for (size_t k = 0; k < (size_t)n * n; k++) D[k] += al; }
     if (dense_inv(D, n)) { free(D); snprintf(c->err, sizeof c->err, "singular coarsest AMG operator"); return -1; }
-    c->amg_cinv = D; c->amg_cn = n;
+    H->cinv = D; H->cn = n;
   }
   return 0;
 }
@@ -854,25 +896,135 @@ static void cheb_smooth(const csr_t *A, const double *dinv, double lmin, double 
     rho = rho_new;
   }
 }
-static void amg_vcycle(orc_ctx *c, const orc_opts *o, int lev, const double *b, double *x) {
-  amg_level *L = &c->amg[lev];
-  if (lev + 1 == c->amg_nlev) {
-    int n = c->amg_cn;
-    for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < n; k++) s += c->amg_cinv[(size_t)i * n + k] * b[k]; x[i] = s; }
+static void amg_vcycle(amg_hier *H, const orc_opts *o, int lev, const double *b, double *x) {
+  amg_level *L = &H->lev[lev];
+  if (lev + 1 == H->nlev) {
+    int n = H->cn;
+    for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < n; k++) s += H->cinv[(size_t)i * n + k] * b[k]; x[i] = s; }
     return;
   }
-  amg_level *N = &c->amg[lev + 1];
+  amg_level *N = &H->lev[lev + 1];
+  if (o->amg_smooth_degree == 1) { /* damped Jacobi, as the GPU's jacobi_pre/post kernels */
+    const int n = L->n;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) L->d0[i] = L->wdinv[i] * b[i];
+    csr_mult(&L->A, L->d0, L->r, 1, b);
+    csr_mult(&L->R, L->r, N->b, 0, NULL);
+    amg_vcycle(H, o, lev + 1, N->b, N->x);
+    csr_mult(&L->P, N->x, L->d0, 2, NULL);
+    csr_mult(&L->A, L->d0, L->r, 1, b);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) x[i] = L->d0[i] + L->wdinv[i] * L->r[i];
+    return;
+  }
   cheb_smooth(&L->A, L->dinv, L->lmin, L->lmax, o->amg_smooth_degree, b, x, 1, L->r, L->d0, L->d1);
   csr_mult(&L->A, x, L->r, 1, b);
   csr_mult(&L->R, L->r, N->b, 0, NULL);
-  amg_vcycle(c, o, lev + 1, N->b, N->x);
+  amg_vcycle(H, o, lev + 1, N->b, N->x);
   csr_mult(&L->P, N->x, x, 2, NULL);
   cheb_smooth(&L->A, L->dinv, L->lmin, L->lmax, o->amg_smooth_degree, b, x, 0, L->r, L->d0, L->d1);
+}
+
+/* pc_kind 2: host side of the Cahouet-Chabard-type preconditioner (same construction as
+ * cfd_hemodynamic_amd/csrc/cfdh_solver.cpp::build_cc_host, written independently) */
+static int cc_setup(orc_ctx *c, const orc_opts *o) {
+  const int nv = c->nv, nu = 2 * nv;
+  if (!c->Lval) { /* geometry: P1 stiffness on the vertex graph + lumped mass */
+    c->Lval = (double *)calloc(c->vptr[nv], sizeof(double));
+    c->Ml = (double *)calloc(nv, sizeof(double));
+    for (int e = 0; e < c->nc; e++) {
+      double xe[3][2], g[3][2], area, h;
+      int vs[3];
+      for (int a = 0; a < 3; a++) { vs[a] = c->cells[3 * e + a]; xe[a][0] = c->x[2 * vs[a]]; xe[a][1] = c->x[2 * vs[a] + 1]; }
+      geom(xe, g, &area, &h);
+      for (int a = 0; a < 3; a++) {
+        c->Ml[vs[a]] += area / 3.0;
+        for (int b = 0; b < 3; b++) c->Lval[c->vptr[vs[a]] + c->cellpos[9 * e + 3 * a + b]] += area * (g[a][0] * g[b][0] + g[a][1] * g[b][1]);
+      }
+    }
+  }
+  if (!c->hA) c->hA = (amg_hier *)calloc(1, sizeof(amg_hier));
+  if (!c->hL) c->hL = (amg_hier *)calloc(1, sizeof(amg_hier));
+  /* scalar proxy (A00_xx + A00_yy)/2 on the vertex graph, zeros dropped */
+  {
+    csr_t Ah;
+    csr_alloc(&Ah, nv, c->vptr[nv]);
+    int n = 0;
+    for (int i = 0; i < nv; i++) {
+      Ah.rowptr[i] = n;
+      int deg = c->vptr[i + 1] - c->vptr[i];
+      const double *rx = c->val + c->rowptr[2 * i], *ry = c->val + c->rowptr[2 * i + 1];
+      for (int k = 0; k < deg; k++) {
+        int w = c->vadj[c->vptr[i] + k];
+        double v = 0.5 * (rx[2 * k] + ry[2 * k + 1]);
+        if (v == 0.0 && w != i) continue;
+        Ah.col[n] = w; Ah.val[n] = v; n++;
+      }
+    }
+    Ah.rowptr[nv] = n;
+    int rc = amg_setup(c, c->hA, &Ah, o, 0);
+    free_csr(&Ah);
+    if (rc) return rc;
+  }
+  uint8_t *pbc = (uint8_t *)malloc(nv);
+  int changed = (c->ccPbc == NULL) || c->hL_singular != c->singular;
+  for (int i = 0; i < nv; i++) { pbc[i] = c->isbc[nu + i]; if (c->ccPbc && c->ccPbc[i] != pbc[i]) changed = 1; }
+  if (changed) {
+    csr_t Lh;
+    csr_alloc(&Lh, nv, c->vptr[nv]);
+    int n = 0;
+    for (int i = 0; i < nv; i++) {
+      Lh.rowptr[i] = n;
+      if (pbc[i]) { Lh.col[n] = i; Lh.val[n] = 1.0; n++; continue; }
+      for (int k = c->vptr[i]; k < c->vptr[i + 1]; k++) { int w = c->vadj[k]; if (pbc[w]) continue; Lh.col[n] = w; Lh.val[n] = c->Lval[k]; n++; }
+    }
+    Lh.rowptr[nv] = n;
+    int rc = amg_setup(c, c->hL, &Lh, o, c->singular);
+    free_csr(&Lh);
+    if (rc) { free(pbc); return rc; }
+    free(c->ccPbc); c->ccPbc = pbc; c->hL_singular = c->singular;
+    free(c->ccMl); c->ccMl = (double *)malloc(sizeof(double) * nv);
+    for (int i = 0; i < nv; i++) c->ccMl[i] = pbc[i] ? 0.0 : c->Ml[i];
+  } else free(pbc);
+  c->cc_alpha = 2.0 * c->rho / c->dt; c->cc_beta = c->mu;
+  {
+    csr_t Hh;
+    csr_alloc(&Hh, nv, c->vptr[nv]);
+    int n = 0;
+    for (int i = 0; i < nv; i++) {
+      Hh.rowptr[i] = n;
+      if (c->ccPbc[i]) { Hh.col[n] = i; Hh.val[n] = 1.0; n++; continue; }
+      int deg = c->vptr[i + 1] - c->vptr[i];
+      const double *rp = c->val + c->rowptr[nu + i] + 2 * deg; /* A11 row */
+      int kd = 0;
+      while (c->vadj[c->vptr[i] + kd] != i) kd++;
+      double Ld = c->Lval[c->vptr[i] + kd];
+      double T = Ld > 0 ? rp[kd] / Ld : 0.0;
+      for (int k = 0; k < deg; k++) {
+        int w = c->vadj[c->vptr[i] + k];
+        if (c->ccPbc[w]) continue;
+        double v = c->cc_beta * rp[k];
+        if (w == i) v += (1.0 + c->cc_alpha * T) * c->Ml[i];
+        Hh.col[n] = w; Hh.val[n] = v; n++;
+      }
+    }
+    Hh.rowptr[nv] = n;
+    if (c->Hlev) level_free(c->Hlev); else c->Hlev = (amg_level *)calloc(1, sizeof(amg_level));
+    level_setup(c->Hlev, Hh, 8.0);
+  }
+  return 0;
 }
 
 /* PC setup for the current Jacobian: ILU(0) of A00 and of Sp = A11 - A10 D^-1 A01 */
 static int pc_setup(orc_ctx *c, const orc_opts *o) {
   const int nv = c->nv, nu = 2 * nv;
+  if (o->pc_kind == 2) {
+    if (!c->amg_valid || c->amg_force) {
+      if (cc_setup(c, o)) return -1;
+      c->amg_valid = 1; c->amg_force = 0; c->amg_its_ref = 0;
+    }
+    return 0;
+  }
   /* A00 copy */
   csr_t *A = &c->A00f;
   if (!A->rowptr) {
@@ -946,7 +1098,8 @@ static int pc_setup(orc_ctx *c, const orc_opts *o) {
     A00v = *A;
     c->lmaxA = 1.15 * power_lmax(&A00v, Dinv, 8);
     if (!c->amg_valid || c->amg_force) {
-      if (amg_setup(c, S, o)) return -1;
+      if (!c->hS) c->hS = (amg_hier *)calloc(1, sizeof(amg_hier));
+      if (amg_setup(c, c->hS, S, o, c->singular)) return -1;
       c->amg_valid = 1; c->amg_force = 0; c->amg_its_ref = 0;
     }
     return 0;
@@ -1038,6 +1191,39 @@ typedef struct {
 
 static void pc_apply(orc_ctx *c, pc_ws *p, const double *r, double *z) {
   const int nv = c->nv, nu = 2 * nv;
+  if (p->o->pc_kind == 2) {
+    const orc_opts *o = p->o;
+    /* y_u = V(A~) r_u, component by component */
+    for (int cpt = 0; cpt < 2; cpt++) {
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < nv; i++) p->cd0[i] = r[2 * i + cpt];
+      amg_vcycle(c->hA, o, 0, p->cd0, p->cd1);
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < nv; i++) p->yu[2 * i + cpt] = p->cd1[i];
+    }
+    blk_mult(c, 3, p->yu, p->tp);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nv; i++) p->tp[i] = r[nu + i] - p->tp[i];
+    /* z_p = (a' L^-1 + b' M_l^-1) H^-1 t_p */
+    amg_level *Hl = c->Hlev;
+    cheb_smooth(&Hl->A, Hl->dinv, Hl->lmin, Hl->lmax, 3, p->tp, p->yp, 1, Hl->r, Hl->d0, Hl->d1);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nv; i++) p->cd0[i] = c->ccMl[i] * p->yp[i];
+    amg_vcycle(c->hL, o, 0, p->cd0, p->cd1);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nv; i++) z[nu + i] = c->ccPbc[i] ? p->tp[i] : c->cc_alpha * p->cd1[i] + c->cc_beta * p->yp[i];
+    blk_mult(c, 2, z + nu, p->tu);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nu; i++) p->tu[i] = r[i] - p->tu[i];
+    for (int cpt = 0; cpt < 2; cpt++) {
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < nv; i++) p->cd0[i] = p->tu[2 * i + cpt];
+      amg_vcycle(c->hA, o, 0, p->cd0, p->cd1);
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < nv; i++) z[2 * i + cpt] = p->cd1[i];
+    }
+    return;
+  }
   if (p->o->pc_kind == 1) {
     const orc_opts *o = p->o;
     const csr_t *A = &c->A00f;
@@ -1045,7 +1231,7 @@ static void pc_apply(orc_ctx *c, pc_ws *p, const double *r, double *z) {
     cheb_smooth(A, c->dinvA, lmin, c->lmaxA, o->cheb_degree, r, p->yu, 1, p->cr, p->cd0, p->cd1);
     blk_mult(c, 3, p->yu, p->tp);
     for (int i = 0; i < nv; i++) p->tp[i] = r[nu + i] - p->tp[i];
-    amg_vcycle(c, o, 0, p->tp, z + nu);
+    amg_vcycle(c->hS, o, 0, p->tp, z + nu);
     blk_mult(c, 2, z + nu, p->tu);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < nu; i++) p->tu[i] = r[i] - p->tu[i];
@@ -1140,7 +1326,7 @@ void orc_default_opts(orc_opts *o) {
   o->sub_rtol = 1e-5; o->sub_max_it = 10000; o->sub_restart = 30;
   o->remove_p_mean = 1; o->verbose = 0;
   o->pc_kind = 0; o->cheb_degree = 3; o->cheb_ratio = 10.0; o->amg_smooth_degree = 1; o->amg_smooth_ratio = 8.0;
-  o->amg_theta = 0.08; o->amg_max_coarse = 300;
+  o->amg_theta = 0.08; o->amg_max_coarse = 1000;
 }
 
 /* One time step: Newton on the monolithic vector xv (in: initial guess = previous
@@ -1176,7 +1362,7 @@ int orc_solve_step(orc_ctx *c, double *xv, const orc_opts *o, orc_stats *st) {
     if (pc_setup(c, o)) { reason = -3; break; }
     int its_before = st->krylov_its;
     int kr = fgmres(c, o, &pc, F, d, singular, &st->krylov_its);
-    if (o->pc_kind == 1) { /* adaptive lagging of the hierarchy, as in libcfdh */
+    if (o->pc_kind >= 1) { /* adaptive lagging of the hierarchy, as in libcfdh */
       int kits = st->krylov_its - its_before;
       if (c->amg_its_ref == 0) c->amg_its_ref = kits > 0 ? kits : 1;
       else if (kits > (3 * c->amg_its_ref) / 2 + 5) c->amg_force = 1;

@@ -275,3 +275,31 @@ def test_full_size_steps_converge_and_are_consistent(big):
     assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
     assert abs(res[0][1] - res[1][1]) <= 1e-7 * res[1][1]
     assert res[1][2] < 1e-8  # |F| after the tight solve, from |F0| ~ 3e2
+
+
+def test_lid_cavity_config_c2():
+    """BASELINE configs[1]: lid_driven2D P1/P1 nx=288 -> 250 563 DOF, singular pressure.  Size-independent
+    checks: Newton/Krylov converge, the constant-pressure mode stays projected out, both preconditioners
+    (SELFP/Chebyshev and Cahouet-Chabard/AMG) reach the same step solution."""
+    case = lid_case(288, dt=0.01, mu=0.01)
+    nv = case.nv
+    assert 3 * nv == 250563
+    sols = []
+    for pc_type in (1, 0):
+        ctx = make_ctx(case)
+        o = ctx.default_options()
+        o.pc_type = pc_type
+        o.snes_rtol, o.ksp_rtol = 1e-10, 1e-8
+        ctx.set_options(o)
+        z2, z1 = np.zeros(2 * nv), np.zeros(nv)
+        ctx.set_state(u_prev=z2, p_prev=z1, u=z2, p=z1)
+        for _ in range(2):
+            st = ctx.solve_step()
+            assert st.reason > 0 and st.newton_its <= 6
+            ctx.advance()
+        u, p = ctx.get_solution()
+        assert abs(p.mean()) <= 1e-10 * np.abs(p).max()
+        sols.append((u, p, st.krylov_its))
+        ctx.close()
+    assert np.linalg.norm(sols[0][0] - sols[1][0]) <= 1e-7 * np.linalg.norm(sols[1][0])
+    assert np.linalg.norm(sols[0][1] - sols[1][1]) <= 1e-6 * np.linalg.norm(sols[1][1])

@@ -17,8 +17,10 @@ NAMES = {
     "spmv_full_kernel": "spmv_full_block3x3",
     "asm_kernel<1>": "asm_residual_jacobian",
     "moments_kernel": "tau_moments",
-    "jacobi_pre_kernel": "cheb_step_Sp",
-    "jacobi_post_kernel": "cheb_step_Sp",
+    "jacobi_pre_kernel<double2>": "amg_sweep_velocity_2rhs",
+    "jacobi_post_kernel<double2>": "amg_sweep_velocity_2rhs",
+    "jacobi_pre_kernel<double>": "amg_sweep_pressure",
+    "jacobi_post_kernel<double>": "amg_sweep_pressure",
 }
 
 
