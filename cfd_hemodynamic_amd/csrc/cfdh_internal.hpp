@@ -57,6 +57,12 @@ struct CsrDev {
   int n = 0, m = 0, nnz = 0;
   dbuf<int> rowptr, col;
   dbuf<double> val;
+  // SELL-64 copy (sliced ELLPACK, slices of 64 consecutive rows, column-major inside a slice):
+  // one lane per row streams fully coalesced, no cross-lane reduction.  sptr[s] = first padded
+  // entry of slice s (in units of entries); width of slice s = (sptr[s+1]-sptr[s]) / 64.
+  int nslice = 0;
+  dbuf<int> sptr, scol;
+  dbuf<double> sval, svalw;  // svalw: values scaled by a column weight (Jacobi pre-sweep), optional
 };
 
 struct AmgLevel {

@@ -976,6 +976,59 @@ __global__ __launch_bounds__(TPB) void jacobi_post_kernel(int n, const int *__re
   }
 }
 
+// ---- SELL-64 variants: one lane per row, fully coalesced matrix stream, no cross-lane reduction
+template <int MODE, typename T>
+__global__ __launch_bounds__(TPB) void sell_spmv_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                        const double *__restrict__ sval, const T *__restrict__ x,
+                                                        T *__restrict__ y, const T *__restrict__ b) {
+  const int row = blockIdx.x * TPB + threadIdx.x;
+  if (row >= n) return;
+  const int sl = row >> 6, lane = row & 63;
+  const int p0 = sptr[sl], w = (sptr[sl + 1] - p0) >> 6;
+  T a = vzero((const T *)nullptr);
+  for (int k = 0; k < w; k++) {
+    const int p = p0 + k * 64 + lane;
+    a = vfma(sval[p], x[scol[p]], a);
+  }
+  if (MODE == 0) y[row] = a;
+  else if (MODE == 1) y[row] = vsub(b[row], a);
+  else if (MODE == 2) y[row] = vadd(y[row], a);
+  else y[row] = vadd(b[row], a);
+}
+template <typename T>
+__global__ __launch_bounds__(TPB) void sell_jacobi_pre_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                              const double *__restrict__ svalw, const double *__restrict__ wdinv,
+                                                              const T *__restrict__ b, T *__restrict__ xa, T *__restrict__ r) {
+  const int row = blockIdx.x * TPB + threadIdx.x;
+  if (row >= n) return;
+  const int sl = row >> 6, lane = row & 63;
+  const int p0 = sptr[sl], w = (sptr[sl + 1] - p0) >> 6;
+  T a = vzero((const T *)nullptr);
+  for (int k = 0; k < w; k++) {
+    const int p = p0 + k * 64 + lane;
+    a = vfma(svalw[p], b[scol[p]], a);   // A (w D^-1 b): the column weight is folded into svalw
+  }
+  const T bi = b[row];
+  xa[row] = vscale(wdinv[row], bi);
+  r[row] = vsub(bi, a);
+}
+template <typename T>
+__global__ __launch_bounds__(TPB) void sell_jacobi_post_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                               const double *__restrict__ sval, const double *__restrict__ wdinv,
+                                                               const T *__restrict__ b, const T *__restrict__ xin,
+                                                               T *__restrict__ xout) {
+  const int row = blockIdx.x * TPB + threadIdx.x;
+  if (row >= n) return;
+  const int sl = row >> 6, lane = row & 63;
+  const int p0 = sptr[sl], w = (sptr[sl + 1] - p0) >> 6;
+  T a = vzero((const T *)nullptr);
+  for (int k = 0; k < w; k++) {
+    const int p = p0 + k * 64 + lane;
+    a = vfma(sval[p], xin[scol[p]], a);
+  }
+  xout[row] = vadd(xin[row], vscale(wdinv[row], vsub(b[row], a)));
+}
+
 template <typename T>
 static int amg_cycle_jacobi(cfdh_ctx *c, AmgHier &H, size_t lev, const T *b, T *x, int prof) {
   AmgLevel *L = H.lev[lev];
@@ -986,18 +1039,33 @@ static int amg_cycle_jacobi(cfdh_ctx *c, AmgHier &H, size_t lev, const T *b, T *
   }
   AmgLevel *N = H.lev[lev + 1];
   const int n = L->n;
-  dim3 grid((unsigned)((8ll * n + TPB - 1) / TPB)), block(TPB);
+  // short, regular rows (the finest levels of FE operators): SELL-64, one lane per row;
+  // long coarse-level rows: 8 lanes per row over CSR
+  const bool sell = L->A.nnz <= 12ll * n && n >= 16384;
+  dim3 block(TPB), gridS((unsigned)((n + TPB - 1) / TPB)), gridC((unsigned)((8ll * n + TPB - 1) / TPB));
   T *xa = (T *)L->d0.p, *x1 = (T *)L->d1.p, *r = (T *)L->r.p;
   if (prof && lev == 0) prof_begin(c, prof);
-  hipLaunchKernelGGL((jacobi_pre_kernel<T>), grid, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->wdinv.p, b,
-                     xa, r);
+  if (sell)
+    hipLaunchKernelGGL((sell_jacobi_pre_kernel<T>), gridS, block, 0, c->stream, n, L->A.sptr.p, L->A.scol.p, L->A.svalw.p,
+                       L->wdinv.p, b, xa, r);
+  else
+    hipLaunchKernelGGL((jacobi_pre_kernel<T>), gridC, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p,
+                       L->wdinv.p, b, xa, r);
   if (prof && lev == 0) prof_end(c, prof);
   CHK(csr_spmv_t<T>(c, L->R, r, (T *)N->b.p, 0, (const T *)nullptr));   // b_c = R r
   CHK(amg_cycle_jacobi<T>(c, H, lev + 1, (const T *)N->b.p, (T *)N->x.p, prof));
-  CHK(csr_spmv_t<T>(c, L->P, (const T *)N->x.p, x1, 3, xa));            // x1 = xa + P x_c
+  if (sell)
+    hipLaunchKernelGGL((sell_spmv_kernel<3, T>), gridS, block, 0, c->stream, n, L->P.sptr.p, L->P.scol.p, L->P.sval.p,
+                       (const T *)N->x.p, x1, (const T *)xa);           // x1 = xa + P x_c
+  else
+    CHK(csr_spmv_t<T>(c, L->P, (const T *)N->x.p, x1, 3, xa));
   if (prof && lev == 0) prof_begin(c, prof);
-  hipLaunchKernelGGL((jacobi_post_kernel<T>), grid, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p, L->wdinv.p, b,
-                     x1, x);
+  if (sell)
+    hipLaunchKernelGGL((sell_jacobi_post_kernel<T>), gridS, block, 0, c->stream, n, L->A.sptr.p, L->A.scol.p, L->A.sval.p,
+                       L->wdinv.p, b, x1, x);
+  else
+    hipLaunchKernelGGL((jacobi_post_kernel<T>), gridC, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p,
+                       L->wdinv.p, b, x1, x);
   if (prof && lev == 0) prof_end(c, prof);
   HIPCHK(c, hipGetLastError());
   return 0;

@@ -422,11 +422,38 @@ static void transpose_host(const CsrHost &A, CsrHost &T) {
     for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) { int p = fill[A.col[k]]++; T.col[p] = i; T.val[p] = A.val[k]; }
 }
 
-static int upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D) {
+// colw (optional): per-column weights for the scaled copy svalw[k] = val[k] * colw[col[k]]
+static int upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<double> *colw = nullptr) {
   D.n = H.n; D.m = H.m; D.nnz = H.nnz();
   HIPCHK(c, D.rowptr.upload(H.rowptr, c->stream));
   HIPCHK(c, D.col.upload(H.col, c->stream));
   HIPCHK(c, D.val.upload(H.val, c->stream));
+  // SELL-64
+  const int ns = (H.n + 63) / 64;
+  std::vector<int> sptr(ns + 1, 0);
+  for (int sl = 0; sl < ns; sl++) {
+    int w = 0;
+    for (int r = sl * 64; r < std::min(H.n, sl * 64 + 64); r++) w = std::max(w, H.rowptr[r + 1] - H.rowptr[r]);
+    sptr[sl + 1] = sptr[sl] + 64 * w;
+  }
+  std::vector<int> scol((size_t)sptr[ns], 0);
+  std::vector<double> sval((size_t)sptr[ns], 0.0), svalw;
+  if (colw) svalw.assign((size_t)sptr[ns], 0.0);
+  for (int r = 0; r < H.n; r++) {
+    const int sl = r >> 6, lane = r & 63;
+    for (int k = H.rowptr[r], j = 0; k < H.rowptr[r + 1]; k++, j++) {
+      const size_t p = (size_t)sptr[sl] + (size_t)j * 64 + lane;
+      scol[p] = H.col[k]; sval[p] = H.val[k];
+      if (colw) svalw[p] = H.val[k] * (*colw)[H.col[k]];
+    }
+    // padding keeps column 0 with value 0: a harmless in-range gather
+  }
+  D.nslice = ns;
+  HIPCHK(c, D.sptr.upload(sptr, c->stream));
+  HIPCHK(c, D.scol.upload(scol, c->stream));
+  HIPCHK(c, D.sval.upload(sval, c->stream));
+  if (colw) HIPCHK(c, D.svalw.upload(svalw, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // host temporaries go out of scope
   return 0;
 }
 
@@ -465,7 +492,6 @@ int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, i
   const double lm = lam_max_host(A, dinv, 15);
   L.lmax = 1.1 * lm;
   L.lmin = L.lmax / ratio;
-  CHK(upload_csr(c, A, L.A));
   HIPCHK(c, L.dinv.upload(dinv, c->stream));
   {
     // damped-Jacobi weights: 1/theta, theta = (lmax+lmin)/2; rows that are diagonal-only are solved exactly
@@ -477,6 +503,7 @@ int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, i
       w[i] = dinv[i] * (offd == 0 ? 1.0 : itheta);
     }
     HIPCHK(c, L.wdinv.upload(w, c->stream));
+    CHK(upload_csr(c, A, L.A, &w));
   }
   const size_t nn = (size_t)A.n * ncol;
   HIPCHK(c, L.x.alloc(nn)); HIPCHK(c, L.b.alloc(nn)); HIPCHK(c, L.r.alloc(nn));
