@@ -172,7 +172,7 @@ int k_moments(cfdh_ctx *c) {
 // ---------------------------------------------------------------- fused assembly
 struct AsmArgs {
   const double *coords, *mom, *x, *un, *bcval, *bcmult;
-  const int *vptr, *vdiag, *inc_cell, *blk_row, *blk_inc, *blk_maxrank, *blk_vptr, *blk_vlist, *blk_cptr, *blk_clist;
+  const int *vptr, *vdiag, *inc_cell, *blk_row, *blk_inc, *blk_maxrank, *blk_vptr, *blk_vlist, *blk_cptr, *blk_clist, *wave_maxlen;
   const unsigned *inc_slot, *inc_rank, *inc_loc;
   const unsigned char *cflag, *bcflag;
   double *A00, *A01, *A10, *A11, *F;
@@ -187,15 +187,10 @@ struct AsmArgs {
 // coordinates, iterate, u_prev, Dirichlet flags, and the 64-B tau-moment records; every lane then
 // gathers its element from LDS only (a per-lane gather from global memory costs one L1 line
 // per lane per load and made the first version of this kernel L1/TA-bound).
-template <int MODE, int OCC = 3, bool ATOMIC = false>
+template <int MODE, int OCC = 3>
 __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
   constexpr bool JAC = (MODE != 0);
   constexpr bool WJ = (MODE == 1);
-  __shared__ double sA00[WJ ? CFDH_MAX_SLOTS * 4 : 1];
-  __shared__ double sA01[WJ ? CFDH_MAX_SLOTS * 2 : 1];
-  __shared__ double sA10[WJ ? CFDH_MAX_SLOTS * 2 : 1];
-  __shared__ double sA11[WJ ? CFDH_MAX_SLOTS : 1];
-  __shared__ double sF[CFDH_MAX_ROWS * 3];
   __shared__ double2 sX[CFDH_MAX_BV], sU[CFDH_MAX_BV], sUn[CFDH_MAX_BV];
   __shared__ double sP[CFDH_MAX_BV];
   __shared__ int sVid[CFDH_MAX_BV];
@@ -205,10 +200,7 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
   __shared__ int sRow[CFDH_MAX_ROWS + 1];
   const int t = threadIdx.x, blk = blockIdx.x;
   const int row0 = p.blk_row[blk], row1 = p.blk_row[blk + 1];
-  const int inc0 = p.blk_inc[blk], ninc = p.blk_inc[blk + 1] - inc0;
-  const int s0 = p.vptr[row0], nslots = p.vptr[row1] - s0;
   const int nrows = row1 - row0;
-  const int maxr = p.blk_maxrank[blk];
   const int nvo = p.nvo;
   {
     const int v0 = p.blk_vptr[blk], nvl = p.blk_vptr[blk + 1] - v0;
@@ -228,32 +220,26 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
       sMom[i] = *(const double2 *)(p.mom + 8 * (size_t)cid + 2 * (i & 3));
     }
     for (int i = t; i < ncl; i += CFDH_MAX_INC) sCf[i] = p.cflag[p.blk_clist[c0 + i]];
-    for (int i = t; i <= nrows; i += CFDH_MAX_INC) sRow[i] = p.vptr[row0 + i] - s0;
+    for (int i = t; i <= nrows; i += CFDH_MAX_INC) sRow[i] = p.vptr[row0 + i];
   }
-  if (WJ) {
-    for (int i = t; i < nslots * 4; i += CFDH_MAX_INC) sA00[i] = 0.0;
-    for (int i = t; i < nslots * 2; i += CFDH_MAX_INC) { sA01[i] = 0.0; sA10[i] = 0.0; }
-    for (int i = t; i < nslots; i += CFDH_MAX_INC) sA11[i] = 0.0;
-  }
-  for (int i = t; i < nrows * 3; i += CFDH_MAX_INC) sF[i] = 0.0;
   __syncthreads();
 
-  const bool active = t < ninc;
+  const size_t lk = (size_t)blk * CFDH_MAX_INC + t;
+  const unsigned loc = p.inc_loc[lk], meta = p.inc_slot[lk], seg = p.inc_rank[lk];
+  const bool active = loc != 0xFFFFFFFFu;
   double Fr[3] = {0, 0, 0};
-  double J00[3][2][2], J01[3][2], J10[3][2], J11[3];
-  int sl[3] = {0, 0, 0}, rk[3] = {0, 0, 0}, rloc = 0;
+  double J00[3][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}}, J01[3][2] = {{0, 0}, {0, 0}, {0, 0}},
+         J10[3][2] = {{0, 0}, {0, 0}, {0, 0}}, J11[3] = {0, 0, 0};
+  int row = 0;
+  unsigned fl0 = 0;
+  double xrow[3] = {0, 0, 0};
   if (active) {
-    const int k = inc0 + t;
-    const int a = p.inc_cell[k] & 3;
-    const unsigned slots = p.inc_slot[k], ranks = p.inc_rank[k], loc = p.inc_loc[k];
+    const int a = (meta >> 24) & 3;
     const int lc = loc & 255;
     const int lv[3] = {(int)((loc >> 8) & 255), (int)((loc >> 16) & 255), (int)((loc >> 24) & 255)};
     const int vv[3] = {sVid[lv[0]], sVid[lv[1]], sVid[lv[2]]};
     const int v0 = vv[0], v1 = vv[1], v2 = vv[2];
-    rloc = v0 - row0;
-    const int sbase = sRow[rloc];
-    sl[0] = sbase + (slots & 255); sl[1] = sbase + ((slots >> 8) & 255); sl[2] = sbase + ((slots >> 16) & 255);
-    rk[0] = ranks & 255; rk[1] = (ranks >> 8) & 255; rk[2] = (ranks >> 16) & 255;
+    row = v0;
     unsigned cf = sCf[lc];
     cf = ((cf >> a) | (cf << (3 - a))) & 7u;
     // moments, rotated
@@ -404,8 +390,10 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
       }
     }
     // ---- Dirichlet: lifting F += J[:,bc](g - x), zero bc columns and rows
-    const unsigned fl0 = sFl[lv[0]], fl1 = sFl[lv[1]], fl2 = sFl[lv[2]];
+    fl0 = sFl[lv[0]];
+    const unsigned fl1 = sFl[lv[1]], fl2 = sFl[lv[2]];
     (void)v1; (void)v2;
+    xrow[0] = ue[0][0]; xrow[1] = ue[0][1]; xrow[2] = pe[0];
     if (fl0 | fl1 | fl2) {
       const unsigned flb[3] = {fl0, fl1, fl2};
 #pragma unroll
@@ -446,71 +434,78 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
       }
     }
   }
-  __syncthreads();
-  // ---- deterministic accumulation: in round r only the r-th contribution of a slot adds
-  if (ATOMIC) {  // experiment: unordered LDS atomics (not bitwise reproducible)
-    if (active) {
-#pragma unroll
-      for (int b = 0; b < 3; b++) {
-        if (WJ) {
-          const int s = sl[b];
-          atomicAdd(&sA00[4 * s + 0], J00[b][0][0]); atomicAdd(&sA00[4 * s + 1], J00[b][0][1]);
-          atomicAdd(&sA00[4 * s + 2], J00[b][1][0]); atomicAdd(&sA00[4 * s + 3], J00[b][1][1]);
-          atomicAdd(&sA01[2 * s + 0], J01[b][0]); atomicAdd(&sA01[2 * s + 1], J01[b][1]);
-          atomicAdd(&sA10[2 * s + 0], J10[b][0]); atomicAdd(&sA10[2 * s + 1], J10[b][1]);
-          atomicAdd(&sA11[s], J11[b]);
-        }
-        if (b == 0) { atomicAdd(&sF[3 * rloc], Fr[0]); atomicAdd(&sF[3 * rloc + 1], Fr[1]); atomicAdd(&sF[3 * rloc + 2], Fr[2]); }
-      }
-    }
-    __syncthreads();
-  }
-  for (int r = 0; r < (ATOMIC ? 0 : maxr); r++) {
-    if (active) {
-#pragma unroll
-      for (int b = 0; b < 3; b++) {
-        if (rk[b] == r) {
-          if (WJ) {
-            const int s = sl[b];
-            sA00[4 * s + 0] += J00[b][0][0]; sA00[4 * s + 1] += J00[b][0][1];
-            sA00[4 * s + 2] += J00[b][1][0]; sA00[4 * s + 3] += J00[b][1][1];
-            sA01[2 * s + 0] += J01[b][0]; sA01[2 * s + 1] += J01[b][1];
-            sA10[2 * s + 0] += J10[b][0]; sA10[2 * s + 1] += J10[b][1];
-            sA11[s] += J11[b];
-          }
-          if (b == 0) { sF[3 * rloc] += Fr[0]; sF[3 * rloc + 1] += Fr[1]; sF[3 * rloc + 2] += Fr[2]; }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  // ---- Dirichlet rows: diagonal = number of bc objects, F = x - g
-  if (t < nrows) {
-    const int row = row0 + t;
-    const unsigned fl = p.bcflag[row];
-    if (fl) {
-      const int dsl = p.vdiag[row] - s0;
-      if (fl & 1u) { if (WJ) sA00[4 * dsl + 0] = p.bcmult[3 * row]; sF[3 * t] = p.x[2 * row] - p.bcval[3 * row]; }
-      if (fl & 2u) { if (WJ) sA00[4 * dsl + 3] = p.bcmult[3 * row + 1]; sF[3 * t + 1] = p.x[2 * row + 1] - p.bcval[3 * row + 1]; }
-      if (fl & 4u) { if (WJ) sA11[dsl] = p.bcmult[3 * row + 2]; sF[3 * t + 2] = p.x[2 * nvo + row] - p.bcval[3 * row + 2]; }
-    }
-  }
-  __syncthreads();
-  // ---- coalesced write-out of the block's contiguous CSR segment
+  // ---- wavefront-level segmented reduction (all 64 lanes take part; idle lanes carry zeros)
+  const int lane = t & 63;
+  const int seg_pos = seg & 255, seg_len = (seg >> 8) & 255, prev_off = (int)((seg >> 16) & 255) - 64;
+  const bool has_prev = (meta >> 27) & 1u, emit_v2 = (meta >> 26) & 1u;
+  const int wmax = p.wave_maxlen[blk * (CFDH_MAX_INC / 64) + (t >> 6)];
   if (WJ) {
-    double *o00 = p.A00 + 4 * (size_t)s0, *o01 = p.A01 + 2 * (size_t)s0, *o10 = p.A10 + 2 * (size_t)s0, *o11 = p.A11 + (size_t)s0;
-    for (int i = t; i < nslots * 2; i += CFDH_MAX_INC) {
-      ((double2 *)o00)[i] = make_double2(sA00[2 * i], sA00[2 * i + 1]);
+    // off-diagonal block of the edge (i, v1): this cell's B1 plus B2 of the previous cell of the fan
+    const int src = lane + (has_prev ? prev_off : 0);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) { const double v = __shfl(J00[2][i][j], src); if (has_prev) J00[1][i][j] += v; }
+      { const double v = __shfl(J01[2][i], src); if (has_prev) J01[1][i] += v; }
+      { const double v = __shfl(J10[2][i], src); if (has_prev) J10[1][i] += v; }
     }
-    for (int i = t; i < nslots; i += CFDH_MAX_INC) {
-      ((double2 *)o01)[i] = make_double2(sA01[2 * i], sA01[2 * i + 1]);
-      ((double2 *)o10)[i] = make_double2(sA10[2 * i], sA10[2 * i + 1]);
-      o11[i] = sA11[i];
+    { const double v = __shfl(J11[2], src); if (has_prev) J11[1] += v; }
+  }
+  // diagonal block and residual: sum over the lanes of the row, result in its first lane
+  for (int off = 1; off < wmax; off <<= 1) {
+    const bool take = active && (seg_pos + off < seg_len);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { const double v = __shfl_down(Fr[i], off); if (take) Fr[i] += v; }
+    if (WJ) {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) { const double v = __shfl_down(J00[0][i][j], off); if (take) J00[0][i][j] += v; }
+        { const double v = __shfl_down(J01[0][i], off); if (take) J01[0][i] += v; }
+        { const double v = __shfl_down(J10[0][i], off); if (take) J10[0][i] += v; }
+      }
+      { const double v = __shfl_down(J11[0], off); if (take) J11[0] += v; }
     }
   }
-  for (int i = t; i < nrows; i += CFDH_MAX_INC) {
-    ((double2 *)(p.F + 2 * (size_t)row0))[i] = make_double2(sF[3 * i], sF[3 * i + 1]);
-    p.F[2 * (size_t)nvo + row0 + i] = sF[3 * i + 2];
+  // ---- every block of the row now sits complete in exactly one lane: plain stores
+  if (active) {
+    const size_t sb = (size_t)sRow[row - row0];
+    if (WJ) {
+      {
+        const size_t s1 = sb + ((meta >> 8) & 255);
+        *(double2 *)(p.A00 + 4 * s1) = make_double2(J00[1][0][0], J00[1][0][1]);
+        *(double2 *)(p.A00 + 4 * s1 + 2) = make_double2(J00[1][1][0], J00[1][1][1]);
+        *(double2 *)(p.A01 + 2 * s1) = make_double2(J01[1][0], J01[1][1]);
+        *(double2 *)(p.A10 + 2 * s1) = make_double2(J10[1][0], J10[1][1]);
+        p.A11[s1] = J11[1];
+      }
+      if (emit_v2) {
+        const size_t s2 = sb + ((meta >> 16) & 255);
+        *(double2 *)(p.A00 + 4 * s2) = make_double2(J00[2][0][0], J00[2][0][1]);
+        *(double2 *)(p.A00 + 4 * s2 + 2) = make_double2(J00[2][1][0], J00[2][1][1]);
+        *(double2 *)(p.A01 + 2 * s2) = make_double2(J01[2][0], J01[2][1]);
+        *(double2 *)(p.A10 + 2 * s2) = make_double2(J10[2][0], J10[2][1]);
+        p.A11[s2] = J11[2];
+      }
+    }
+    if (seg_pos == 0) {
+      // Dirichlet rows: diagonal = number of bc objects, F = x - g (everything else in the row is zero)
+      if (fl0) {
+        if (fl0 & 1u) { J00[0][0][0] = p.bcmult[3 * row]; Fr[0] = xrow[0] - p.bcval[3 * row]; }
+        if (fl0 & 2u) { J00[0][1][1] = p.bcmult[3 * row + 1]; Fr[1] = xrow[1] - p.bcval[3 * row + 1]; }
+        if (fl0 & 4u) { J11[0] = p.bcmult[3 * row + 2]; Fr[2] = xrow[2] - p.bcval[3 * row + 2]; }
+      }
+      if (WJ) {
+        const size_t s0 = sb + (meta & 255);
+        *(double2 *)(p.A00 + 4 * s0) = make_double2(J00[0][0][0], J00[0][0][1]);
+        *(double2 *)(p.A00 + 4 * s0 + 2) = make_double2(J00[0][1][0], J00[0][1][1]);
+        *(double2 *)(p.A01 + 2 * s0) = make_double2(J01[0][0], J01[0][1]);
+        *(double2 *)(p.A10 + 2 * s0) = make_double2(J10[0][0], J10[0][1]);
+        p.A11[s0] = J11[0];
+      }
+      *(double2 *)(p.F + 2 * (size_t)row) = make_double2(Fr[0], Fr[1]);
+      p.F[2 * (size_t)nvo + row] = Fr[2];
+    }
   }
 }
 
@@ -518,19 +513,13 @@ int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
   AsmArgs a;
   a.coords = c->coords.p; a.mom = c->mom.p; a.x = xstate; a.un = c->xprev.p; a.bcval = c->bcval.p; a.bcmult = c->bcmult.p;
   a.vptr = c->vptr.p; a.vdiag = c->vdiag.p; a.inc_cell = c->inc_cell.p;
-  a.blk_vptr = c->blk_vptr.p; a.blk_vlist = c->blk_vlist.p; a.blk_cptr = c->blk_cptr.p; a.blk_clist = c->blk_clist.p; a.inc_loc = c->inc_loc.p;
+  a.blk_vptr = c->blk_vptr.p; a.blk_vlist = c->blk_vlist.p; a.blk_cptr = c->blk_cptr.p; a.blk_clist = c->blk_clist.p; a.inc_loc = c->inc_loc.p; a.wave_maxlen = c->wave_maxlen.p;
   a.blk_row = c->blk_row.p; a.blk_inc = c->blk_inc.p; a.blk_maxrank = c->blk_maxrank.p;
   a.inc_slot = c->inc_slot.p; a.inc_rank = c->inc_rank.p; a.cflag = c->cflag.p; a.bcflag = c->bcflag.p;
   a.A00 = c->A00.p; a.A01 = c->A01.p; a.A10 = c->A10.p; a.A11 = c->A11.p; a.F = c->F.p;
   a.nvo = c->nvo; a.dt = c->dt; a.rho = c->rho; a.mu = c->mu; a.muf = c->muf; a.fx = c->f[0]; a.fy = c->f[1];
   prof_begin(c, 0);
-  static int variant = -1;
-  if (variant < 0) { const char *e = getenv("CFDH_ASM_VARIANT"); variant = e ? atoi(e) : 0; }
-  if (mode == 1 && variant == 1) hipLaunchKernelGGL((asm_kernel<1, 3, false>), dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
-  else if (mode == 1 && variant == 2) hipLaunchKernelGGL((asm_kernel<1, 2, true>), dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
-  else if (mode == 1 && variant == 3) hipLaunchKernelGGL((asm_kernel<1, 3, true>), dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
-  else if (mode == 1 && variant == 4) hipLaunchKernelGGL((asm_kernel<1, 4, false>), dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
-  else if (mode == 1) hipLaunchKernelGGL(asm_kernel<1>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
+  if (mode == 1) hipLaunchKernelGGL(asm_kernel<1>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
   else if (mode == 2) hipLaunchKernelGGL(asm_kernel<2>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
   else hipLaunchKernelGGL(asm_kernel<0>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
   prof_end(c, 0);
@@ -986,6 +975,7 @@ __global__ __launch_bounds__(TPB) void sell_spmv_kernel(int n, const int *__rest
   const int sl = row >> 6, lane = row & 63;
   const int p0 = sptr[sl], w = (sptr[sl + 1] - p0) >> 6;
   T a = vzero((const T *)nullptr);
+#pragma unroll 4
   for (int k = 0; k < w; k++) {
     const int p = p0 + k * 64 + lane;
     a = vfma(sval[p], x[scol[p]], a);
@@ -1004,6 +994,7 @@ __global__ __launch_bounds__(TPB) void sell_jacobi_pre_kernel(int n, const int *
   const int sl = row >> 6, lane = row & 63;
   const int p0 = sptr[sl], w = (sptr[sl + 1] - p0) >> 6;
   T a = vzero((const T *)nullptr);
+#pragma unroll 4
   for (int k = 0; k < w; k++) {
     const int p = p0 + k * 64 + lane;
     a = vfma(svalw[p], b[scol[p]], a);   // A (w D^-1 b): the column weight is folded into svalw
@@ -1022,6 +1013,7 @@ __global__ __launch_bounds__(TPB) void sell_jacobi_post_kernel(int n, const int 
   const int sl = row >> 6, lane = row & 63;
   const int p0 = sptr[sl], w = (sptr[sl + 1] - p0) >> 6;
   T a = vzero((const T *)nullptr);
+#pragma unroll 4
   for (int k = 0; k < w; k++) {
     const int p = p0 + k * 64 + lane;
     a = vfma(sval[p], xin[scol[p]], a);

@@ -107,11 +107,19 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
     c->nfac = (int)c->fac_cell.size();
   }
   const int nc = c->nc;
-  for (int e = 0; e < nc; e++) {
-    const int *v = &c->h_cells[3 * e];
-    const double *X = c->h_coords.data();
-    double det = (X[2 * v[1]] - X[2 * v[0]]) * (X[2 * v[2] + 1] - X[2 * v[0] + 1]) - (X[2 * v[1] + 1] - X[2 * v[0] + 1]) * (X[2 * v[2]] - X[2 * v[0]]);
-    if (!(std::fabs(det) > 0)) return cfdh_fail(c, CFDH_E_ARG, "zero-area cell %d", c->cell_user[e]);
+  {
+    // positive orientation of the internal cells (the assembly kernel walks the cells of a vertex
+    // counter-clockwise); a flipped cell swaps its local vertices 1 and 2, and so its local facets
+    std::vector<unsigned char> flipped(nc, 0);
+    for (int e = 0; e < nc; e++) {
+      int *v = &c->h_cells[3 * e];
+      const double *X = c->h_coords.data();
+      double det = (X[2 * v[1]] - X[2 * v[0]]) * (X[2 * v[2] + 1] - X[2 * v[0] + 1]) - (X[2 * v[1] + 1] - X[2 * v[0] + 1]) * (X[2 * v[2]] - X[2 * v[0]]);
+      if (!(std::fabs(det) > 0)) return cfdh_fail(c, CFDH_E_ARG, "zero-area cell %d", c->cell_user[e]);
+      if (det < 0) { std::swap(v[1], v[2]); flipped[e] = 1; }
+    }
+    for (int k = 0; k < c->nfac; k++)
+      if (flipped[c->fac_cell[k]] && c->fac_local[k] != 0) c->fac_local[k] = 3 - c->fac_local[k];
   }
 
   // ---- vertex -> incident (cell, local) for owned rows; vertex graph
@@ -167,44 +175,80 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
     }
   }
 
-  // ---- incidence metadata (rotated so that the row vertex is local 0)
-  std::vector<int> inc_cell(ninc), inc_row(ninc);
-  std::vector<unsigned> inc_slot(ninc), inc_rank(ninc);
+  // ---- incidences of a row ordered as counter-clockwise fans around the vertex: consecutive
+  // lanes then share the edge between their cells, so the two contributions of an off-diagonal
+  // block are summed with ONE lane shuffle and the diagonal block with a segmented wave reduction
+  // (no LDS accumulation, no atomics, fixed order => bitwise reproducible).
+  struct LaneRec { int cellslot; unsigned slots; unsigned seg; unsigned char a, has_prev, emit_v2; };
+  std::vector<LaneRec> rowlanes(ninc);  // in row order, position = vcptr[v] + fan position
   {
-    std::vector<unsigned char> cnt;
+    std::vector<int> ord, v1s, v2s, used;
     for (int v = 0; v < nvo; v++) {
-      const int *nb = &c->h_vcol[c->h_vptr[v]];
-      int deg = c->h_vptr[v + 1] - c->h_vptr[v];
-      cnt.assign(deg, 0);
-      for (int k = vcptr[v]; k < vcptr[v + 1]; k++) {
-        int e = vcell[k] >> 2, a = vcell[k] & 3;
-        unsigned slot = 0, rank = 0;
-        for (int b = 0; b < 3; b++) {
-          int w = c->h_cells[3 * e + (a + b) % 3];
-          int s = (int)(std::lower_bound(nb, nb + deg, w) - nb);
-          slot |= (unsigned)s << (8 * b);
-          rank |= (unsigned)cnt[s] << (8 * b);
-          cnt[s]++;
-        }
-        inc_cell[k] = vcell[k]; inc_row[k] = v; inc_slot[k] = slot; inc_rank[k] = rank;
+      const int k0 = vcptr[v], n = vcptr[v + 1] - k0;
+      if (n > 64) return cfdh_fail(c, CFDH_E_ARG, "vertex %d has %d cells: more than one wavefront", c->iperm[v], n);
+      v1s.assign(n, 0); v2s.assign(n, 0); used.assign(n, 0); ord.clear();
+      for (int q = 0; q < n; q++) {
+        const int e = vcell[k0 + q] >> 2, a = vcell[k0 + q] & 3;
+        v1s[q] = c->h_cells[3 * e + (a + 1) % 3]; v2s[q] = c->h_cells[3 * e + (a + 2) % 3];
       }
+      auto find_by_v1 = [&](int w) { for (int q = 0; q < n; q++) if (!used[q] && v1s[q] == w) return q; return -1; };
+      auto has_v2 = [&](int w, int self) { for (int q = 0; q < n; q++) if (q != self && v2s[q] == w) return true; return false; };
+      std::vector<int> fan_first_pos, fan_len, fan_closed;
+      // open fans first (start = cell whose (i,v1) edge has no other cell), then closed ones
+      for (int pass = 0; pass < 2; pass++)
+        for (int q0 = 0; q0 < n; q0++) {
+          if (used[q0]) continue;
+          if (pass == 0 && has_v2(v1s[q0], q0)) continue;
+          const int first = (int)ord.size();
+          int q = q0;
+          while (q >= 0) { used[q] = 1; ord.push_back(q); q = find_by_v1(v2s[q]); }
+          const int len = (int)ord.size() - first;
+          const bool closed = (pass == 1) && v2s[ord.back()] == v1s[ord[first]];
+          fan_first_pos.push_back(first); fan_len.push_back(len); fan_closed.push_back(closed ? 1 : 0);
+        }
+      const int *nb = &c->h_vcol[c->h_vptr[v]];
+      const int deg = c->h_vptr[v + 1] - c->h_vptr[v];
+      for (size_t f = 0; f < fan_len.size(); f++)
+        for (int t = 0; t < fan_len[f]; t++) {
+          const int pos = fan_first_pos[f] + t, q = ord[pos];
+          const int e = vcell[k0 + q] >> 2, a = vcell[k0 + q] & 3;
+          LaneRec L;
+          L.cellslot = vcell[k0 + q]; L.a = (unsigned char)a;
+          unsigned slots = 0;
+          for (int bq = 0; bq < 3; bq++) {
+            const int w = c->h_cells[3 * e + (a + bq) % 3];
+            slots |= (unsigned)(std::lower_bound(nb, nb + deg, w) - nb) << (8 * bq);
+          }
+          L.slots = slots;
+          int prev_off = 0;
+          if (t > 0) prev_off = -1;
+          else if (fan_closed[f] && fan_len[f] > 1) prev_off = fan_len[f] - 1;
+          L.has_prev = prev_off != 0;
+          L.emit_v2 = (t == fan_len[f] - 1) && !fan_closed[f];
+          if (fan_closed[f] && fan_len[f] == 1) { L.has_prev = 0; L.emit_v2 = 1; }
+          L.seg = (unsigned)pos | ((unsigned)n << 8) | ((unsigned)(prev_off + 64) << 16);
+          rowlanes[k0 + pos] = L;
+        }
     }
   }
-  // ---- workgroup blocks of whole rows, each with its own compact vertex and cell lists:
-  // the kernel stages those (coalesced) in LDS and every lane gathers from LDS only
+  // ---- pack whole rows into wavefronts (64 lanes) and 4 wavefronts into a workgroup; every
+  // workgroup carries compact lists of the vertices and cells it touches (staged in LDS)
   std::vector<int> blk_row(1, 0), blk_maxrank, blk_inc(1, 0), blk_vptr(1, 0), blk_cptr(1, 0), blk_vlist, blk_clist;
-  std::vector<unsigned> inc_loc(ninc);  // lcell | lv0<<8 | lv1<<16 | lv2<<24 (block-local indices, rotated)
+  std::vector<unsigned> lane_loc, lane_meta, lane_seg;   // per lane of every workgroup (0xFFFFFFFF = idle lane)
+  std::vector<int> wave_maxlen;
   {
     std::vector<int> vmark(nv, -1), vloc(nv, 0), cmark(nc, -1), cloc(nc, 0);
     int r0 = 0, bid = 0;
     while (r0 < nvo) {
-      int r1 = r0, inc = 0, slots = 0, mr = 2, nvl = 0, ncl = 0;
-      const size_t v_begin = blk_vlist.size(), c_begin = blk_clist.size();
+      int r1 = r0, nvl = 0, ncl = 0, wave = 0, lane = 0, wmax = 0;
+      std::vector<unsigned> bloc(CFDH_MAX_INC, 0xFFFFFFFFu), bmeta(CFDH_MAX_INC, 0), bseg(CFDH_MAX_INC, 0);
+      int wmaxes[CFDH_MAX_INC / 64] = {0};
       while (r1 < nvo) {
-        const int di = vcptr[r1 + 1] - vcptr[r1], ds = c->h_vptr[r1 + 1] - c->h_vptr[r1];
-        if (di > CFDH_MAX_INC || ds > CFDH_MAX_SLOTS) return cfdh_fail(c, CFDH_E_ARG, "vertex valence too large");
-        if (inc + di > CFDH_MAX_INC || slots + ds > CFDH_MAX_SLOTS || r1 - r0 >= CFDH_MAX_ROWS) break;
-        // vertices / cells this row would add
+        const int di = vcptr[r1 + 1] - vcptr[r1];
+        if (r1 - r0 >= CFDH_MAX_ROWS) break;
+        int w2 = wave, l2 = lane;
+        if (l2 + di > 64) { w2++; l2 = 0; }
+        if (w2 >= CFDH_MAX_INC / 64) break;
         int addv = 0, addc = 0;
         for (int k = vcptr[r1]; k < vcptr[r1 + 1]; k++) {
           const int e = vcell[k] >> 2;
@@ -213,7 +257,6 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
         }
         if (nvl + addv > CFDH_MAX_BV || ncl + addc > CFDH_MAX_BC) {
           if (r1 == r0) return cfdh_fail(c, CFDH_E_ARG, "vertex patch too large for one workgroup");
-          // undo the marks of this row (entries with loc == -1 were added by it)
           for (int k = vcptr[r1]; k < vcptr[r1 + 1]; k++) {
             const int e = vcell[k] >> 2;
             if (cmark[e] == bid && cloc[e] == -1) cmark[e] = -1;
@@ -221,22 +264,35 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
           }
           break;
         }
+        wave = w2; lane = l2;
         for (int k = vcptr[r1]; k < vcptr[r1 + 1]; k++) {
-          const int e = vcell[k] >> 2, a = vcell[k] & 3;
+          const LaneRec &L = rowlanes[k];
+          const int e = L.cellslot >> 2, a = L.a;
           if (cloc[e] == -1) { cloc[e] = ncl++; blk_clist.push_back(e); }
           for (int q = 0; q < 3; q++) { const int w = c->h_cells[3 * e + q]; if (vloc[w] == -1) { vloc[w] = nvl++; blk_vlist.push_back(w); } }
           unsigned loc = (unsigned)cloc[e];
           for (int q = 0; q < 3; q++) loc |= (unsigned)vloc[c->h_cells[3 * e + (a + q) % 3]] << (8 * (q + 1));
-          inc_loc[k] = loc;
+          const int t = wave * 64 + lane;
+          bloc[t] = loc;
+          bmeta[t] = L.slots | ((unsigned)a << 24) | ((unsigned)L.emit_v2 << 26) | ((unsigned)L.has_prev << 27);
+          bseg[t] = L.seg;
+          lane++;
         }
-        inc += di; slots += ds; mr = std::max(mr, di); r1++;
+        wmaxes[wave] = std::max(wmaxes[wave], di);
+        wmax = std::max(wmax, di);
+        r1++;
       }
-      (void)v_begin; (void)c_begin;
-      blk_row.push_back(r1); blk_maxrank.push_back(mr); blk_inc.push_back(vcptr[r1]);
+      lane_loc.insert(lane_loc.end(), bloc.begin(), bloc.end());
+      lane_meta.insert(lane_meta.end(), bmeta.begin(), bmeta.end());
+      lane_seg.insert(lane_seg.end(), bseg.begin(), bseg.end());
+      for (int w = 0; w < CFDH_MAX_INC / 64; w++) wave_maxlen.push_back(wmaxes[w]);
+      blk_row.push_back(r1); blk_maxrank.push_back(wmax); blk_inc.push_back(vcptr[r1]);
       blk_vptr.push_back((int)blk_vlist.size()); blk_cptr.push_back((int)blk_clist.size());
       r0 = r1; bid++;
     }
   }
+  std::vector<int> inc_cell(1, 0), inc_row(1, 0);
+  std::vector<unsigned> inc_slot(lane_meta), inc_rank(lane_seg), inc_loc(lane_loc);
   c->nblk = (int)blk_maxrank.size();
 
   // ---- uploads
@@ -264,6 +320,7 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
   HIPCHK(c, c->blk_vptr.upload(blk_vptr, s)); HIPCHK(c, c->blk_cptr.upload(blk_cptr, s));
   HIPCHK(c, c->blk_vlist.upload(blk_vlist, s)); HIPCHK(c, c->blk_clist.upload(blk_clist, s));
   HIPCHK(c, c->inc_loc.upload(inc_loc, s));
+  HIPCHK(c, c->wave_maxlen.upload(wave_maxlen, s));
   {
     std::vector<unsigned char> cown(nc);
     for (int k = 0; k < nc; k++) cown[k] = cells[3 * c->cell_user[k]] < nvo ? 1 : 0;

@@ -42,14 +42,15 @@ def test_assembly_and_spmv_match_oracle(case_fn, arg):
     assert abs(J - Jg).max() <= 1e-13 * abs(J).max()
     v = np.random.default_rng(3).standard_normal(3 * nv)
     assert np.abs(ctx.spmv(v) - J @ v).max() <= 1e-13 * np.abs(J @ v).max()
-    # residual-only evaluation (lifting still applied) gives the same F
+    # residual-only evaluation (lifting still applied) gives the same F (a separately compiled kernel
+    # instance: equal to round-off, not bitwise)
     ctx.assemble(False)
-    assert np.array_equal(np.concatenate(ctx.get_residual()), Fg)
+    assert np.abs(np.concatenate(ctx.get_residual()) - Fg).max() <= 1e-14 * np.abs(Fg).max()
     ctx.close()
 
 
 def test_assembly_is_bitwise_reproducible():
-    """No atomics: LDS accumulation in fixed rounds -> identical bits run to run."""
+    """No atomics: wavefront segmented reduction in a fixed order -> identical bits run to run."""
     case = dfg_case(24)
     nv = case.nv
     xv, un = _rand_state(nv, 5)

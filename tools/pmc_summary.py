@@ -15,12 +15,12 @@ import sys
 NAMES = {
     "cheb_a00_step_kernel": "cheb_step_A00",
     "spmv_full_kernel": "spmv_full_block3x3",
-    "asm_kernel<1>": "asm_residual_jacobian",
+    "asm_kernel<1": "asm_residual_jacobian",
     "moments_kernel": "tau_moments",
-    "jacobi_pre_kernel<double2>": "amg_sweep_velocity_2rhs",
-    "jacobi_post_kernel<double2>": "amg_sweep_velocity_2rhs",
-    "jacobi_pre_kernel<double>": "amg_sweep_pressure",
-    "jacobi_post_kernel<double>": "amg_sweep_pressure",
+    "sell_jacobi_pre_kernel<HIP_vector_type<double, 2": "amg_sweep_velocity_2rhs",
+    "sell_jacobi_post_kernel<HIP_vector_type<double, 2": "amg_sweep_velocity_2rhs",
+    "sell_jacobi_pre_kernel<double>": "amg_sweep_pressure",
+    "sell_jacobi_post_kernel<double>": "amg_sweep_pressure",
 }
 
 
