@@ -44,7 +44,7 @@ SYMBOLS = [
     "cfdh_create", "cfdh_destroy", "cfdh_last_error", "cfdh_abi_version", "cfdh_set_params", "cfdh_default_options",
     "cfdh_set_options", "cfdh_clear_dirichlet", "cfdh_add_dirichlet", "cfdh_set_state", "cfdh_get_solution",
     "cfdh_get_previous", "cfdh_get_residual", "cfdh_advance", "cfdh_assemble", "cfdh_get_csr", "cfdh_spmv", "cfdh_solve_step",
-    "cfdh_functional", "cfdh_set_halo", "cfdh_comm_unique_id", "cfdh_comm_init", "cfdh_comm_set_callbacks",
+    "cfdh_functional", "cfdh_set_global_pressure_space", "cfdh_set_halo", "cfdh_comm_unique_id", "cfdh_comm_init", "cfdh_comm_set_callbacks",
     "cfdh_profile_enable", "cfdh_profile_get", "cfdh_profile_reset", "cfdh_info",
 ]
 
@@ -95,6 +95,7 @@ def lib():
     L.cfdh_solve_step.argtypes = [vp, C.POINTER(Stats)]
     L.cfdh_functional.argtypes = [vp, C.c_int, C.c_int, dp]
     L.cfdh_set_halo.argtypes = [vp, C.c_int, ip, lp, ip, lp, ip]
+    L.cfdh_set_global_pressure_space.argtypes = [vp, C.c_int64, C.c_int64, ip, dp, ip, C.c_int64, ip]
     L.cfdh_comm_unique_id.argtypes = [C.c_void_p]
     L.cfdh_comm_init.argtypes = [vp, C.c_void_p, C.c_int, C.c_int]
     L.cfdh_comm_set_callbacks.argtypes = [vp, ALLREDUCE_FN, EXCHANGE_FN, C.c_void_p, C.c_int, C.c_int]
@@ -257,6 +258,13 @@ class Context:
         rp = np.ascontiguousarray(recv_ptr, dtype=np.int64)
         ri = np.ascontiguousarray(recv_idx, dtype=np.int32)
         self._chk(self.L.cfdh_set_halo(self.h, len(a), _ip(a), _lp(sp_), _ip(si), _lp(rp), _ip(ri)))
+
+    def set_global_pressure_space(self, x_global, cells_global, owned_global, pbc_nodes_global):
+        xg = np.ascontiguousarray(x_global, dtype=np.float64)[:, :2].copy()
+        cg = np.ascontiguousarray(cells_global, dtype=np.int32)
+        og = np.ascontiguousarray(owned_global, dtype=np.int32)
+        pb = np.ascontiguousarray(pbc_nodes_global, dtype=np.int32)
+        self._chk(self.L.cfdh_set_global_pressure_space(self.h, len(xg), len(cg), _ip(cg), _dp(xg), _ip(og), len(pb), _ip(pb)))
 
     def comm_init_rccl(self, uid_bytes, rank, nranks):
         buf = C.create_string_buffer(bytes(uid_bytes), 128)

@@ -73,10 +73,11 @@ void cfdh_destroy(cfdh_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   comm_finalize(c);
-  c->hS.clear(); c->hL.clear(); c->hA.clear();
+  c->hS.clear(); c->hL.clear(); c->hA.clear(); c->hLg.clear();
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-  for (auto &e : c->pc_graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
+  for (auto &e : c->pc_graphs) { if (e.exec) (void)hipGraphExecDestroy(e.exec); if (e.exec2) (void)hipGraphExecDestroy(e.exec2); }
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->h_big) (void)hipHostFree(c->h_big);
   hipStream_t s = c->stream;
   delete c;
   if (s) (void)hipStreamDestroy(s);
@@ -292,6 +293,65 @@ int cfdh_spmv(cfdh_ctx *c, const double *x, double *y) {
     y[2 * (size_t)v] = o[2 * (size_t)k]; y[2 * (size_t)v + 1] = o[2 * (size_t)k + 1];
     y[2 * (size_t)c->nvo + v] = o[2 * (size_t)c->nvo + k];
   }
+  return 0;
+}
+
+int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const int32_t *cells, const double *coords,
+                                   const int32_t *owned_global, int64_t n_pbc, const int32_t *pbc_nodes) {
+  ENTER(c);
+  if (nvg <= 0 || ncg <= 0 || !cells || !coords || !owned_global || (n_pbc > 0 && !pbc_nodes))
+    return cfdh_fail(c, CFDH_E_ARG, "bad global pressure space arguments");
+  const int n = (int)nvg;
+  for (int64_t k = 0; k < 3 * ncg; k++) if (cells[k] < 0 || cells[k] >= n) return cfdh_fail(c, CFDH_E_ARG, "global cell vertex out of range");
+  std::vector<unsigned char> pbc(n, 0);
+  for (int64_t k = 0; k < n_pbc; k++) {
+    if (pbc_nodes[k] < 0 || pbc_nodes[k] >= n) return cfdh_fail(c, CFDH_E_ARG, "global Dirichlet node out of range");
+    pbc[pbc_nodes[k]] = 1;
+  }
+  // global P1 stiffness as (row, col, value) triplets -> CSR with Dirichlet rows/cols removed
+  std::vector<std::vector<std::pair<int, double>>> rows(n);
+  for (int64_t e = 0; e < ncg; e++) {
+    const int32_t *v = cells + 3 * e;
+    const double x0 = coords[2 * v[0]], y0 = coords[2 * v[0] + 1], x1 = coords[2 * v[1]], y1 = coords[2 * v[1] + 1],
+                 x2 = coords[2 * v[2]], y2 = coords[2 * v[2] + 1];
+    const double det = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0), area = 0.5 * std::fabs(det);
+    if (!(area > 0)) return cfdh_fail(c, CFDH_E_ARG, "zero-area global cell");
+    const double g[3][2] = {{(y1 - y2) / det, (x2 - x1) / det}, {(y2 - y0) / det, (x0 - x2) / det}, {(y0 - y1) / det, (x1 - x0) / det}};
+    for (int a = 0; a < 3; a++) {
+      if (pbc[v[a]]) continue;
+      for (int b = 0; b < 3; b++) {
+        if (pbc[v[b]]) continue;
+        rows[v[a]].push_back({v[b], area * (g[a][0] * g[b][0] + g[a][1] * g[b][1])});
+      }
+    }
+  }
+  CsrHost &L = c->gp_L;
+  L.n = L.m = n; L.rowptr.assign(n + 1, 0); L.col.clear(); L.val.clear();
+  for (int i = 0; i < n; i++) {
+    if (pbc[i]) { L.col.push_back(i); L.val.push_back(1.0); }
+    else {
+      auto &r = rows[i];
+      std::sort(r.begin(), r.end());
+      for (size_t k = 0; k < r.size(); k++) {
+        if (k > 0 && r[k].first == r[k - 1].first) L.val.back() += r[k].second;
+        else { L.col.push_back(r[k].first); L.val.push_back(r[k].second); }
+      }
+    }
+    L.rowptr[i + 1] = (int)L.col.size();
+  }
+  c->gp_singular = (n_pbc == 0);
+  std::vector<int> l2g(c->nvo);
+  for (int k = 0; k < c->nvo; k++) {
+    const int g = owned_global[c->iperm[k]];
+    if (g < 0 || g >= n) return cfdh_fail(c, CFDH_E_ARG, "owned_global out of range");
+    l2g[k] = g;
+  }
+  HIPCHK(c, c->gp_l2g.upload(l2g, c->stream));
+  HIPCHK(c, c->gp_rhs.alloc(n)); HIPCHK(c, c->gp_sol.alloc(n));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->gp_n = n;
+  c->gp_dirty = true;
+  c->pc_valid = false;
   return 0;
 }
 

@@ -113,8 +113,15 @@ int comm_allreduce_dev(cfdh_ctx *c, double *dev, int n, int op) {
     return 0;
   }
   if (!c->cb_ar) return cfdh_fail(c, CFDH_E_COMM, "multi-rank context without communicator");
-  if (n > 512) return cfdh_fail(c, CFDH_E_COMM, "host-staged allreduce limited to 512 values");
   double *h = c->h_pinned + 512;
+  if (n > 512) {
+    if (c->h_big_n < (size_t)n) {
+      if (c->h_big) (void)hipHostFree(c->h_big);
+      HIPCHK(c, hipHostMalloc((void **)&c->h_big, sizeof(double) * (size_t)n));
+      c->h_big_n = (size_t)n;
+    }
+    h = c->h_big;
+  }
   HIPCHK(c, hipMemcpyAsync(h, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->cb_ar(c->cb_user, h, n, op) != 0) return cfdh_fail(c, CFDH_E_COMM, "allreduce callback failed");

@@ -176,7 +176,7 @@ struct cfdh_ctx {
   dbuf<double> pu0, pu1, pu2, pr, pp0, pp1;  // PC work vectors
   dbuf<double> prand;                        // fixed start vector of the power iteration
   dbuf<double> cheb_coef;                    // [1/theta, (c1,c2) per step] of the A00 Chebyshev solve
-  struct PcGraph { const double *r; double *z; hipGraphExec_t exec; };
+  struct PcGraph { const double *r; double *z; hipGraphExec_t exec, exec2; };
   std::vector<PcGraph> pc_graphs;            // one captured preconditioner application per Krylov slot
   bool pc_graph_valid = false, capturing = false, use_graph = true;
   AmgHier hS;               // SELFP Schur matrix Sp (pc_type 0)
@@ -188,6 +188,15 @@ struct cfdh_ctx {
   double cc_alpha = 0, cc_beta = 0;
   std::vector<double> h_Lval, h_Ml;  // P1 stiffness on the vertex graph, lumped mass (geometry only)
   long long bc_version = 0;
+  // replicated global pressure space (multi-rank pc_type 1)
+  int gp_n = 0;                       // global vertex count (0: not set, pressure solve is rank-local)
+  CsrHost gp_L;                       // global Laplacian with Dirichlet rows (host, for the hierarchy)
+  bool gp_singular = false, gp_dirty = false;
+  AmgHier hLg;                        // its hierarchy (identical on every rank)
+  dbuf<int> gp_l2g;                   // [nvo] global id of owned vertex (internal numbering)
+  dbuf<double> gp_rhs, gp_sol;        // [gp_n]
+  double *h_big = nullptr;            // pinned staging of the host-callback all-reduce
+  size_t h_big_n = 0;
   std::vector<unsigned char> hL_pbc;  // Dirichlet set hL was built for
   int hL_singular = -1;
   bool pc_valid = false;
@@ -259,6 +268,8 @@ int k_csr_spmv(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mod
 int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x);
 int k_level_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, int degree);
 int k_cc_scale(cfdh_ctx *c, int n, const double *ml, const double *z, double *y);
+int k_scatter_global(cfdh_ctx *c, int n, const int *l2g, const double *loc, double *glob);
+int k_gather_global(cfdh_ctx *c, int n, const int *l2g, const double *glob, double *loc);
 int k_cc_combine(cfdh_ctx *c, int n, double alpha, double beta, const double *t, const double *z, const double *r, const unsigned char *pbc, double *out);
 int k_nullspace_test(cfdh_ctx *c, double *nrm);
 

@@ -1085,7 +1085,7 @@ static int amg_cycle_cheb(cfdh_ctx *c, AmgHier &H, size_t lev, const double *b, 
 // x = V(H) b; for ncol == 2 b and x hold interleaved pairs
 int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x) {
   if (!H.valid || H.lev.empty()) return cfdh_fail(c, CFDH_E_STATE, "AMG hierarchy not built");
-  const bool prof = (&H == &c->hS) || (&H == &c->hL);
+  const bool prof = (&H == &c->hS) || (&H == &c->hL) || (&H == &c->hLg);
   if (H.ncol == 2) return amg_cycle_jacobi<double2>(c, H, 0, (const double2 *)b, (double2 *)x, 5);
   if (c->opt.amg_smooth_degree == 1) return amg_cycle_jacobi<double>(c, H, 0, b, x, prof ? 4 : 0);
   return amg_cycle_cheb(c, H, 0, b, x, prof);
@@ -1101,6 +1101,24 @@ __global__ __launch_bounds__(TPB) void cc_combine_kernel(int n, double alpha, do
                                                          const unsigned char *__restrict__ pbc, double *__restrict__ out) {
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i < n) out[i] = pbc[i] ? r[i] : alpha * t[i] + beta * z[i];
+}
+__global__ __launch_bounds__(TPB) void scatter_global_kernel(int n, const int *__restrict__ l2g, const double *__restrict__ loc, double *__restrict__ glob) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i < n) glob[l2g[i]] = loc[i];
+}
+__global__ __launch_bounds__(TPB) void gather_global_kernel(int n, const int *__restrict__ l2g, const double *__restrict__ glob, double *__restrict__ loc) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i < n) loc[i] = glob[l2g[i]];
+}
+int k_scatter_global(cfdh_ctx *c, int n, const int *l2g, const double *loc, double *glob) {
+  hipLaunchKernelGGL(scatter_global_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, l2g, loc, glob);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int k_gather_global(cfdh_ctx *c, int n, const int *l2g, const double *glob, double *loc) {
+  hipLaunchKernelGGL(gather_global_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, l2g, glob, loc);
+  HIPCHK(c, hipGetLastError());
+  return 0;
 }
 int k_cc_scale(cfdh_ctx *c, int n, const double *ml, const double *z, double *y) {
   hipLaunchKernelGGL(cc_scale_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, ml, z, y);

@@ -142,6 +142,10 @@ static int build_cc_host(cfdh_ctx *c) {
     HIPCHK(c, c->ccMl.upload(ml, c->stream));
     HIPCHK(c, c->ccPbc.upload(pbc, c->stream));
   }
+  if (c->gp_n > 0 && (c->gp_dirty || !c->hLg.valid)) {
+    CHK(cfdh_amg_setup(c, c->hLg, c->gp_L, c->gp_singular, 1));
+    c->gp_dirty = false;
+  }
   // --- H
   c->cc_alpha = 2.0 * c->rho / c->dt;
   c->cc_beta = c->mu;
@@ -222,17 +226,32 @@ int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
   return 0;
 }
 
-static int pc_apply_body(cfdh_ctx *c, const double *r, double *z) {
+// part: 0 = whole application; with a replicated global pressure space the application is split at the
+// all-reduce of the pressure right-hand side: 1 = up to it, 2 = after it (each part is graph-capturable)
+static int pc_apply_body(cfdh_ctx *c, const double *r, double *z, int part) {
   const int nvo = c->nvo, nu = 2 * nvo;
   const double *ru = r, *rp = r + nu;
   double *zu = z, *zp = z + nu;
   if (c->opt.pc_type == 1) {
-    CHK(k_amg_vcycle(c, c->hA, ru, c->pu0.p));              // y_u = V(A00~) r_u   (both components at once)
-    CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));     // t_p = r_p - A10 y_u
-    // z_p = S~^-1 t_p : zH = Cheb3(H) t_p ; y = M_l zH ; z_p = a' V(L) y + b' zH
-    CHK(k_level_smooth(c, &c->Hlev, c->pp0.p, c->pp1.p, 3));
-    CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
-    CHK(k_amg_vcycle(c, c->hL, c->pu1.p, c->pu2.p));
+    const bool global_p = c->gp_n > 0 && c->nranks > 1;
+    if (part != 2) {
+      CHK(k_amg_vcycle(c, c->hA, ru, c->pu0.p));              // y_u = V(A00~) r_u   (both components at once)
+      CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));     // t_p = r_p - A10 y_u
+      // z_p = S~^-1 t_p : zH = Cheb3(H) t_p ; y = M_l zH ; z_p = a' V(L) y + b' zH
+      CHK(k_level_smooth(c, &c->Hlev, c->pp0.p, c->pp1.p, 3));
+      CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
+      if (global_p) {
+        CHK(v_zero(c, c->gp_n, c->gp_rhs.p));
+        CHK(k_scatter_global(c, nvo, c->gp_l2g.p, c->pu1.p, c->gp_rhs.p));
+      }
+    }
+    if (part == 1) return 0;
+    if (global_p) {
+      CHK(k_amg_vcycle(c, c->hLg, c->gp_rhs.p, c->gp_sol.p)); // the same global V-cycle on every rank
+      CHK(k_gather_global(c, nvo, c->gp_l2g.p, c->gp_sol.p, c->pu2.p));
+    } else {
+      CHK(k_amg_vcycle(c, c->hL, c->pu1.p, c->pu2.p));
+    }
     CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, c->pp0.p, c->ccPbc.p, zp));
     if (c->opt.schur_full) {
       CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));         // t_u = r_u - A01 z_p
@@ -242,6 +261,7 @@ static int pc_apply_body(cfdh_ctx *c, const double *r, double *z) {
     }
     return 0;
   }
+  if (part == 2) return 0;
   CHK(k_cheb_a00(c, ru, c->pu0.p));                       // y_u = C(A00) r_u
   CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));     // t_p = r_p - A10 y_u
   CHK(k_amg_vcycle(c, c->hS, c->pp0.p, zp));              // z_p = V(Sp) t_p
@@ -258,34 +278,53 @@ static int pc_apply_body(cfdh_ctx *c, const double *r, double *z) {
 // into a hipGraph and replayed (the Krylov loop is launch-bound otherwise: MI355X guide,
 // "graph-replay-floor").  Operands differ per Krylov slot (r = V_j, z = Z_j), so one graph is
 // kept per (r, z) pair -- no staging copies; all are dropped when the hierarchy is rebuilt.
+static int capture_part(cfdh_ctx *c, const double *r, double *z, int part, hipGraphExec_t *out) {
+  hipGraph_t g = nullptr;
+  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  c->capturing = true;
+  int rc = pc_apply_body(c, r, z, part);
+  c->capturing = false;
+  hipError_t e = hipStreamEndCapture(c->stream, &g);
+  if (rc) return rc;
+  if (e != hipSuccess || !g) return cfdh_fail(c, CFDH_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return cfdh_fail(c, CFDH_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  return 0;
+}
+
 int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z) {
   const int nvo = c->nvo;
   const bool graph = c->use_graph && !c->prof_on;
+  const bool split = c->opt.pc_type == 1 && c->gp_n > 0 && c->nranks > 1;  // all-reduce in the middle
   if (!graph) {
-    CHK(pc_apply_body(c, r, z));
+    if (split) {
+      CHK(pc_apply_body(c, r, z, 1));
+      CHK(comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0));
+      CHK(pc_apply_body(c, r, z, 2));
+    } else {
+      CHK(pc_apply_body(c, r, z, 0));
+    }
   } else {
     if (!c->pc_graph_valid) {
-      for (auto &e : c->pc_graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
+      for (auto &e : c->pc_graphs) { if (e.exec) (void)hipGraphExecDestroy(e.exec); if (e.exec2) (void)hipGraphExecDestroy(e.exec2); }
       c->pc_graphs.clear();
       c->pc_graph_valid = true;
     }
-    hipGraphExec_t exec = nullptr;
-    for (auto &e : c->pc_graphs) if (e.r == r && e.z == z) { exec = e.exec; break; }
-    if (!exec) {
-      hipGraph_t g = nullptr;
-      HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      c->capturing = true;
-      int rc = pc_apply_body(c, r, z);
-      c->capturing = false;
-      hipError_t e = hipStreamEndCapture(c->stream, &g);
-      if (rc) return rc;
-      if (e != hipSuccess || !g) return cfdh_fail(c, CFDH_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-      e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(g);
-      if (e != hipSuccess) return cfdh_fail(c, CFDH_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-      c->pc_graphs.push_back({r, z, exec});
+    cfdh_ctx::PcGraph *pg = nullptr;
+    for (auto &e : c->pc_graphs) if (e.r == r && e.z == z) { pg = &e; break; }
+    if (!pg) {
+      cfdh_ctx::PcGraph ng{r, z, nullptr, nullptr};
+      CHK(capture_part(c, r, z, split ? 1 : 0, &ng.exec));
+      if (split) CHK(capture_part(c, r, z, 2, &ng.exec2));
+      c->pc_graphs.push_back(ng);
+      pg = &c->pc_graphs.back();
     }
-    HIPCHK(c, hipGraphLaunch(exec, c->stream));
+    HIPCHK(c, hipGraphLaunch(pg->exec, c->stream));
+    if (split) {
+      CHK(comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0));
+      HIPCHK(c, hipGraphLaunch(pg->exec2, c->stream));
+    }
   }
   if (c->singular) CHK(v_sub_mean(c, nvo, z + 2 * (size_t)nvo));
   return 0;

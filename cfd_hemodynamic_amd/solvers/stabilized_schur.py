@@ -122,6 +122,10 @@ class Solver(SolverBase):
         self._bcs = [(0, bc) for bc in self.bcu_d] + [(1, bc) for bc in self.bcp_d]
         self._bc_cache = None
         self._upload_bcs()
+        if self._part is not None:
+            # the pressure part of the preconditioner is solved globally (replicated) on every rank
+            pnodes = np.unique(np.concatenate([bc.dofs for bc in self.bcp_d])) if self.bcp_d else np.zeros(0, np.int32)
+            self.ctx.set_global_pressure_space(self.mesh.x, self.mesh.cells, self._part.owned_global, pnodes)
         # x_n = (u_prev, p_prev): initial guess of the first step (stabilized_schur.py:216-223)
         self._sync_previous()
         up, pp = self._loc_u(self._u_prev.x._array), self._loc_p(self._p_prev.x._array)

@@ -173,6 +173,15 @@ int cfdh_functional(cfdh_ctx *ctx, int kind, int marker, double *out);
  * neighbour order, starting at nv_owned). */
 int cfdh_set_halo(cfdh_ctx *ctx, int nnbr, const int32_t *nbr_rank, const int64_t *send_ptr,
                   const int32_t *send_idx, const int64_t *recv_ptr, const int32_t *recv_idx);
+/* Global pressure space of a partitioned run.  The pressure part of the preconditioner is a Poisson-type
+ * solve whose low modes couple all parts; a rank-local (block-Jacobi) version multiplies the FGMRES
+ * iterations by ~10.  Every rank therefore receives the whole (replicated, geometry-only) mesh and the
+ * global pressure-Dirichlet set, builds the same global Laplacian hierarchy and applies it redundantly to
+ * the all-reduced right-hand side.  owned_global[nv_owned]: global vertex id of each owned local vertex
+ * (local numbering of cfdh_create).  Call after the Dirichlet data are known; no-op need for one rank. */
+int cfdh_set_global_pressure_space(cfdh_ctx *ctx, int64_t nv_global, int64_t nc_global, const int32_t *cells_global,
+                                   const double *coords_global, const int32_t *owned_global, int64_t n_pbc,
+                                   const int32_t *pbc_nodes_global);
 /* RCCL over xGMI: rank 0 creates the 128-byte unique id, the launcher
  * broadcasts it, every rank calls cfdh_comm_init. */
 int cfdh_comm_unique_id(void *id128);
