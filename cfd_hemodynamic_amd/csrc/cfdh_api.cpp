@@ -75,7 +75,7 @@ void cfdh_destroy(cfdh_ctx *c) {
   comm_finalize(c);
   c->hS.clear(); c->hL.clear(); c->hA.clear(); c->hLg.clear();
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-  for (auto &e : c->pc_graphs) { if (e.exec) (void)hipGraphExecDestroy(e.exec); if (e.exec2) (void)hipGraphExecDestroy(e.exec2); }
+  for (auto &e : c->pc_graphs) for (auto &x : e.exec) if (x) (void)hipGraphExecDestroy(x);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->h_big) (void)hipHostFree(c->h_big);
   hipStream_t s = c->stream;

@@ -176,7 +176,7 @@ struct cfdh_ctx {
   dbuf<double> pu0, pu1, pu2, pr, pp0, pp1;  // PC work vectors
   dbuf<double> prand;                        // fixed start vector of the power iteration
   dbuf<double> cheb_coef;                    // [1/theta, (c1,c2) per step] of the A00 Chebyshev solve
-  struct PcGraph { const double *r; double *z; hipGraphExec_t exec, exec2; };
+  struct PcGraph { const double *r; double *z; hipGraphExec_t exec[4]; };
   std::vector<PcGraph> pc_graphs;            // one captured preconditioner application per Krylov slot
   bool pc_graph_valid = false, capturing = false, use_graph = true;
   AmgHier hS;               // SELFP Schur matrix Sp (pc_type 0)
@@ -195,6 +195,7 @@ struct cfdh_ctx {
   AmgHier hLg;                        // its hierarchy (identical on every rank)
   dbuf<int> gp_l2g;                   // [nvo] global id of owned vertex (internal numbering)
   dbuf<double> gp_rhs, gp_sol;        // [gp_n]
+  dbuf<double> pcw;                   // [NL] scratch vector with ghost tail for the coupling products
   double *h_big = nullptr;            // pinned staging of the host-callback all-reduce
   size_t h_big_n = 0;
   std::vector<unsigned char> hL_pbc;  // Dirichlet set hL was built for
@@ -261,6 +262,7 @@ int k_moments(cfdh_ctx *c);
 int k_assemble(cfdh_ctx *c, const double *xstate, int mode);  // mode 0: F only, 1: F+J, 2: F with lifting (no J write)
 int k_spmv_full(cfdh_ctx *c, const double *x, double *y);
 int k_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b, double alpha);  // y = b*? see .hip
+int k_spmv_block_ghost(cfdh_ctx *c, int blk, const double *xv, double *y, const double *b);
 int k_extract_diag(cfdh_ctx *c);
 int k_cheb_a00(cfdh_ctx *c, const double *b, double *x);
 int k_cheb_a00_coeffs(cfdh_ctx *c);  // x = Cheb_k(A00) b, zero initial guess

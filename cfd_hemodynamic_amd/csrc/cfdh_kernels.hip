@@ -615,6 +615,49 @@ __global__ __launch_bounds__(TPB) void spmv_blk_kernel(int nvo, const int *__res
   }
 }
 
+// coupling blocks INCLUDING ghost columns: xv is a full vector in the [u | p | ghost triplets] layout whose
+// ghost tail was refreshed by comm_halo.  GB 2: y_u = b_u - A01 x_p ; GB 3: y_p = b_p - A10 x_u.
+template <int GB>
+__global__ __launch_bounds__(TPB) void spmv_blk_ghost_kernel(int nvo, const int *__restrict__ vptr, const int *__restrict__ vcol,
+                                                             const double *__restrict__ A, const double *__restrict__ xv,
+                                                             double *__restrict__ y, const double *__restrict__ bvec) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  double a0 = 0, a1 = 0;
+  if (row < nvo) {
+    const int ks = vptr[row], ke = vptr[row + 1];
+    for (int k = ks + l; k < ke; k += 8) {
+      const int w = vcol[k];
+      const double2 cc = *(const double2 *)(A + 2 * (size_t)k);
+      if (GB == 2) {
+        const double xp = xv[poff(w, nvo)];
+        a0 += cc.x * xp; a1 += cc.y * xp;
+      } else {
+        const int uo = uoff(w, nvo);
+        a0 += cc.x * xv[uo] + cc.y * xv[uo + 1];
+      }
+    }
+  }
+  a0 = group8_sum(a0);
+  if (GB == 2) a1 = group8_sum(a1);
+  if (row < nvo && l == 0) {
+    if (GB == 2) {
+      const double2 bb = *(const double2 *)(bvec + 2 * (size_t)row);
+      *(double2 *)(y + 2 * (size_t)row) = make_double2(bb.x - a0, bb.y - a1);
+    } else {
+      y[row] = bvec[row] - a0;
+    }
+  }
+}
+int k_spmv_block_ghost(cfdh_ctx *c, int blk, const double *xv, double *y, const double *b) {
+  const long long nthreads = 8ll * c->nvo;
+  dim3 grid((unsigned)((nthreads + TPB - 1) / TPB)), block(TPB);
+  if (blk == 2) hipLaunchKernelGGL((spmv_blk_ghost_kernel<2>), grid, block, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A01.p, xv, y, b);
+  else hipLaunchKernelGGL((spmv_blk_ghost_kernel<3>), grid, block, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A10.p, xv, y, b);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int k_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b, double /*alpha*/) {
   const long long nthreads = 8ll * c->nvo;
   dim3 grid((unsigned)((nthreads + TPB - 1) / TPB)), block(TPB);

@@ -226,42 +226,56 @@ int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
   return 0;
 }
 
-// part: 0 = whole application; with a replicated global pressure space the application is split at the
-// all-reduce of the pressure right-hand side: 1 = up to it, 2 = after it (each part is graph-capturable)
-static int pc_apply_body(cfdh_ctx *c, const double *r, double *z, int part) {
+// The application is a sequence of stages separated by the exchanges of a partitioned run:
+//   stage 0: y_u = V(A00~) r_u                                   | halo(y_u)
+//   stage 1: t_p = r_p - A10 y_u ; zH = Cheb3(H) t_p ; y = M_l zH | all-reduce of the global pressure rhs
+//   stage 2: t = V(L) y ; z_p = a' t + b' zH                      | halo(z_p)
+//   stage 3: z_u = V(A00~)(r_u - A01 z_p)
+// With one rank (no exchanges) all stages run back to back; each stage is graph-capturable.
+static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
   const int nvo = c->nvo, nu = 2 * nvo;
   const double *ru = r, *rp = r + nu;
   double *zu = z, *zp = z + nu;
+  const bool multi = c->nranks > 1;
+  const bool global_p = c->gp_n > 0 && multi;
   if (c->opt.pc_type == 1) {
-    const bool global_p = c->gp_n > 0 && c->nranks > 1;
-    if (part != 2) {
-      CHK(k_amg_vcycle(c, c->hA, ru, c->pu0.p));              // y_u = V(A00~) r_u   (both components at once)
-      CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));     // t_p = r_p - A10 y_u
-      // z_p = S~^-1 t_p : zH = Cheb3(H) t_p ; y = M_l zH ; z_p = a' V(L) y + b' zH
-      CHK(k_level_smooth(c, &c->Hlev, c->pp0.p, c->pp1.p, 3));
-      CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
-      if (global_p) {
-        CHK(v_zero(c, c->gp_n, c->gp_rhs.p));
-        CHK(k_scatter_global(c, nvo, c->gp_l2g.p, c->pu1.p, c->gp_rhs.p));
-      }
+    switch (stage) {
+      case 0:
+        // in a partitioned run y_u lands in the halo scratch vector so that its ghosts can be refreshed
+        CHK(k_amg_vcycle(c, c->hA, ru, multi ? c->pcw.p : c->pu0.p));
+        return 0;
+      case 1:
+        if (multi) CHK(k_spmv_block_ghost(c, 3, c->pcw.p, c->pp0.p, rp));   // t_p = r_p - A10 y_u (with ghosts)
+        else CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));
+        CHK(k_level_smooth(c, &c->Hlev, c->pp0.p, c->pp1.p, 3));
+        CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
+        if (global_p) {
+          CHK(v_zero(c, c->gp_n, c->gp_rhs.p));
+          CHK(k_scatter_global(c, nvo, c->gp_l2g.p, c->pu1.p, c->gp_rhs.p));
+        }
+        return 0;
+      case 2:
+        if (global_p) {
+          CHK(k_amg_vcycle(c, c->hLg, c->gp_rhs.p, c->gp_sol.p));  // the same global V-cycle on every rank
+          CHK(k_gather_global(c, nvo, c->gp_l2g.p, c->gp_sol.p, c->pu2.p));
+        } else {
+          CHK(k_amg_vcycle(c, c->hL, c->pu1.p, c->pu2.p));
+        }
+        CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, c->pp0.p, c->ccPbc.p, zp));
+        if (multi && c->opt.schur_full) CHK(v_copy(c, nvo, zp, c->pcw.p + nu));  // z_p into the halo scratch vector
+        return 0;
+      default:
+        if (c->opt.schur_full) {
+          if (multi) CHK(k_spmv_block_ghost(c, 2, c->pcw.p, c->pu0.p, ru));  // t_u = r_u - A01 z_p (with ghosts)
+          else CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));
+          CHK(k_amg_vcycle(c, c->hA, c->pu0.p, zu));
+        } else {
+          CHK(v_copy(c, nu, multi ? c->pcw.p : c->pu0.p, zu));              // block lower-triangular variant
+        }
+        return 0;
     }
-    if (part == 1) return 0;
-    if (global_p) {
-      CHK(k_amg_vcycle(c, c->hLg, c->gp_rhs.p, c->gp_sol.p)); // the same global V-cycle on every rank
-      CHK(k_gather_global(c, nvo, c->gp_l2g.p, c->gp_sol.p, c->pu2.p));
-    } else {
-      CHK(k_amg_vcycle(c, c->hL, c->pu1.p, c->pu2.p));
-    }
-    CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, c->pp0.p, c->ccPbc.p, zp));
-    if (c->opt.schur_full) {
-      CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));         // t_u = r_u - A01 z_p
-      CHK(k_amg_vcycle(c, c->hA, c->pu0.p, zu));            // z_u = V(A00~) t_u
-    } else {
-      CHK(v_copy(c, nu, c->pu0.p, zu));                     // block lower-triangular variant
-    }
-    return 0;
   }
-  if (part == 2) return 0;
+  if (stage != 0) return 0;  // pc_type 0 is rank-local: one stage
   CHK(k_cheb_a00(c, ru, c->pu0.p));                       // y_u = C(A00) r_u
   CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));     // t_p = r_p - A10 y_u
   CHK(k_amg_vcycle(c, c->hS, c->pp0.p, zp));              // z_p = V(Sp) t_p
@@ -274,56 +288,59 @@ static int pc_apply_body(cfdh_ctx *c, const double *r, double *z, int part) {
   return 0;
 }
 
-// z = P^-1 r.  The ~35 kernels of one application have fixed shapes, so they are captured
-// into a hipGraph and replayed (the Krylov loop is launch-bound otherwise: MI355X guide,
-// "graph-replay-floor").  Operands differ per Krylov slot (r = V_j, z = Z_j), so one graph is
-// kept per (r, z) pair -- no staging copies; all are dropped when the hierarchy is rebuilt.
-static int capture_part(cfdh_ctx *c, const double *r, double *z, int part, hipGraphExec_t *out) {
-  hipGraph_t g = nullptr;
-  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  c->capturing = true;
-  int rc = pc_apply_body(c, r, z, part);
-  c->capturing = false;
-  hipError_t e = hipStreamEndCapture(c->stream, &g);
-  if (rc) return rc;
-  if (e != hipSuccess || !g) return cfdh_fail(c, CFDH_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-  e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(g);
-  if (e != hipSuccess) return cfdh_fail(c, CFDH_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+// exchange that follows stage `stage` in a partitioned run
+static int pc_exchange(cfdh_ctx *c, int stage) {
+  if (c->nranks <= 1 || c->opt.pc_type != 1) return 0;
+  if (stage == 0) return comm_halo(c, c->pcw.p);
+  if (stage == 1) return (c->gp_n > 0) ? comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0) : 0;
+  if (stage == 2) return c->opt.schur_full ? comm_halo(c, c->pcw.p) : 0;
   return 0;
 }
 
+// z = P^-1 r.  The kernels of one application have fixed shapes, so every stage is captured into a
+// hipGraph and replayed (the Krylov loop is launch-bound otherwise: MI355X guide, "graph-replay-floor").
+// Operands differ per Krylov slot (r = V_j, z = Z_j), so graphs are kept per (r, z) pair -- no staging
+// copies; all are dropped when a hierarchy is rebuilt.
 int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z) {
   const int nvo = c->nvo;
   const bool graph = c->use_graph && !c->prof_on;
-  const bool split = c->opt.pc_type == 1 && c->gp_n > 0 && c->nranks > 1;  // all-reduce in the middle
+  const bool multi = c->nranks > 1 && c->opt.pc_type == 1;
+  if (multi && !c->pcw.p) { HIPCHK(c, c->pcw.alloc(c->NL)); HIPCHK(c, c->pcw.zero(c->stream)); }
   if (!graph) {
-    if (split) {
-      CHK(pc_apply_body(c, r, z, 1));
-      CHK(comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0));
-      CHK(pc_apply_body(c, r, z, 2));
-    } else {
-      CHK(pc_apply_body(c, r, z, 0));
-    }
+    for (int st = 0; st < 4; st++) { CHK(pc_stage(c, r, z, st)); CHK(pc_exchange(c, st)); }
   } else {
     if (!c->pc_graph_valid) {
-      for (auto &e : c->pc_graphs) { if (e.exec) (void)hipGraphExecDestroy(e.exec); if (e.exec2) (void)hipGraphExecDestroy(e.exec2); }
+      for (auto &e : c->pc_graphs) for (auto &x : e.exec) if (x) (void)hipGraphExecDestroy(x);
       c->pc_graphs.clear();
       c->pc_graph_valid = true;
     }
     cfdh_ctx::PcGraph *pg = nullptr;
     for (auto &e : c->pc_graphs) if (e.r == r && e.z == z) { pg = &e; break; }
     if (!pg) {
-      cfdh_ctx::PcGraph ng{r, z, nullptr, nullptr};
-      CHK(capture_part(c, r, z, split ? 1 : 0, &ng.exec));
-      if (split) CHK(capture_part(c, r, z, 2, &ng.exec2));
+      cfdh_ctx::PcGraph ng{r, z, {nullptr, nullptr, nullptr, nullptr}};
+      // one rank: all four stages in one graph; partitioned: one graph per stage
+      for (int gidx = 0; gidx < (multi ? 4 : 1); gidx++) {
+        hipGraph_t g = nullptr;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        c->capturing = true;
+        int rc = 0;
+        if (multi) rc = pc_stage(c, r, z, gidx);
+        else for (int st = 0; st < 4 && !rc; st++) rc = pc_stage(c, r, z, st);
+        c->capturing = false;
+        hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc) return rc;
+        if (e != hipSuccess || !g) return cfdh_fail(c, CFDH_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&ng.exec[gidx], g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return cfdh_fail(c, CFDH_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+      }
       c->pc_graphs.push_back(ng);
       pg = &c->pc_graphs.back();
     }
-    HIPCHK(c, hipGraphLaunch(pg->exec, c->stream));
-    if (split) {
-      CHK(comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0));
-      HIPCHK(c, hipGraphLaunch(pg->exec2, c->stream));
+    if (!multi) {
+      HIPCHK(c, hipGraphLaunch(pg->exec[0], c->stream));
+    } else {
+      for (int st = 0; st < 4; st++) { HIPCHK(c, hipGraphLaunch(pg->exec[st], c->stream)); CHK(pc_exchange(c, st)); }
     }
   }
   if (c->singular) CHK(v_sub_mean(c, nvo, z + 2 * (size_t)nvo));
