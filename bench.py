@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--m", type=int, default=200, help="DFG mesh parameter (m=200: 336,474 vertices, 1,009,422 DOF)")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--prof-steps", type=int, default=2, help="extra steps with HIP-event kernel timing (after the timed region)")
+    ap.add_argument("--host-loop-steps", type=int, default=5, help="extra steps with the reference's host-copy loop (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "host"])
     ap.add_argument("--verbose", type=int, default=0)
@@ -133,6 +134,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
+    # the reference's literal loop: u_prev.x.array[:] = u_sol.x.array[:] through the host every step
+    # (scenario.py:306-307) -> PCIe-inclusive rate, reported beside `value`, never as `value`
+    pcie_rate = None
+    if world == 1 and args.host_loop_steps > 0:
+        sync_all()
+        t0h = time.perf_counter()
+        for _ in range(args.host_loop_steps):
+            solver.solveStep()
+            solver.u_prev.x.array[:] = solver.u_sol.x.array[:]
+            solver.p_prev.x.array[:] = solver.p_sol.x.array[:]
+        sync_all()
+        pcie_rate = args.host_loop_steps / (time.perf_counter() - t0h)
+
     # parity metrics of the run (global values)
     drag, lift = sc.drag_lift()
     l2u = solver.functional(2)
@@ -194,6 +208,7 @@ def main():
         "newton_its_per_step": float(np.mean(its_newton)),
         "krylov_its_per_step": float(np.mean(its_krylov)),
         "setup_s": t_setup,
+        "pcie_inclusive_steps_per_s": pcie_rate,
         "drag_coefficient": drag,
         "lift_coefficient": lift,
         "velocity_l2": l2u,

@@ -334,7 +334,7 @@ def create_stenosis_channel(ny, L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, seve
     the exact CAD outline is out of scope).
 
     Structured ny cells across, uniform aspect ~1 in x, shorter-diagonal split.
-    Markers: inlet=1 (x=0), outlet=2 (x=L), wall=3.
+    Markers as in the reference (stenosis.py:22-25): inlet=2 (x=0), outlet=3 (x=L), wall=4.
     """
     ny = int(ny)
     if half_len is None:
@@ -356,8 +356,8 @@ def create_stenosis_channel(ny, L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, seve
     cells = _split_quads(x, quads)
     mesh = Mesh(cells, x, comm=comm, name="stenosis")
     mid = mesh.facet_midpoints()
-    marker = np.full(mesh.num_facets, 3, dtype=np.int32)
-    marker[np.abs(mid[:, 0]) < 1e-9] = 1
-    marker[np.abs(mid[:, 0] - L) < 1e-9] = 2
+    marker = np.full(mesh.num_facets, 4, dtype=np.int32)
+    marker[np.abs(mid[:, 0]) < 1e-9] = 2
+    marker[np.abs(mid[:, 0] - L) < 1e-9] = 3
     ft = MeshTags(mesh, 1, np.arange(mesh.num_facets, dtype=np.int32), marker)
     return mesh, ft

@@ -1,8 +1,17 @@
 """2-D stenosed channel with the boundary data of
 /root/reference/src/scenarios/stenosis.py:124-156 (walls no-slip, parabolic
-inlet `v_max (1 - ((y-R_in)/R_in)^2)` only when `v_max` is given, no pressure
-condition) on the structured y-profile mesh of `mesh.create_stenosis_channel`.
-Units mm, g, s: rho = 1.06e-3 g/mm^3, mu = 3.5e-3 (stenosis.py:27-31)."""
+inlet `v_max (1 - ((y-R_in)/R_in)^2)` only when `v_max` is given) on the
+structured y-profile mesh of `mesh.create_stenosis_channel`.
+Units mm, g, s: rho = 1.06e-3 g/mm^3, mu = 3.5e-3 (stenosis.py:27-31).
+
+Pressure: the reference passes NO pressure condition to `stabilized_schur` for this
+scenario (its p_inlet/p_outlet kwargs are swallowed).  With the
+form of stabilized_schur.py:79 (`+ p n.v ds` on every exterior facet) the constant
+pressure is then in the null space of every Jacobian even with an open outlet, and the
+Newton systems with a prescribed inflow are inconsistent (FGMRES stagnates at ~1e-2; the
+CPU oracle shows the same).  `outlet_pressure=0.0` (default here) therefore fixes p at the
+outlet like the other open-boundary scenarios (dfg_1.py:79-91); `outlet_pressure=None`
+reproduces the reference literally."""
 from __future__ import annotations
 
 import numpy as np
@@ -14,18 +23,21 @@ from ..scenario import Scenario
 
 
 class StenosisSimulation(Scenario):
-    inlet_marker = 1
-    outlet_marker = 2
-    wall_marker = 3
+    fluid_marker = 1
+    inlet_marker = 2
+    outlet_marker = 3
+    wall_marker = 4
 
     def __init__(self, solver_name, dt, T, f: tuple[float, float] = (0, 0), *, rho=1.06e-3, mu=3.5e-3, ny=32,
-                 L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, severity=0.5, v_max=None, **solver_kwargs):
+                 L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, severity=0.5, v_max=None, outlet_pressure=0.0,
+                 **solver_kwargs):
         self._mesh = None
         self._ft = None
         self._bcu = None
         self._bcp = None
         self.ny, self.L, self.R_in, self.R_out = int(ny), L, R_in, R_out
         self.x_sten, self.severity, self.v_max = x_sten, severity, v_max
+        self.outlet_pressure = outlet_pressure
         self.quiet = bool(solver_kwargs.get("quiet", False))
         super().__init__(solver_name, "stenosis", rho, mu, dt, T, f, **solver_kwargs)
         self.setup()
@@ -54,13 +66,19 @@ class StenosisSimulation(Scenario):
                 ui.interpolate(self.inlet_profile)
                 bc_i = BoundaryCondition(ui)
                 bc_i.initTopological(fdim, self._ft.find(self.inlet_marker))
-                self._bcu = [bc_i, bc_w]
+                self._bcu = [bc_w, bc_i]  # walls first, inlet appended (stenosis.py:135,155)
         return self._bcu
 
     @property
     def bcp(self):
-        if not self._bcp:
+        if self._bcp is None:
             self._bcp = []
+            if self.outlet_pressure is not None:
+                pr = Function(self.solver.Q)
+                pr.x.array[:] = float(self.outlet_pressure)
+                bc_o = BoundaryCondition(pr)
+                bc_o.initTopological(1, self._ft.find(self.outlet_marker))
+                self._bcp = [bc_o]
         return self._bcp
 
     def initial_velocity(self, x):

@@ -1344,14 +1344,23 @@ int orc_solve_step(orc_ctx *c, double *xv, const orc_opts *o, orc_stats *st) {
   pc.sub_rtol = o->sub_rtol; pc.sub_max_it = o->sub_max_it;
   pc.o = o;
   pc.cr = (double *)malloc(sizeof(double) * nu); pc.cd0 = (double *)malloc(sizeof(double) * nu); pc.cd1 = (double *)malloc(sizeof(double) * nu);
-  int singular = !c->any_pbc;
-  if (singular != c->singular) { c->singular = singular; c->amg_valid = 0; }
+  int singular = 0; /* decided below by MatNullSpaceTest on the assembled Jacobian (stabilized_schur.py:314) */
   if (o->remove_p_mean) remove_pmean(c, xv);
   double t0 = now_ms();
   orc_assemble(c, xv, 1, F);
   st->ms_assemble += now_ms() - t0;
   double fn = vnorm(n, F);
   st->fnorm0 = fn;
+  {
+    /* nullsp.test(A): |J n| < 1e-7 for the normalised constant-pressure vector n.  An open outlet
+     * (free velocity + the ds terms of :79) makes the system regular even without a pressure condition. */
+    double *nvec = (double *)calloc(n, sizeof(double)), *yv = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < nv; i++) nvec[nu + i] = 1.0 / sqrt((double)nv);
+    blk_mult(c, 0, nvec, yv);
+    singular = vnorm(n, yv) < 1e-7;
+    free(nvec); free(yv);
+    if (singular != c->singular) { c->singular = singular; c->amg_valid = 0; }
+  }
   int reason = 0;
   for (int it = 0;; it++) {
     if (o->verbose) printf("  oracle newton %d |F| = %.6e\n", it, fn);

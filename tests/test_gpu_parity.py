@@ -5,7 +5,7 @@ drag/lift/L2 1e-8 (north_star asks 1e-6)."""
 import numpy as np
 import pytest
 
-from util import dfg_case, lid_case, load_golden, make_ctx, make_oracle
+from util import dfg_case, lid_case, load_golden, make_ctx, make_oracle, stenosis_case
 
 pytestmark = pytest.mark.gpu
 
@@ -92,7 +92,7 @@ def test_golden_vectors(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("case_fn,arg,nsteps", [(dfg_case, 16, 4), (lid_case, 24, 3)])
+@pytest.mark.parametrize("case_fn,arg,nsteps", [(dfg_case, 16, 4), (lid_case, 24, 3), (stenosis_case, 12, 3)])
 def test_time_steps_match_oracle(case_fn, arg, nsteps):
     """Same mesh, dt, initial state; both sides converged tightly; the oracle runs the reference's
     own preconditioner configuration (ILU-based), the GPU its Chebyshev/AMG one."""

@@ -45,7 +45,7 @@ def test_locate_entities_all_vertices_rule():
 
 def test_stenosis_channel_markers():
     m, ft = create_stenosis_channel(8, L=20.0, x_sten=8.0)
-    assert set(np.unique(ft.values)) == {1, 2, 3}
+    assert set(np.unique(ft.values)) == {2, 3, 4}
     assert m.cell_areas().min() > 0
 
 
