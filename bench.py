@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "host"])
     ap.add_argument("--verbose", type=int, default=0)
+    ap.add_argument("--solver", default="stabilized_schur", choices=["stabilized_schur", "stabilized_schur_bdf2"],
+                    help="solver plugin (default: the headline one)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,7 +100,7 @@ def main():
     dt = 0.01
     comm = PartComm(rank, world, args.comm) if world > 1 else None
     t0 = time.perf_counter()
-    sc = DFG1Benchmark("stabilized_schur", dt, 1.0, m=args.m, quiet=True, device=local_rank, comm=comm,
+    sc = DFG1Benchmark(args.solver, dt, 1.0, m=args.m, quiet=True, device=local_rank, comm=comm,
                        verbose=args.verbose)
     solver = sc.solver
     ctx = solver.ctx
@@ -186,7 +188,7 @@ def main():
                 "algorithmic_bytes": d["algorithmic_MB"] * 1e6}
 
     out = {
-        "metric": "time-steps/sec, dfg_1 ~1M DOF (stabilized_schur)",
+        "metric": "time-steps/sec, dfg_1 ~1M DOF (%s)" % args.solver,
         "value": args.steps / elapsed,
         "unit": "time-steps/s",
         "n_gpus": world,
@@ -226,11 +228,17 @@ def main():
         O.set_threads(cores)
         x = np.zeros(3 * nv)
         O.set_un(np.zeros(2 * nv))
+        bdf2 = args.solver == "stabilized_schur_bdf2"
+        un_hist = np.zeros(2 * nv)
         opts = orc.default_opts(pc_kind=2)  # same Newton / FGMRES / Cahouet-Chabard + AMG algorithm and tolerances
         t0 = time.perf_counter()
         nst = 0
         for _ in range(args.warmup + args.cpu_steps):
             ts = time.perf_counter()
+            if bdf2:
+                O.set_scheme(1.0, *((1.0, -1.0, 0.0) if nst == 0 else (1.5, -2.0, 0.5)))
+                O.set_un2(un_hist)
+                un_hist = x[: 2 * nv].copy()  # u_prev of this step = u_prev2 of the next
             x, so = O.solve_step(x, opts)
             O.set_un(x[: 2 * nv])
             nst += 1

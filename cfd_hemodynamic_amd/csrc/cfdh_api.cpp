@@ -227,6 +227,38 @@ int cfdh_advance(cfdh_ctx *c) {
   return 0;
 }
 
+int cfdh_set_time_scheme(cfdh_ctx *c, double theta, double a0, double a1, double a2) {
+  ENTER(c);
+  if (!(theta > 0) || theta > 1 || !(a0 > 0)) return cfdh_fail(c, CFDH_E_ARG, "time scheme needs 0 < theta <= 1 and a0 > 0");
+  if (theta != c->ts_theta || a0 != c->ts_a[0]) c->pc_valid = false;  // a0/(theta dt) scales the preconditioner
+  if (theta != c->ts_theta || a0 != c->ts_a[0] || a1 != c->ts_a[1] || a2 != c->ts_a[2]) c->jac_valid = false;
+  c->ts_theta = theta; c->ts_a[0] = a0; c->ts_a[1] = a1; c->ts_a[2] = a2;
+  return 0;
+}
+
+int cfdh_set_previous2(cfdh_ctx *c, const double *u_prev2) {
+  ENTER(c);
+  if (!u_prev2) return cfdh_fail(c, CFDH_E_ARG, "u_prev2 is NULL");
+  std::vector<double> h;
+  pack_vec(c, u_prev2, nullptr, h, nullptr);
+  CHK(upload_vec(c, h, c->xprev2.p));
+  return 0;
+}
+
+int cfdh_get_previous2(cfdh_ctx *c, double *u_prev2) {
+  ENTER(c);
+  std::vector<double> h;
+  CHK(download_vec(c, c->xprev2.p, h));
+  unpack_vec(c, h, u_prev2, nullptr);
+  return 0;
+}
+
+int cfdh_shift_history(cfdh_ctx *c) {
+  ENTER(c);
+  CHK(v_copy(c, c->NL, c->xprev.p, c->xprev2.p));
+  return 0;
+}
+
 int cfdh_assemble(cfdh_ctx *c, int want_jacobian) {
   ENTER(c);
   if (!c->params_set) return cfdh_fail(c, CFDH_E_STATE, "cfdh_set_params was not called");

@@ -157,7 +157,8 @@ struct cfdh_ctx {
   dbuf<int> d_fac_cell, d_fac_local, d_fac_marker;
 
   // state: layout [u owned 2*nvo | p owned nvo | ghosts 3*ng (ux,uy,p)]
-  dbuf<double> x, xt, xprev, F, dvec;
+  dbuf<double> x, xt, xprev, xprev2, F, dvec;
+  double ts_theta = 0.5, ts_a[3] = {1.0, -1.0, 0.0};  // cfdh_set_time_scheme
   bool state_set = false;
 
   // reductions

@@ -171,13 +171,14 @@ int k_moments(cfdh_ctx *c) {
 
 // ---------------------------------------------------------------- fused assembly
 struct AsmArgs {
-  const double *coords, *mom, *x, *un, *bcval, *bcmult;
+  const double *coords, *mom, *x, *un, *un2, *bcval, *bcmult;
   const int *vptr, *vdiag, *inc_cell, *blk_row, *blk_inc, *blk_maxrank, *blk_vptr, *blk_vlist, *blk_cptr, *blk_clist, *wave_maxlen;
   const unsigned *inc_slot, *inc_rank, *inc_loc;
   const unsigned char *cflag, *bcflag;
   double *A00, *A01, *A10, *A11, *F;
   int nvo;
   double dt, rho, mu, muf, fx, fy;
+  double theta, a0, a1, a2;  // time scheme (cfdh_set_time_scheme)
 };
 
 // MODE 0: residual only; 1: residual + Jacobian; 2: residual with lifting (Jacobian in registers only)
@@ -187,11 +188,13 @@ struct AsmArgs {
 // coordinates, iterate, u_prev, Dirichlet flags, and the 64-B tau-moment records; every lane then
 // gathers its element from LDS only (a per-lane gather from global memory costs one L1 line
 // per lane per load and made the first version of this kernel L1/TA-bound).
-template <int MODE, int OCC = 3>
+// HIST2: the time term carries a2*u_prev2 (BDF2 steps of stabilized_schur_bdf2.py:95-110).
+template <int MODE, bool HIST2 = false, int OCC = 3>
 __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
   constexpr bool JAC = (MODE != 0);
   constexpr bool WJ = (MODE == 1);
   __shared__ double2 sX[CFDH_MAX_BV], sU[CFDH_MAX_BV], sUn[CFDH_MAX_BV];
+  __shared__ double2 sUn2[HIST2 ? CFDH_MAX_BV : 1];
   __shared__ double sP[CFDH_MAX_BV];
   __shared__ int sVid[CFDH_MAX_BV];
   __shared__ unsigned char sFl[CFDH_MAX_BV];
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
       sU[i] = make_double2(p.x[uo], p.x[uo + 1]);
       sP[i] = p.x[po];
       sUn[i] = make_double2(p.un[uo], p.un[uo + 1]);
+      if (HIST2) sUn2[i] = make_double2(p.un2[uo], p.un2[uo + 1]);
       sFl[i] = p.bcflag[vid];
     }
     const int c0 = p.blk_cptr[blk], ncl = p.blk_cptr[blk + 1] - c0;
@@ -269,14 +273,21 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
     g[2][0] = (X[0][1] - X[1][1]) * idet; g[2][1] = (X[1][0] - X[0][0]) * idet;
     const double area = 0.5 * fabs(det);
     const double rho = p.rho, mu = p.mu, idt = 1.0 / p.dt;
+    const double th = p.theta, a0idt = p.a0 * idt;
     double ub[3][2], w[3][2], G[2][2] = {{0, 0}, {0, 0}}, gp[2] = {0, 0};
 #pragma unroll
-    for (int b = 0; b < 3; b++)
+    for (int b = 0; b < 3; b++) {
+      double h2[2] = {0, 0};
+      if (HIST2) {
+        const double2 q = sUn2[lv[b]];
+        h2[0] = p.a2 * q.x; h2[1] = p.a2 * q.y;
+      }
 #pragma unroll
       for (int i = 0; i < 2; i++) {
-        ub[b][i] = 0.5 * (ue[b][i] + une[b][i]);
-        w[b][i] = (ue[b][i] - une[b][i]) * idt;
+        ub[b][i] = th * ue[b][i] + (1.0 - th) * une[b][i];
+        w[b][i] = (p.a0 * ue[b][i] + p.a1 * une[b][i] + h2[i]) * idt;
       }
+    }
 #pragma unroll
     for (int b = 0; b < 3; b++)
 #pragma unroll
@@ -346,12 +357,12 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
 #pragma unroll
           for (int j = 0; j < 2; j++) {
             const double dij = (i == j) ? 1.0 : 0.0;
-            double v = rho * mab0[b] * dij * idt;
-            v += rho * 0.5 * (mab0[b] * G[j][i] + dij * mBa);
-            v += area * mu * 0.5 * (g[b][i] * g[0][j] + gg0b * dij);
-            v += rho * ((dij * idt + 0.5 * G[j][i]) * MBa[b] + 0.5 * dij * BMBa);
-            v += 0.5 * g[0][j] * Q[b][i];
-            v += rho * Lm * 0.5 * g[b][j] * g[0][i];
+            double v = rho * mab0[b] * dij * a0idt;
+            v += rho * th * (mab0[b] * G[j][i] + dij * mBa);
+            v += area * mu * th * (g[b][i] * g[0][j] + gg0b * dij);
+            v += rho * ((dij * a0idt + th * G[j][i]) * MBa[b] + th * dij * BMBa);
+            v += th * g[0][j] * Q[b][i];
+            v += rho * Lm * th * g[b][j] * g[0][i];
             J00[b][i][j] = v;
           }
           J01[b][i] = -area * (1.0 / 3.0) * g[0][i] + g[b][i] * mtB[0];
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const double Gg = G[j][0] * g[0][0] + G[j][1] * g[0][1];
-          J10[b][j] = area * (1.0 / 6.0) * g[b][j] + mt[b] * (g[0][j] * idt + 0.5 * Gg) + 0.5 * g[0][j] * mtB[b];
+          J10[b][j] = area * (1.0 / 3.0) * th * g[b][j] + mt[b] * (g[0][j] * a0idt + th * Gg) + th * g[0][j] * mtB[b];
         }
         J11[b] = T * gg0b / rho;
       }
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
 #pragma unroll
             for (int b = 0; b < 3; b++)
 #pragma unroll
-              for (int j = 0; j < 2; j++) J00[b][i][j] -= p.muf * 0.25 * g[b][i] * n[j] * elen;
+              for (int j = 0; j < 2; j++) J00[b][i][j] -= p.muf * (0.5 * th) * g[b][i] * n[j] * elen;
           }
         }
       }
@@ -511,17 +522,26 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
 
 int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
   AsmArgs a;
-  a.coords = c->coords.p; a.mom = c->mom.p; a.x = xstate; a.un = c->xprev.p; a.bcval = c->bcval.p; a.bcmult = c->bcmult.p;
+  a.coords = c->coords.p; a.mom = c->mom.p; a.x = xstate; a.un = c->xprev.p; a.un2 = c->xprev2.p; a.bcval = c->bcval.p; a.bcmult = c->bcmult.p;
   a.vptr = c->vptr.p; a.vdiag = c->vdiag.p; a.inc_cell = c->inc_cell.p;
   a.blk_vptr = c->blk_vptr.p; a.blk_vlist = c->blk_vlist.p; a.blk_cptr = c->blk_cptr.p; a.blk_clist = c->blk_clist.p; a.inc_loc = c->inc_loc.p; a.wave_maxlen = c->wave_maxlen.p;
   a.blk_row = c->blk_row.p; a.blk_inc = c->blk_inc.p; a.blk_maxrank = c->blk_maxrank.p;
   a.inc_slot = c->inc_slot.p; a.inc_rank = c->inc_rank.p; a.cflag = c->cflag.p; a.bcflag = c->bcflag.p;
   a.A00 = c->A00.p; a.A01 = c->A01.p; a.A10 = c->A10.p; a.A11 = c->A11.p; a.F = c->F.p;
   a.nvo = c->nvo; a.dt = c->dt; a.rho = c->rho; a.mu = c->mu; a.muf = c->muf; a.fx = c->f[0]; a.fy = c->f[1];
+  a.theta = c->ts_theta; a.a0 = c->ts_a[0]; a.a1 = c->ts_a[1]; a.a2 = c->ts_a[2];
+  const bool hist2 = c->ts_a[2] != 0.0;
   prof_begin(c, 0);
-  if (mode == 1) hipLaunchKernelGGL(asm_kernel<1>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
-  else if (mode == 2) hipLaunchKernelGGL(asm_kernel<2>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
-  else hipLaunchKernelGGL(asm_kernel<0>, dim3(c->nblk), dim3(CFDH_MAX_INC), 0, c->stream, a);
+  const dim3 gr(c->nblk), bl(CFDH_MAX_INC);
+  if (!hist2) {
+    if (mode == 1) hipLaunchKernelGGL((asm_kernel<1, false>), gr, bl, 0, c->stream, a);
+    else if (mode == 2) hipLaunchKernelGGL((asm_kernel<2, false>), gr, bl, 0, c->stream, a);
+    else hipLaunchKernelGGL((asm_kernel<0, false>), gr, bl, 0, c->stream, a);
+  } else {
+    if (mode == 1) hipLaunchKernelGGL((asm_kernel<1, true>), gr, bl, 0, c->stream, a);
+    else if (mode == 2) hipLaunchKernelGGL((asm_kernel<2, true>), gr, bl, 0, c->stream, a);
+    else hipLaunchKernelGGL((asm_kernel<0, true>), gr, bl, 0, c->stream, a);
+  }
   prof_end(c, 0);
   HIPCHK(c, hipGetLastError());
   if (mode == 1) c->jac_valid = true;

@@ -345,9 +345,9 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
   HIPCHK(c, c->bcmult.alloc(3 * (size_t)nv));
   c->bc_dirty = true;
   const size_t NL = c->NL;
-  HIPCHK(c, c->x.alloc(NL)); HIPCHK(c, c->xt.alloc(NL)); HIPCHK(c, c->xprev.alloc(NL));
+  HIPCHK(c, c->x.alloc(NL)); HIPCHK(c, c->xt.alloc(NL)); HIPCHK(c, c->xprev.alloc(NL)); HIPCHK(c, c->xprev2.alloc(NL));
   HIPCHK(c, c->F.alloc(NL)); HIPCHK(c, c->dvec.alloc(NL));
-  HIPCHK(c, c->x.zero(s)); HIPCHK(c, c->xt.zero(s)); HIPCHK(c, c->xprev.zero(s)); HIPCHK(c, c->F.zero(s)); HIPCHK(c, c->dvec.zero(s));
+  HIPCHK(c, c->x.zero(s)); HIPCHK(c, c->xt.zero(s)); HIPCHK(c, c->xprev.zero(s)); HIPCHK(c, c->xprev2.zero(s)); HIPCHK(c, c->F.zero(s)); HIPCHK(c, c->dvec.zero(s));
   c->red_blocks = 1024;
   HIPCHK(c, c->red_partial.alloc((size_t)c->red_blocks * 260));
   HIPCHK(c, c->red_out.alloc(1024));

@@ -147,7 +147,7 @@ static int build_cc_host(cfdh_ctx *c) {
     c->gp_dirty = false;
   }
   // --- H
-  c->cc_alpha = 2.0 * c->rho / c->dt;
+  c->cc_alpha = c->rho * c->ts_a[0] / (c->ts_theta * c->dt);  // = 2 rho/dt for the midpoint scheme
   c->cc_beta = c->mu;
   {
     CsrHost Hh;

@@ -138,6 +138,20 @@ int cfdh_get_residual(cfdh_ctx *ctx, double *ru, double *rp);
 /* device-side u_prev <- u_sol, p_prev <- p_sol (scenario.py:306-307) */
 int cfdh_advance(cfdh_ctx *ctx);
 
+/* ---- time scheme (the `stabilized_schur_bdf2` variant) ------------------------ */
+
+/* Spatial terms are evaluated at theta*u + (1-theta)*u_prev and the time term is
+ * (a0*u + a1*u_prev + a2*u_prev2)/dt.  Default (1/2; 1,-1,0) is the midpoint form of
+ * stabilized_schur.py:72-80.  stabilized_schur_bdf2.py:79-80 (u_mid = u_sol) and :95-110,
+ * :298-305 (a0,a1,a2 Constants switched by step_count) map to (1; 1,-1,0) on the first
+ * step and (1; 1.5,-2,0.5) afterwards.  theta in (0,1], a0 > 0. */
+int cfdh_set_time_scheme(cfdh_ctx *ctx, double theta, double a0, double a1, double a2);
+/* u_prev2 (stabilized_schur_bdf2.py:72): upload / download; nv local vertices x 2 */
+int cfdh_set_previous2(cfdh_ctx *ctx, const double *u_prev2);
+int cfdh_get_previous2(cfdh_ctx *ctx, double *u_prev2);
+/* device-side u_prev2 <- u_prev (stabilized_schur_bdf2.py:324, end of solveStep) */
+int cfdh_shift_history(cfdh_ctx *ctx);
+
 /* ---- assembly (exposed for parity tests) ---------------------------------- */
 
 /* assembleResidual (+ assembleJacobian when want_jacobian) at the current

@@ -59,6 +59,9 @@ typedef struct orc_ctx {
   uint8_t *fflag; /* [nc] bit f: facet opposite local vertex f is exterior */
   int *fcell, *flocal;
   double dt, rho, mu, muf, f[2];
+  /* time scheme: spatial terms at theta*u + (1-theta)*u_n, time term (a0 u + a1 u_n + a2 u_nm1)/dt.
+   * stabilized_schur.py:72-80 -> (1/2; 1,-1,0); stabilized_schur_bdf2.py:79-110 -> (1; 1,-1,0) then (1; 1.5,-2,.5) */
+  double theta, a0, a1, a2;
   uint8_t *isbc;
   double *bcval, *bcmult;
   int any_pbc;
@@ -72,6 +75,7 @@ typedef struct orc_ctx {
   int *cellpos;           /* [nc][9]: index of neighbour b in row of vertex a */
   /* per-step data */
   double *un;             /* [nv][2] */
+  double *un2;            /* [nv][2] u_prev2 of stabilized_schur_bdf2.py:72 */
   double *Mom;            /* [nc][7]: M00 M01 M02 M11 M12 M22 L */
   double *Fe, *Je;        /* [nc][9], [nc][81] scratch */
   /* solver workspace (lazily allocated) */
@@ -166,8 +170,9 @@ static void moments(const double une[3][2], double area, double h, double dt, do
 
 /* Element residual Fe[9] / Jacobian Je[9][9]; local order (a,i)->2a+i, p_a->6+a. */
 static void element(const orc_ctx *c, const double xe[3][2], const double ue[3][2], const double une[3][2],
-                    const double pe[3], const double mom[7], int fflag, double Fe[9], double *Je /*81 or NULL*/) {
+                    const double un2e[3][2], const double pe[3], const double mom[7], int fflag, double Fe[9], double *Je /*81 or NULL*/) {
   const double rho = c->rho, mu = c->mu, dt = c->dt, muf = c->muf;
+  const double th = c->theta, a0 = c->a0, a1 = c->a1, a2 = c->a2;
   double g[3][2], area, h;
   geom(xe, g, &area, &h);
   double M[3][3] = {{mom[0], mom[1], mom[2]}, {mom[1], mom[3], mom[4]}, {mom[2], mom[4], mom[5]}};
@@ -175,8 +180,8 @@ static void element(const orc_ctx *c, const double xe[3][2], const double ue[3][
   double ub[3][2], w[3][2], G[2][2] = {{0, 0}, {0, 0}}, gp[2] = {0, 0};
   for (int a = 0; a < 3; a++)
     for (int i = 0; i < 2; i++) {
-      ub[a][i] = 0.5 * (ue[a][i] + une[a][i]);
-      w[a][i] = (ue[a][i] - une[a][i]) / dt;
+      ub[a][i] = th * ue[a][i] + (1.0 - th) * une[a][i];
+      w[a][i] = (a0 * ue[a][i] + a1 * une[a][i] + a2 * un2e[a][i]) / dt;
     }
   for (int a = 0; a < 3; a++)
     for (int i = 0; i < 2; i++) {
@@ -230,21 +235,21 @@ static void element(const orc_ctx *c, const double xe[3][2], const double ue[3][
         for (int i = 0; i < 2; i++) {
           for (int j = 0; j < 2; j++) {
             double dij = (i == j) ? 1.0 : 0.0;
-            double v = rho * mab[a][b] * dij / dt;
-            v += rho * 0.5 * (mab[a][b] * G[j][i] + dij * mB[a][b]);
-            v += area * mu * 0.5 * (g[b][i] * g[a][j] + gg[a][b] * dij);
-            v += rho * ((dij / dt + 0.5 * G[j][i]) * MB[b][a] + 0.5 * dij * BMB[b][a]);
-            v += 0.5 * g[a][j] * Q[b][i];
-            v += rho * Lm * 0.5 * g[b][j] * g[a][i];
+            double v = rho * mab[a][b] * dij * a0 / dt;
+            v += rho * th * (mab[a][b] * G[j][i] + dij * mB[a][b]);
+            v += area * mu * th * (g[b][i] * g[a][j] + gg[a][b] * dij);
+            v += rho * ((dij * a0 / dt + th * G[j][i]) * MB[b][a] + th * dij * BMB[b][a]);
+            v += th * g[a][j] * Q[b][i];
+            v += rho * Lm * th * g[b][j] * g[a][i];
             Je[(2 * a + i) * 9 + 2 * b + j] = v;
           }
           Je[(2 * a + i) * 9 + 6 + b] = -area / 3.0 * g[a][i] + g[b][i] * mtB[a];
         }
         for (int j = 0; j < 2; j++) {
           double Gg = G[j][0] * g[a][0] + G[j][1] * g[a][1];
-          double v = area / 3.0 * 0.5 * g[b][j];
-          v += mt[b] * (g[a][j] / dt + 0.5 * Gg);
-          v += 0.5 * g[a][j] * mtB[b];
+          double v = area / 3.0 * th * g[b][j];
+          v += mt[b] * (g[a][j] * a0 / dt + th * Gg);
+          v += th * g[a][j] * mtB[b];
           Je[(6 + a) * 9 + 2 * b + j] = v;
         }
         Je[(6 + a) * 9 + 6 + b] = T * gg[a][b] / rho;
@@ -270,7 +275,7 @@ static void element(const orc_ctx *c, const double xe[3][2], const double ue[3][
             Je[(2 * a + i) * 9 + 6 + b] += n[i] * elen * (a == b ? 2.0 : 1.0) / 6.0;
           }
           for (int b = 0; b < 3; b++)
-            for (int j = 0; j < 2; j++) Je[(2 * a + i) * 9 + 2 * b + j] -= muf * 0.5 * g[b][i] * n[j] * elen * 0.5;
+            for (int j = 0; j < 2; j++) Je[(2 * a + i) * 9 + 2 * b + j] -= muf * th * g[b][i] * n[j] * elen * 0.5;
         }
       }
     }
@@ -283,10 +288,12 @@ void orc_element(double dt, double rho, double mu, double muf, const double *f, 
   orc_ctx c;
   memset(&c, 0, sizeof c);
   c.dt = dt; c.rho = rho; c.mu = mu; c.muf = muf; c.f[0] = f[0]; c.f[1] = f[1];
+  c.theta = 0.5; c.a0 = 1.0; c.a1 = -1.0; c.a2 = 0.0;
   double g[3][2], area, h, mom[7];
   geom((const double(*)[2])xe, g, &area, &h);
   moments((const double(*)[2])une, area, h, dt, mu / rho, mom);
-  element(&c, (const double(*)[2])xe, (const double(*)[2])ue, (const double(*)[2])une, pe, mom, fflag, Fe, Je);
+  element(&c, (const double(*)[2])xe, (const double(*)[2])ue, (const double(*)[2])une, (const double(*)[2])une, pe,
+          mom, fflag, Fe, Je);
 }
 
 /* ------------------------------------------------------------------ setup */
@@ -305,10 +312,12 @@ orc_ctx *orc_create(int nv, int nc, const int *cells, const double *x, int nf, c
   c->bcval = (double *)calloc(c->ndof, sizeof(double));
   c->bcmult = (double *)calloc(c->ndof, sizeof(double));
   c->un = (double *)calloc(2 * nv, sizeof(double));
+  c->un2 = (double *)calloc(2 * nv, sizeof(double));
   c->Mom = (double *)calloc((size_t)7 * nc, sizeof(double));
   c->Fe = (double *)malloc(sizeof(double) * 9 * (size_t)nc);
   c->Je = (double *)malloc(sizeof(double) * 81 * (size_t)nc);
   c->rho = 1; c->mu = 1; c->muf = 1; c->dt = 1;
+  c->theta = 0.5; c->a0 = 1.0; c->a1 = -1.0; c->a2 = 0.0;
 #ifdef _OPENMP
   /* never oversubscribe a cgroup-limited box: default to <= 8 threads unless told otherwise */
   c->nthreads = omp_get_max_threads();
@@ -394,7 +403,7 @@ static void free_csr(csr_t *m) { free(m->rowptr); free(m->col); free(m->val); fr
 void orc_destroy(orc_ctx *c) {
   if (!c) return;
   free(c->cells); free(c->x); free(c->fflag); free(c->fcell); free(c->flocal); free(c->isbc); free(c->bcval);
-  free(c->bcmult); free(c->un); free(c->Mom); free(c->Fe); free(c->Je); free(c->vcptr); free(c->vcell);
+  free(c->bcmult); free(c->un); free(c->un2); free(c->Mom); free(c->Fe); free(c->Je); free(c->vcptr); free(c->vcell);
   free(c->vptr); free(c->vadj); free(c->rowptr); free(c->col); free(c->val); free(c->cellpos);
   free_csr(&c->A00f); free_csr(&c->Sp); free(c->sp_rowptr); free(c->sp_col);
   amg_free(c); free(c->dinvA);
@@ -404,6 +413,13 @@ void orc_destroy(orc_ctx *c) {
 void orc_set_params(orc_ctx *c, double dt, double rho, double mu, double muf, const double *f) {
   c->dt = dt; c->rho = rho; c->mu = mu; c->muf = muf; c->f[0] = f[0]; c->f[1] = f[1];
 }
+/* time scheme (see orc_ctx) */
+void orc_set_scheme(orc_ctx *c, double theta, double a0, double a1, double a2) {
+  c->theta = theta; c->a0 = a0; c->a1 = a1; c->a2 = a2;
+}
+/* u_prev2 of stabilized_schur_bdf2.py:72,324 */
+void orc_set_un2(orc_ctx *c, const double *un2) { memcpy(c->un2, un2, sizeof(double) * 2 * c->nv); }
+
 void orc_set_threads(orc_ctx *c, int n) {
 #ifdef _OPENMP
   if (n > 0) { omp_set_num_threads(n); c->nthreads = n; }
@@ -459,18 +475,19 @@ void orc_assemble(orc_ctx *c, const double *xv, int want_jac, double *F) {
   const int need_j = want_jac || any_lift;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < nc; e++) {
-    double xe[3][2], ue[3][2], une[3][2], pe[3];
+    double xe[3][2], ue[3][2], une[3][2], un2e[3][2], pe[3];
     int ld[9];
     for (int a = 0; a < 3; a++) {
       int v = c->cells[3 * e + a];
       xe[a][0] = c->x[2 * v]; xe[a][1] = c->x[2 * v + 1];
       ue[a][0] = xv[2 * v]; ue[a][1] = xv[2 * v + 1];
       une[a][0] = c->un[2 * v]; une[a][1] = c->un[2 * v + 1];
+      un2e[a][0] = c->un2[2 * v]; un2e[a][1] = c->un2[2 * v + 1];
       pe[a] = xv[nu + v];
       ld[2 * a] = 2 * v; ld[2 * a + 1] = 2 * v + 1; ld[6 + a] = nu + v;
     }
     double *Fe = c->Fe + 9 * (size_t)e, *Je = c->Je + 81 * (size_t)e;
-    element(c, xe, ue, une, pe, c->Mom + 7 * (size_t)e, c->fflag[e], Fe, need_j ? Je : NULL);
+    element(c, xe, ue, une, un2e, pe, c->Mom + 7 * (size_t)e, c->fflag[e], Fe, need_j ? Je : NULL);
     int anybc = 0;
     for (int k = 0; k < 9; k++) anybc |= c->isbc[ld[k]];
     if (anybc) {
@@ -986,7 +1003,7 @@ static int cc_setup(orc_ctx *c, const orc_opts *o) {
     free(c->ccMl); c->ccMl = (double *)malloc(sizeof(double) * nv);
     for (int i = 0; i < nv; i++) c->ccMl[i] = pbc[i] ? 0.0 : c->Ml[i];
   } else free(pbc);
-  c->cc_alpha = 2.0 * c->rho / c->dt; c->cc_beta = c->mu;
+  c->cc_alpha = c->rho * c->a0 / (c->theta * c->dt); c->cc_beta = c->mu;
   {
     csr_t Hh;
     csr_alloc(&Hh, nv, c->vptr[nv]);

@@ -44,7 +44,13 @@ _QL, _QW = quad_rule()
 
 
 class Params:
-    def __init__(self, dt, rho, mu, f=(0.0, 0.0), mu_facet=None):
+    """theta, a0, a1, a2: time scheme.  Base solver (stabilized_schur.py:72-80): spatial terms at
+    u_mid = (u + u_n)/2 -> theta = 1/2, time term (u - u_n)/dt -> (a0,a1,a2) = (1,-1,0).
+    stabilized_schur_bdf2.py:79-110: fully implicit u_mid = u -> theta = 1, time term
+    (a0 u + a1 u_n + a2 u_nm1)/dt with BDF1 (1,-1,0) on the first step, BDF2 (1.5,-2,0.5) after."""
+
+    def __init__(self, dt, rho, mu, f=(0.0, 0.0), mu_facet=None, theta=0.5, a0=1.0, a1=-1.0, a2=0.0):
+        self.theta, self.a0, self.a1, self.a2 = float(theta), float(a0), float(a1), float(a2)
         self.dt = float(dt)
         self.rho = float(rho)
         self.mu = float(mu)
@@ -96,7 +102,7 @@ def tau_moments(un, area, h, prm):
     return M, Lm
 
 
-def element_tensors(x, cells, u, un, p, prm, facet_flags=None, want_jac=True):
+def element_tensors(x, cells, u, un, p, prm, facet_flags=None, want_jac=True, un2=None):
     """Element residual Fe [nc,9] and Jacobian Je [nc,9,9].
 
     Local dof order: velocity (a,i) -> 2a+i (0..5), pressure a -> 6+a.
@@ -107,8 +113,11 @@ def element_tensors(x, cells, u, un, p, prm, facet_flags=None, want_jac=True):
     g, area, h = geometry(x, cells)
     nc = len(cells)
     ue, une, pe = u[cells], un[cells], p[cells]
-    ub = 0.5 * (ue + une)
-    w = (ue - une) / dt
+    th, a0 = prm.theta, prm.a0
+    ub = th * ue + (1.0 - th) * une
+    w = (a0 * ue + prm.a1 * une) / dt
+    if prm.a2 != 0.0:
+        w = w + prm.a2 * un2[cells] / dt
     G = np.einsum("cai,caj->cij", g, ub)  # G_ij = d_i ubar_j
     divu = G[:, 0, 0] + G[:, 1, 1]
     Cn = np.einsum("cai,cij->caj", ub, G)
@@ -143,20 +152,20 @@ def element_tensors(x, cells, u, un, p, prm, facet_flags=None, want_jac=True):
                 for i in range(2):
                     for j in range(2):
                         dij = 1.0 if i == j else 0.0
-                        v = rho * mab[:, a, b] * dij / dt
-                        v = v + rho * 0.5 * (mab[:, a, b] * G[:, j, i] + dij * mB[:, a, b])
-                        v = v + area * mu * 0.5 * (g[:, b, i] * g[:, a, j] + gg[:, a, b] * dij)
-                        v = v + rho * ((dij / dt + 0.5 * G[:, j, i]) * MB[:, b, a] + 0.5 * dij * BMB[:, b, a])
-                        v = v + 0.5 * g[:, a, j] * Q[:, b, i]
-                        v = v + rho * Lm * 0.5 * g[:, b, j] * g[:, a, i]
+                        v = rho * mab[:, a, b] * dij * a0 / dt
+                        v = v + rho * th * (mab[:, a, b] * G[:, j, i] + dij * mB[:, a, b])
+                        v = v + area * mu * th * (g[:, b, i] * g[:, a, j] + gg[:, a, b] * dij)
+                        v = v + rho * ((dij * a0 / dt + th * G[:, j, i]) * MB[:, b, a] + th * dij * BMB[:, b, a])
+                        v = v + th * g[:, a, j] * Q[:, b, i]
+                        v = v + rho * Lm * th * g[:, b, j] * g[:, a, i]
                         Je[:, 2 * a + i, 2 * b + j] = v
                     # J_up
                     Je[:, 2 * a + i, 6 + b] = -area / 3.0 * g[:, a, i] + g[:, b, i] * mtB[:, a]
                 for j in range(2):
                     Gg = G[:, j, 0] * g[:, a, 0] + G[:, j, 1] * g[:, a, 1]
-                    v = area / 3.0 * 0.5 * g[:, b, j]
-                    v = v + mt[:, b] * (g[:, a, j] / dt + 0.5 * Gg)
-                    v = v + 0.5 * g[:, a, j] * np.einsum("cd,cd->c", mt, beta[:, :, b])
+                    v = area / 3.0 * th * g[:, b, j]
+                    v = v + mt[:, b] * (g[:, a, j] * a0 / dt + th * Gg)
+                    v = v + th * g[:, a, j] * np.einsum("cd,cd->c", mt, beta[:, :, b])
                     Je[:, 6 + a, 2 * b + j] = v
                 Je[:, 6 + a, 6 + b] = T * gg[:, a, b] / rho
 
@@ -180,7 +189,7 @@ def element_tensors(x, cells, u, un, p, prm, facet_flags=None, want_jac=True):
                             Je[sel, 2 * a + i, 6 + b] += n[:, i] * elen * (2.0 if a == b else 1.0) / 6.0
                         for b in range(3):
                             for j in range(2):
-                                Je[sel, 2 * a + i, 2 * b + j] -= muf * 0.5 * g[sel, b, i] * n[:, j] * elen / 2.0
+                                Je[sel, 2 * a + i, 2 * b + j] -= muf * th * g[sel, b, i] * n[:, j] * elen / 2.0
     Fe[:, 0:6] = Fu.reshape(nc, 6)
     Fe[:, 6:9] = Fp
     return Fe, Je
@@ -240,7 +249,7 @@ class Problem:
     def split(self, xvec):
         return xvec[: 2 * self.nv].reshape(-1, 2), xvec[2 * self.nv :]
 
-    def assemble(self, xvec, un, want_jac=True, apply_bc=True):
+    def assemble(self, xvec, un, want_jac=True, apply_bc=True, un2=None):
         """F (and J as scipy CSR) at the monolithic state `xvec`, previous
         velocity `un` [nv,2]; Dirichlet handling of stabilized_schur.py:157-175."""
         u, p = self.split(xvec)
@@ -251,7 +260,8 @@ class Problem:
             if np.any(lift != 0.0):
                 need_j = True
         Fe, Je = element_tensors(self.x, self.cells, u, np.asarray(un).reshape(-1, 2), p, self.prm,
-                                 self.facet_flags, want_jac=need_j)
+                                 self.facet_flags, want_jac=need_j,
+                                 un2=None if un2 is None else np.asarray(un2).reshape(-1, 2))
         ld = self.ldofs
         if apply_bc and self.isbc.any():
             bce = self.isbc[ld]  # [nc,9]
@@ -276,12 +286,12 @@ class Problem:
         return F, J
 
     # -- Newton with a direct solve -----------------------------------------
-    def newton(self, x0, un, rtol=1e-12, atol=1e-14, max_it=25, remove_p_mean=False, verbose=False):
+    def newton(self, x0, un, rtol=1e-12, atol=1e-14, max_it=25, remove_p_mean=False, verbose=False, un2=None):
         x = x0.copy()
         hist = []
         singular = not self.isbc[2 * self.nv :].any()
         for it in range(max_it + 1):
-            F, J = self.assemble(x, un, want_jac=True)
+            F, J = self.assemble(x, un, want_jac=True, un2=un2)
             fn = np.linalg.norm(F)
             hist.append(fn)
             if verbose:

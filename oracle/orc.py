@@ -53,6 +53,8 @@ def lib():
         L.orc_clear_bcs.argtypes = [C.c_void_p]
         L.orc_add_bc.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, dp]
         L.orc_set_un.argtypes = [C.c_void_p, dp]
+        L.orc_set_un2.argtypes = [C.c_void_p, dp]
+        L.orc_set_scheme.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_assemble.argtypes = [C.c_void_p, dp, C.c_int, dp]
         L.orc_get_csr.argtypes = [C.c_void_p, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp)]
         L.orc_default_opts.argtypes = [C.POINTER(Opts)]
@@ -128,6 +130,14 @@ class Oracle:
     def set_un(self, un):
         un = np.ascontiguousarray(un, dtype=np.float64).reshape(-1)
         lib().orc_set_un(self.h, _dp(un))
+
+    def set_un2(self, un2):
+        un2 = np.ascontiguousarray(un2, dtype=np.float64).reshape(-1)
+        lib().orc_set_un2(self.h, _dp(un2))
+
+    def set_scheme(self, theta, a0, a1, a2):
+        """(1/2; 1,-1,0) = stabilized_schur.py; (1; 1,-1,0) / (1; 1.5,-2,.5) = stabilized_schur_bdf2.py:95-110,298-305."""
+        lib().orc_set_scheme(self.h, float(theta), float(a0), float(a1), float(a2))
 
     def assemble(self, xv, want_jac=True):
         xv = np.ascontiguousarray(xv, dtype=np.float64)
