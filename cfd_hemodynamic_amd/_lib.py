@@ -44,7 +44,7 @@ SYMBOLS = [
     "cfdh_create", "cfdh_destroy", "cfdh_last_error", "cfdh_abi_version", "cfdh_set_params", "cfdh_default_options",
     "cfdh_set_options", "cfdh_clear_dirichlet", "cfdh_add_dirichlet", "cfdh_set_state", "cfdh_get_solution",
     "cfdh_get_previous", "cfdh_get_residual", "cfdh_advance", "cfdh_set_time_scheme", "cfdh_set_previous2", "cfdh_get_previous2",
-    "cfdh_shift_history", "cfdh_assemble", "cfdh_get_csr", "cfdh_spmv", "cfdh_solve_step",
+    "cfdh_shift_history", "cfdh_set_boundary_terms", "cfdh_assemble", "cfdh_get_csr", "cfdh_spmv", "cfdh_solve_step",
     "cfdh_functional", "cfdh_set_global_pressure_space", "cfdh_set_halo", "cfdh_comm_unique_id", "cfdh_comm_init", "cfdh_comm_set_callbacks",
     "cfdh_profile_enable", "cfdh_profile_get", "cfdh_profile_reset", "cfdh_info",
 ]
@@ -91,6 +91,7 @@ def lib():
     L.cfdh_set_previous2.argtypes = [vp, dp]
     L.cfdh_get_previous2.argtypes = [vp, dp]
     L.cfdh_shift_history.argtypes = [vp]
+    L.cfdh_set_boundary_terms.argtypes = [vp, C.c_int, C.c_int, C.c_double]
     L.cfdh_get_residual.argtypes = [vp, dp, dp]
     L.cfdh_get_previous.argtypes = [vp, dp, dp]
     L.cfdh_advance.argtypes = [vp]
@@ -223,6 +224,9 @@ class Context:
 
     def set_time_scheme(self, theta, a0, a1, a2):
         self._chk(self.L.cfdh_set_time_scheme(self.h, float(theta), float(a0), float(a1), float(a2)))
+
+    def set_boundary_terms(self, ds_terms=True, backflow_marker=-1, beta=0.0):
+        self._chk(self.L.cfdh_set_boundary_terms(self.h, int(bool(ds_terms)), int(backflow_marker), float(beta)))
 
     def set_previous2(self, u_prev2):
         u_prev2 = np.ascontiguousarray(u_prev2, dtype=np.float64).reshape(-1)

@@ -236,6 +236,25 @@ int cfdh_set_time_scheme(cfdh_ctx *c, double theta, double a0, double a1, double
   return 0;
 }
 
+int cfdh_set_boundary_terms(cfdh_ctx *c, int ds_terms, int backflow_marker, double beta) {
+  ENTER(c);
+  if (beta < 0) return cfdh_fail(c, CFDH_E_ARG, "backflow beta must be >= 0");
+  if (!(beta > 0)) backflow_marker = -1;
+  const bool changed = (ds_terms != 0) != c->ds_terms || beta != c->bf_beta || backflow_marker != c->bf_marker;
+  c->ds_terms = ds_terms != 0; c->bf_beta = beta; c->bf_marker = backflow_marker;
+  if (!changed) return 0;
+  std::vector<unsigned char> cflag((size_t)c->nc, 0);
+  for (int k = 0; k < c->nfac; k++) {
+    cflag[c->fac_cell[k]] |= (unsigned char)(1u << c->fac_local[k]);
+    if (backflow_marker >= 0 && c->fac_marker[k] == backflow_marker) cflag[c->fac_cell[k]] |= (unsigned char)(8u << c->fac_local[k]);
+  }
+  HIPCHK(c, c->cflag.upload(cflag, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->jac_valid = false;
+  c->pc_valid = false;
+  return 0;
+}
+
 int cfdh_set_previous2(cfdh_ctx *c, const double *u_prev2) {
   ENTER(c);
   if (!u_prev2) return cfdh_fail(c, CFDH_E_ARG, "u_prev2 is NULL");

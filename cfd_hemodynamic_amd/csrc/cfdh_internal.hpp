@@ -159,6 +159,9 @@ struct cfdh_ctx {
   // state: layout [u owned 2*nvo | p owned nvo | ghosts 3*ng (ux,uy,p)]
   dbuf<double> x, xt, xprev, xprev2, F, dvec;
   double ts_theta = 0.5, ts_a[3] = {1.0, -1.0, 0.0};  // cfdh_set_time_scheme
+  bool ds_terms = true;      // cfdh_set_boundary_terms
+  double bf_beta = 0.0;
+  int bf_marker = -1;
   bool state_set = false;
 
   // reductions

@@ -179,6 +179,8 @@ struct AsmArgs {
   int nvo;
   double dt, rho, mu, muf, fx, fy;
   double theta, a0, a1, a2;  // time scheme (cfdh_set_time_scheme)
+  double beta_bf;            // backflow coefficient beta*rho on facets flagged in cflag bits 3..5 (cfdh_set_boundary_terms)
+  int ds_terms;              // the ds pair of stabilized_schur.py:79 on all exterior facets
 };
 
 // MODE 0: residual only; 1: residual + Jacobian; 2: residual with lifting (Jacobian in registers only)
@@ -189,7 +191,11 @@ struct AsmArgs {
 // gathers its element from LDS only (a per-lane gather from global memory costs one L1 line
 // per lane per load and made the first version of this kernel L1/TA-bound).
 // HIST2: the time term carries a2*u_prev2 (BDF2 steps of stabilized_schur_bdf2.py:95-110).
-template <int MODE, bool HIST2 = false, int OCC = 3>
+#ifndef CFDH_BF_OCC
+#define CFDH_BF_OCC 2  // the backflow variant needs ~10 more VGPRs than the 168 of 3 waves/SIMD: run it at 2
+#endif
+// BF: backflow facets present (compiled out otherwise so that the base solver keeps its register budget).
+template <int MODE, bool HIST2 = false, bool BF = false, int OCC = (BF ? CFDH_BF_OCC : 3)>
 __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
   constexpr bool JAC = (MODE != 0);
   constexpr bool WJ = (MODE == 1);
@@ -244,8 +250,11 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
     const int vv[3] = {sVid[lv[0]], sVid[lv[1]], sVid[lv[2]]};
     const int v0 = vv[0], v1 = vv[1], v2 = vv[2];
     row = v0;
-    unsigned cf = sCf[lc];
+    const unsigned cfraw = sCf[lc];
+    unsigned cf = cfraw & 7u, cb = cfraw >> 3;
     cf = ((cf >> a) | (cf << (3 - a))) & 7u;
+    cb = ((cb >> a) | (cb << (3 - a))) & 7u;
+    if (!p.ds_terms) cf = 0;
     // moments, rotated
     const double2 m0 = sMom[4 * lc], m1 = sMom[4 * lc + 1], m2 = sMom[4 * lc + 2], m3 = sMom[4 * lc + 3];
     const double o00 = m0.x, o01 = m0.y, o02 = m1.x, o11 = m1.y, o12 = m2.x, o22 = m2.y, Lm = m3.x;
@@ -373,6 +382,39 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
           J10[b][j] = area * (1.0 / 3.0) * th * g[b][j] + mt[b] * (g[0][j] * a0idt + th * Gg) + th * g[0][j] * mtB[b];
         }
         J11[b] = T * gg0b / rho;
+      }
+    }
+    // ---- backflow stabilisation on outlet facets that contain local vertex 0:
+    //      F -= beta rho oint (u_prev.n)_- (ubar.v), 2-point Gauss (stabilized_schur_backflow.py:165-176)
+    if (BF && (cb & 6u)) {
+#pragma unroll
+      for (int f = 1; f < 3; f++) {
+        if (!((cb >> f) & 1u)) continue;
+        const int other = (f == 1) ? 2 : 1;
+        const double gl = hypot(g[f][0], g[f][1]);
+        const double n[2] = {-g[f][0] / gl, -g[f][1] / gl};
+        const double elen = 2.0 * area * gl;
+        // nodal values re-read from LDS (keeps the register live ranges of the element algebra short)
+        const double2 un0 = sUn[lv[0]], uno = sUn[lv[other]];
+        const double s0 = un0.x * n[0] + un0.y * n[1], so = uno.x * n[0] + uno.y * n[1];
+        const double gq = 0.28867513459481288;  // 1/(2 sqrt 3)
+        double w00 = 0.0, w0o = 0.0;  // sum_q c_q l0 l0, sum_q c_q l0 lo
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const double t = q == 0 ? 0.5 - gq : 0.5 + gq;
+          const double l0 = 1.0 - t, lo = t;
+          const double sq = l0 * s0 + lo * so;
+          const double cq = p.beta_bf * 0.25 * (sq - fabs(sq)) * elen;
+          w00 += cq * l0 * l0;
+          w0o += cq * l0 * lo;
+        }
+        const double2 u0 = sU[lv[0]], uo = sU[lv[other]];
+        Fr[0] -= w00 * (th * u0.x + (1.0 - th) * un0.x) + w0o * (th * uo.x + (1.0 - th) * uno.x);
+        Fr[1] -= w00 * (th * u0.y + (1.0 - th) * un0.y) + w0o * (th * uo.y + (1.0 - th) * uno.y);
+        if (JAC) {
+          J00[0][0][0] -= th * w00; J00[0][1][1] -= th * w00;
+          J00[other][0][0] -= th * w0o; J00[other][1][1] -= th * w0o;
+        }
       }
     }
     // ---- exterior facets that contain local vertex 0 (facets 1 and 2)
@@ -530,18 +572,22 @@ int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
   a.A00 = c->A00.p; a.A01 = c->A01.p; a.A10 = c->A10.p; a.A11 = c->A11.p; a.F = c->F.p;
   a.nvo = c->nvo; a.dt = c->dt; a.rho = c->rho; a.mu = c->mu; a.muf = c->muf; a.fx = c->f[0]; a.fy = c->f[1];
   a.theta = c->ts_theta; a.a0 = c->ts_a[0]; a.a1 = c->ts_a[1]; a.a2 = c->ts_a[2];
+  a.beta_bf = c->bf_beta * c->rho; a.ds_terms = c->ds_terms ? 1 : 0;
   const bool hist2 = c->ts_a[2] != 0.0;
   prof_begin(c, 0);
   const dim3 gr(c->nblk), bl(CFDH_MAX_INC);
-  if (!hist2) {
-    if (mode == 1) hipLaunchKernelGGL((asm_kernel<1, false>), gr, bl, 0, c->stream, a);
-    else if (mode == 2) hipLaunchKernelGGL((asm_kernel<2, false>), gr, bl, 0, c->stream, a);
-    else hipLaunchKernelGGL((asm_kernel<0, false>), gr, bl, 0, c->stream, a);
-  } else {
-    if (mode == 1) hipLaunchKernelGGL((asm_kernel<1, true>), gr, bl, 0, c->stream, a);
-    else if (mode == 2) hipLaunchKernelGGL((asm_kernel<2, true>), gr, bl, 0, c->stream, a);
-    else hipLaunchKernelGGL((asm_kernel<0, true>), gr, bl, 0, c->stream, a);
-  }
+  const bool bf = c->bf_beta > 0.0 && c->bf_marker >= 0;
+#define CFDH_ASM_LAUNCH(H2, BFV)                                                                   \
+  do {                                                                                             \
+    if (mode == 1) hipLaunchKernelGGL((asm_kernel<1, H2, BFV>), gr, bl, 0, c->stream, a);         \
+    else if (mode == 2) hipLaunchKernelGGL((asm_kernel<2, H2, BFV>), gr, bl, 0, c->stream, a);    \
+    else hipLaunchKernelGGL((asm_kernel<0, H2, BFV>), gr, bl, 0, c->stream, a);                   \
+  } while (0)
+  if (!hist2 && !bf) CFDH_ASM_LAUNCH(false, false);
+  else if (hist2 && !bf) CFDH_ASM_LAUNCH(true, false);
+  else if (!hist2 && bf) CFDH_ASM_LAUNCH(false, true);
+  else CFDH_ASM_LAUNCH(true, true);
+#undef CFDH_ASM_LAUNCH
   prof_end(c, 0);
   HIPCHK(c, hipGetLastError());
   if (mode == 1) c->jac_valid = true;
@@ -1163,7 +1209,7 @@ __global__ __launch_bounds__(TPB) void cc_combine_kernel(int n, double alpha, do
                                                          const double *__restrict__ z, const double *__restrict__ r,
                                                          const unsigned char *__restrict__ pbc, double *__restrict__ out) {
   const int i = blockIdx.x * TPB + threadIdx.x;
-  if (i < n) out[i] = pbc[i] ? r[i] : alpha * t[i] + beta * z[i];
+  if (i < n) out[i] = (pbc[i] & 1) ? r[i] : alpha * t[i] + beta * z[i];
 }
 __global__ __launch_bounds__(TPB) void scatter_global_kernel(int n, const int *__restrict__ l2g, const double *__restrict__ loc, double *__restrict__ glob) {
   const int i = blockIdx.x * TPB + threadIdx.x;

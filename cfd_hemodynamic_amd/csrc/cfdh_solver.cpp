@@ -115,8 +115,19 @@ static int build_cc_host(cfdh_ctx *c) {
     CHK(cfdh_amg_setup(c, c->hA, Ah, false, 2));
   }
   // --- pressure Laplacian hierarchy (once per Dirichlet set)
+  // pbc bit0: the pressure dof is Dirichlet (identity row in H, z_p = r_p); bit1: Dirichlet in L only --
+  // with a do-nothing boundary (ds_terms off) the vertices of every exterior facet that is not a
+  // no-slip/inflow facet form the outflow boundary of the pressure Poisson problem.
   std::vector<unsigned char> pbc(nvo);
   for (int i = 0; i < nvo; i++) pbc[i] = (c->h_bcflag[i] & 4u) ? 1 : 0;
+  if (!c->ds_terms)
+    for (int k = 0; k < c->nfac; k++) {
+      const int e = c->fac_cell[k], fl = c->fac_local[k];
+      const int v1 = c->h_cells[3 * (size_t)e + (fl + 1) % 3], v2 = c->h_cells[3 * (size_t)e + (fl + 2) % 3];
+      if ((c->h_bcflag[v1] & 3u) == 3u && (c->h_bcflag[v2] & 3u) == 3u) continue;
+      if (v1 < nvo) pbc[v1] |= 2;
+      if (v2 < nvo) pbc[v2] |= 2;
+    }
   if (!c->hL.valid || c->hL_pbc != pbc || c->hL_singular != c->singular) {
     CsrHost Lh;
     Lh.n = Lh.m = nvo;
@@ -154,13 +165,13 @@ static int build_cc_host(cfdh_ctx *c) {
     Hh.n = Hh.m = nvo;
     Hh.rowptr.assign(nvo + 1, 0);
     for (int i = 0; i < nvo; i++) {
-      if (pbc[i]) { Hh.col.push_back(i); Hh.val.push_back(1.0); }
+      if (pbc[i] & 1) { Hh.col.push_back(i); Hh.val.push_back(1.0); }
       else {
         const size_t kd = (size_t)c->h_vdiag[i];
         const double T = c->h_Lval[kd] > 0 ? a11[kd] / c->h_Lval[kd] : 0.0;
         for (int k = vp[i]; k < vp[i + 1]; k++) {
           const int w = vc[k];
-          if (w >= nvo || pbc[w]) continue;
+          if (w >= nvo || (pbc[w] & 1)) continue;
           double v = c->cc_beta * a11[k];
           if (w == i) v += (1.0 + c->cc_alpha * T) * c->h_Ml[i];
           Hh.col.push_back(w); Hh.val.push_back(v);

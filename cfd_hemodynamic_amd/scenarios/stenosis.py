@@ -39,6 +39,8 @@ class StenosisSimulation(Scenario):
         self.x_sten, self.severity, self.v_max = x_sten, severity, v_max
         self.outlet_pressure = outlet_pressure
         self.quiet = bool(solver_kwargs.get("quiet", False))
+        if v_max is not None:
+            solver_kwargs["v_max"] = float(v_max)  # stenosis.py:92-94 (required by the backflow solver)
         super().__init__(solver_name, "stenosis", rho, mu, dt, T, f, **solver_kwargs)
         self.setup()
 

@@ -125,6 +125,15 @@ class Solver(SolverBase):
         if self._part is not None:
             # the pressure part of the preconditioner is solved globally (replicated) on every rank
             pnodes = np.unique(np.concatenate([bc.dofs for bc in self.bcp_d])) if self.bcp_d else np.zeros(0, np.int32)
+            if not getattr(self, "_ds_terms", True):
+                # do-nothing boundary: the vertices of the exterior facets that are not no-slip/inflow facets are
+                # the Dirichlet set of the preconditioner's pressure Laplacian (as build_cc_host does per rank)
+                fixed = np.zeros(self.mesh.num_vertices, dtype=bool)
+                for bc in self.bcu_d:
+                    fixed[bc.dofs] = True
+                fv = self.mesh.facet_vertices
+                open_f = ~(fixed[fv[:, 0]] & fixed[fv[:, 1]])
+                pnodes = np.unique(np.concatenate([pnodes, fv[open_f].ravel()])).astype(np.int32)
             self.ctx.set_global_pressure_space(self.mesh.x, self.mesh.cells, self._part.owned_global, pnodes)
         # x_n = (u_prev, p_prev): initial guess of the first step (stabilized_schur.py:216-223)
         self._sync_previous()

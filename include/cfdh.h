@@ -146,6 +146,17 @@ int cfdh_advance(cfdh_ctx *ctx);
  * :298-305 (a0,a1,a2 Constants switched by step_count) map to (1; 1,-1,0) on the first
  * step and (1; 1.5,-2,0.5) afterwards.  theta in (0,1], a0 > 0. */
 int cfdh_set_time_scheme(cfdh_ctx *ctx, double theta, double a0, double a1, double a2);
+/* ---- boundary terms (the `stabilized_schur_backflow` variant) --------------------- */
+
+/* ds_terms != 0 (default): the pair `dot(p n, v) ds - dot(mu grad(u_mid) n, v) ds` of
+ * stabilized_schur.py:79 on ALL exterior facets.  stabilized_schur_backflow.py:107 drops it
+ * (do-nothing outlet): ds_terms = 0.  beta > 0 adds the backflow stabilisation
+ * -beta rho (u_prev.n)_- (u_mid . v) ds, (s)_- = (s-|s|)/2, on the exterior facets whose marker
+ * (facet_marker of cfdh_create) equals backflow_marker (`ds_out`, tags["outlet"],
+ * stabilized_schur_backflow.py:158-176), integrated with the 2-point Gauss rule FFCx picks
+ * for its estimated degree 3. */
+int cfdh_set_boundary_terms(cfdh_ctx *ctx, int ds_terms, int backflow_marker, double beta);
+
 /* u_prev2 (stabilized_schur_bdf2.py:72): upload / download; nv local vertices x 2 */
 int cfdh_set_previous2(cfdh_ctx *ctx, const double *u_prev2);
 int cfdh_get_previous2(cfdh_ctx *ctx, double *u_prev2);

@@ -56,12 +56,17 @@ typedef struct orc_ctx {
   int nv, nc, nf, ndof;
   int *cells;   /* [nc][3] */
   double *x;    /* [nv][2] */
-  uint8_t *fflag; /* [nc] bit f: facet opposite local vertex f is exterior */
+  uint8_t *fflag; /* [nc] bit f: facet opposite local vertex f is exterior; bit 3+f: it is a backflow (outlet) facet */
   int *fcell, *flocal;
   double dt, rho, mu, muf, f[2];
   /* time scheme: spatial terms at theta*u + (1-theta)*u_n, time term (a0 u + a1 u_n + a2 u_nm1)/dt.
    * stabilized_schur.py:72-80 -> (1/2; 1,-1,0); stabilized_schur_bdf2.py:79-110 -> (1; 1,-1,0) then (1; 1.5,-2,.5) */
   double theta, a0, a1, a2;
+  /* boundary terms: ds_terms = the ds pair of stabilized_schur.py:79 on all exterior facets (dropped by
+   * stabilized_schur_backflow.py:107); beta_bf = backflow coefficient on the facets flagged in bits 3..5
+   * of fflag (stabilized_schur_backflow.py:158-176) */
+  int ds_terms;
+  double beta_bf;
   uint8_t *isbc;
   double *bcval, *bcmult;
   int any_pbc;
@@ -255,8 +260,35 @@ static void element(const orc_ctx *c, const double xe[3][2], const double ue[3][
         Je[(6 + a) * 9 + 6 + b] = T * gg[a][b] / rho;
       }
   }
+  /* backflow stabilisation on outlet facets: - beta rho oint (u_prev.n)_- (ubar.v), (s)_- = (s-|s|)/2
+   * (stabilized_schur_backflow.py:165-176).  Estimated degree 1+1+1 = 3 (UFL: degree(abs(x)) = degree(x))
+   * -> 2-point Gauss-Legendre on the facet. */
+  if (c->beta_bf != 0.0 && (fflag >> 3)) {
+    const double gq = 0.5 / sqrt(3.0);
+    for (int f = 0; f < 3; f++) {
+      if (!((fflag >> (3 + f)) & 1)) continue;
+      double gl = hypot(g[f][0], g[f][1]);
+      double n[2] = {-g[f][0] / gl, -g[f][1] / gl};
+      double elen = 2.0 * area * gl;
+      int ev[2] = {(f + 1) % 3, (f + 2) % 3};
+      double s1 = une[ev[0]][0] * n[0] + une[ev[0]][1] * n[1], s2 = une[ev[1]][0] * n[0] + une[ev[1]][1] * n[1];
+      for (int q = 0; q < 2; q++) {
+        double t = q == 0 ? 0.5 - gq : 0.5 + gq;
+        double lam[2] = {1.0 - t, t};
+        double sq = lam[0] * s1 + lam[1] * s2;
+        double cq = c->beta_bf * rho * 0.5 * (sq - fabs(sq)) * 0.5 * elen;
+        double uq[2] = {lam[0] * ub[ev[0]][0] + lam[1] * ub[ev[1]][0], lam[0] * ub[ev[0]][1] + lam[1] * ub[ev[1]][1]};
+        for (int ka = 0; ka < 2; ka++)
+          for (int i = 0; i < 2; i++) {
+            Fe[2 * ev[ka] + i] -= cq * lam[ka] * uq[i];
+            if (Je)
+              for (int kb = 0; kb < 2; kb++) Je[(2 * ev[ka] + i) * 9 + 2 * ev[kb] + i] -= th * cq * lam[ka] * lam[kb];
+          }
+      }
+    }
+  }
   /* exterior facets: + oint p n.v - oint mu_f (nabla_grad(ubar) n).v   (stabilized_schur.py:79) */
-  for (int f = 0; f < 3; f++) {
+  for (int f = 0; f < 3 && c->ds_terms; f++) {
     if (!((fflag >> f) & 1)) continue;
     double gl = hypot(g[f][0], g[f][1]);
     double n[2] = {-g[f][0] / gl, -g[f][1] / gl};
@@ -288,7 +320,7 @@ void orc_element(double dt, double rho, double mu, double muf, const double *f, 
   orc_ctx c;
   memset(&c, 0, sizeof c);
   c.dt = dt; c.rho = rho; c.mu = mu; c.muf = muf; c.f[0] = f[0]; c.f[1] = f[1];
-  c.theta = 0.5; c.a0 = 1.0; c.a1 = -1.0; c.a2 = 0.0;
+  c.theta = 0.5; c.a0 = 1.0; c.a1 = -1.0; c.a2 = 0.0; c.ds_terms = 1;
   double g[3][2], area, h, mom[7];
   geom((const double(*)[2])xe, g, &area, &h);
   moments((const double(*)[2])une, area, h, dt, mu / rho, mom);
@@ -317,7 +349,7 @@ orc_ctx *orc_create(int nv, int nc, const int *cells, const double *x, int nf, c
   c->Fe = (double *)malloc(sizeof(double) * 9 * (size_t)nc);
   c->Je = (double *)malloc(sizeof(double) * 81 * (size_t)nc);
   c->rho = 1; c->mu = 1; c->muf = 1; c->dt = 1;
-  c->theta = 0.5; c->a0 = 1.0; c->a1 = -1.0; c->a2 = 0.0;
+  c->theta = 0.5; c->a0 = 1.0; c->a1 = -1.0; c->a2 = 0.0; c->ds_terms = 1; c->beta_bf = 0.0;
 #ifdef _OPENMP
   /* never oversubscribe a cgroup-limited box: default to <= 8 threads unless told otherwise */
   c->nthreads = omp_get_max_threads();
@@ -416,6 +448,12 @@ void orc_set_params(orc_ctx *c, double dt, double rho, double mu, double muf, co
 /* time scheme (see orc_ctx) */
 void orc_set_scheme(orc_ctx *c, double theta, double a0, double a1, double a2) {
   c->theta = theta; c->a0 = a0; c->a1 = a1; c->a2 = a2;
+}
+/* boundary terms (see orc_ctx): nbf facets (indices into the exterior-facet arrays) carry the backflow term */
+void orc_set_boundary_terms(orc_ctx *c, int ds_terms, double beta, int nbf, const int *bf_facets) {
+  c->ds_terms = ds_terms; c->beta_bf = beta;
+  for (int e = 0; e < c->nc; e++) c->fflag[e] &= 7u;
+  for (int k = 0; k < nbf; k++) c->fflag[c->fcell[bf_facets[k]]] |= (uint8_t)(8u << c->flocal[bf_facets[k]]);
 }
 /* u_prev2 of stabilized_schur_bdf2.py:72,324 */
 void orc_set_un2(orc_ctx *c, const double *un2) { memcpy(c->un2, un2, sizeof(double) * 2 * c->nv); }
@@ -983,9 +1021,21 @@ static int cc_setup(orc_ctx *c, const orc_opts *o) {
     free_csr(&Ah);
     if (rc) return rc;
   }
+  /* Dirichlet set of the pressure Laplacian: the pressure-Dirichlet dofs, plus -- with a do-nothing
+   * boundary (ds_terms off) -- the vertices of every exterior facet that is not a no-slip/inflow facet
+   * (outflow boundary of the pressure Poisson problem; Elman-Silvester-Wathen 2014, sec. 9.2).
+   * pbc: bit0 = pressure dof is Dirichlet (identity row in H, z_p = r_p), bit1 = Dirichlet in L only. */
   uint8_t *pbc = (uint8_t *)malloc(nv);
   int changed = (c->ccPbc == NULL) || c->hL_singular != c->singular;
-  for (int i = 0; i < nv; i++) { pbc[i] = c->isbc[nu + i]; if (c->ccPbc && c->ccPbc[i] != pbc[i]) changed = 1; }
+  for (int i = 0; i < nv; i++) pbc[i] = c->isbc[nu + i] ? 1 : 0;
+  if (!c->ds_terms)
+    for (int k = 0; k < c->nf; k++) {
+      int e = c->fcell[k], fl = c->flocal[k];
+      int v1 = c->cells[3 * e + (fl + 1) % 3], v2 = c->cells[3 * e + (fl + 2) % 3];
+      if (c->isbc[2 * v1] && c->isbc[2 * v1 + 1] && c->isbc[2 * v2] && c->isbc[2 * v2 + 1]) continue;
+      pbc[v1] |= 2; pbc[v2] |= 2;
+    }
+  for (int i = 0; i < nv; i++) if (c->ccPbc && c->ccPbc[i] != pbc[i]) changed = 1;
   if (changed) {
     csr_t Lh;
     csr_alloc(&Lh, nv, c->vptr[nv]);
@@ -996,7 +1046,9 @@ static int cc_setup(orc_ctx *c, const orc_opts *o) {
       for (int k = c->vptr[i]; k < c->vptr[i + 1]; k++) { int w = c->vadj[k]; if (pbc[w]) continue; Lh.col[n] = w; Lh.val[n] = c->Lval[k]; n++; }
     }
     Lh.rowptr[nv] = n;
-    int rc = amg_setup(c, c->hL, &Lh, o, c->singular);
+    int any_l = 0;
+    for (int i = 0; i < nv; i++) any_l |= pbc[i];
+    int rc = amg_setup(c, c->hL, &Lh, o, c->singular || !any_l);
     free_csr(&Lh);
     if (rc) { free(pbc); return rc; }
     free(c->ccPbc); c->ccPbc = pbc; c->hL_singular = c->singular;
@@ -1010,7 +1062,7 @@ static int cc_setup(orc_ctx *c, const orc_opts *o) {
     int n = 0;
     for (int i = 0; i < nv; i++) {
       Hh.rowptr[i] = n;
-      if (c->ccPbc[i]) { Hh.col[n] = i; Hh.val[n] = 1.0; n++; continue; }
+      if (c->ccPbc[i] & 1) { Hh.col[n] = i; Hh.val[n] = 1.0; n++; continue; }
       int deg = c->vptr[i + 1] - c->vptr[i];
       const double *rp = c->val + c->rowptr[nu + i] + 2 * deg; /* A11 row */
       int kd = 0;
@@ -1019,7 +1071,7 @@ static int cc_setup(orc_ctx *c, const orc_opts *o) {
       double T = Ld > 0 ? rp[kd] / Ld : 0.0;
       for (int k = 0; k < deg; k++) {
         int w = c->vadj[c->vptr[i] + k];
-        if (c->ccPbc[w]) continue;
+        if (c->ccPbc[w] & 1) continue;
         double v = c->cc_beta * rp[k];
         if (w == i) v += (1.0 + c->cc_alpha * T) * c->Ml[i];
         Hh.col[n] = w; Hh.val[n] = v; n++;
@@ -1228,7 +1280,7 @@ static void pc_apply(orc_ctx *c, pc_ws *p, const double *r, double *z) {
     for (int i = 0; i < nv; i++) p->cd0[i] = c->ccMl[i] * p->yp[i];
     amg_vcycle(c->hL, o, 0, p->cd0, p->cd1);
 #pragma omp parallel for schedule(static)
-    for (int i = 0; i < nv; i++) z[nu + i] = c->ccPbc[i] ? p->tp[i] : c->cc_alpha * p->cd1[i] + c->cc_beta * p->yp[i];
+    for (int i = 0; i < nv; i++) z[nu + i] = (c->ccPbc[i] & 1) ? p->tp[i] : c->cc_alpha * p->cd1[i] + c->cc_beta * p->yp[i];
     blk_mult(c, 2, z + nu, p->tu);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < nu; i++) p->tu[i] = r[i] - p->tu[i];

@@ -49,8 +49,14 @@ class Params:
     stabilized_schur_bdf2.py:79-110: fully implicit u_mid = u -> theta = 1, time term
     (a0 u + a1 u_n + a2 u_nm1)/dt with BDF1 (1,-1,0) on the first step, BDF2 (1.5,-2,0.5) after."""
 
-    def __init__(self, dt, rho, mu, f=(0.0, 0.0), mu_facet=None, theta=0.5, a0=1.0, a1=-1.0, a2=0.0):
+    def __init__(self, dt, rho, mu, f=(0.0, 0.0), mu_facet=None, theta=0.5, a0=1.0, a1=-1.0, a2=0.0,
+                 ds_terms=True, beta_backflow=0.0):
         self.theta, self.a0, self.a1, self.a2 = float(theta), float(a0), float(a1), float(a2)
+        # ds_terms: the `dot(p n, v) ds - dot(mu grad(u_mid) n, v) ds` pair of stabilized_schur.py:79 on ALL
+        # exterior facets; stabilized_schur_backflow.py:107 drops it (do-nothing outlet) and adds
+        # -beta rho (u_prev.n)_- (u_mid . v) on the outlet facets (:165-176).
+        self.ds_terms = bool(ds_terms)
+        self.beta_backflow = float(beta_backflow)
         self.dt = float(dt)
         self.rho = float(rho)
         self.mu = float(mu)
@@ -169,7 +175,34 @@ def element_tensors(x, cells, u, un, p, prm, facet_flags=None, want_jac=True, un
                     Je[:, 6 + a, 2 * b + j] = v
                 Je[:, 6 + a, 6 + b] = T * gg[:, a, b] / rho
 
-    if facet_flags is not None and np.any(facet_flags):
+    if facet_flags is not None and prm.beta_backflow != 0.0 and np.any(facet_flags >> 3):
+        # backflow stabilisation (stabilized_schur_backflow.py:165-176; Moghadam et al. 2011 eq. 10):
+        #   F -= beta rho int_out (u_prev.n)_- (ubar . v) ds,  (s)_- = (s - |s|)/2.
+        # UFL estimates degree(abs(x)) = degree(x): 1 + 1 + 1 = 3 -> 2-point Gauss-Legendre per facet.
+        gq = 0.5 / np.sqrt(3.0)
+        for f in range(3):
+            sel = np.nonzero((facet_flags >> (3 + f)) & 1)[0]
+            if len(sel) == 0:
+                continue
+            gf = g[sel, f]
+            gl = np.linalg.norm(gf, axis=1)
+            n = -gf / gl[:, None]
+            elen = 2.0 * area[sel] * gl
+            a1, a2 = (f + 1) % 3, (f + 2) % 3
+            s1 = np.einsum("ci,ci->c", une[sel, a1], n)
+            s2 = np.einsum("ci,ci->c", une[sel, a2], n)
+            for t in (0.5 - gq, 0.5 + gq):
+                lam = {a1: 1.0 - t, a2: t}
+                sq = (1.0 - t) * s1 + t * s2
+                cq = prm.beta_backflow * rho * 0.5 * (sq - np.abs(sq)) * 0.5 * elen
+                uq = (1.0 - t) * ub[sel, a1] + t * ub[sel, a2]
+                for a in (a1, a2):
+                    Fu[sel, a, :] -= (cq * lam[a])[:, None] * uq
+                    if want_jac:
+                        for b in (a1, a2):
+                            for i in range(2):
+                                Je[sel, 2 * a + i, 2 * b + i] -= th * cq * lam[a] * lam[b]
+    if facet_flags is not None and prm.ds_terms and np.any(facet_flags & 7):
         for f in range(3):
             sel = np.nonzero((facet_flags >> f) & 1)[0]
             if len(sel) == 0:
@@ -198,6 +231,16 @@ def element_tensors(x, cells, u, un, p, prm, facet_flags=None, want_jac=True, un
 class Problem:
     """Mesh + parameters + Dirichlet data in plain arrays (independent of the product)."""
 
+    def set_boundary_terms(self, ds_terms, backflow_facets=None, beta=0.0):
+        """backflow_facets: indices into the exterior-facet arrays (the facets tagged `outlet`)."""
+        self.prm.ds_terms = bool(ds_terms)
+        self.prm.beta_backflow = float(beta)
+        ff = self._ext_flags.copy()
+        if backflow_facets is not None and len(backflow_facets):
+            k = np.asarray(backflow_facets, dtype=np.int64)
+            np.bitwise_or.at(ff, self.facet_cells[k], (8 << self.facet_local[k]).astype(np.uint8))
+        self.facet_flags = ff
+
     def __init__(self, x, cells, facet_cells, facet_local, prm):
         self.x = np.ascontiguousarray(x, dtype=np.float64)
         self.cells = np.ascontiguousarray(cells, dtype=np.int64)
@@ -209,6 +252,7 @@ class Problem:
         ff = np.zeros(self.nc, dtype=np.uint8)
         np.bitwise_or.at(ff, self.facet_cells, (1 << self.facet_local).astype(np.uint8))
         self.facet_flags = ff
+        self._ext_flags = ff.copy()
         self.ndof = 3 * self.nv
         c = self.cells
         ld = np.empty((self.nc, 9), dtype=np.int64)

@@ -54,6 +54,7 @@ def lib():
         L.orc_add_bc.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, dp]
         L.orc_set_un.argtypes = [C.c_void_p, dp]
         L.orc_set_un2.argtypes = [C.c_void_p, dp]
+        L.orc_set_boundary_terms.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, ip]
         L.orc_set_scheme.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_assemble.argtypes = [C.c_void_p, dp, C.c_int, dp]
         L.orc_get_csr.argtypes = [C.c_void_p, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp)]
@@ -134,6 +135,11 @@ class Oracle:
     def set_un2(self, un2):
         un2 = np.ascontiguousarray(un2, dtype=np.float64).reshape(-1)
         lib().orc_set_un2(self.h, _dp(un2))
+
+    def set_boundary_terms(self, ds_terms, backflow_facets=None, beta=0.0):
+        """ds_terms False + backflow facets = stabilized_schur_backflow.py:107,158-176."""
+        bf = np.ascontiguousarray(backflow_facets if backflow_facets is not None else [], dtype=np.int32)
+        lib().orc_set_boundary_terms(self.h, int(bool(ds_terms)), float(beta), len(bf), _ip(bf))
 
     def set_scheme(self, theta, a0, a1, a2):
         """(1/2; 1,-1,0) = stabilized_schur.py; (1; 1,-1,0) / (1; 1.5,-2,.5) = stabilized_schur_bdf2.py:95-110,298-305."""

@@ -80,12 +80,26 @@ def stenosis_case(ny, L=20.0, x_sten=8.0, v_max=100.0, dt=0.01):
     return Case(mesh, bcs, dt, 1.06e-3, 3.5e-3, markers={"ft": ft})
 
 
+def stenosis_backflow_case(ny, beta=0.2, **kw):
+    """stabilized_schur_backflow.py:107,158-176,193-195 on the stenosed channel: walls + inlet Dirichlet,
+    NO pressure condition, do-nothing outlet (no ds terms) with backflow stabilisation on marker 3."""
+    case = stenosis_case(ny, **kw)
+    case.bcs = [b for b in case.bcs if b[0] == 0]
+    case.ds_terms = False
+    case.backflow_marker = 3
+    case.backflow_facets = np.asarray(case.markers["ft"].find(3), dtype=np.int32)
+    case.beta_backflow = beta
+    return case
+
+
 def make_oracle(case):
     from oracle import orc
     m = case.mesh
     O = orc.Oracle(m.x, m.cells, m.facet_cells, m.facet_local, case.dt, case.rho, case.mu, case.f)
     for field, nodes, vals in case.bcs:
         (O.add_bc_u if field == 0 else O.add_bc_p)(nodes, vals)
+    if getattr(case, "backflow_facets", None) is not None:
+        O.set_boundary_terms(case.ds_terms, case.backflow_facets, case.beta_backflow)
     return O
 
 
@@ -95,6 +109,8 @@ def make_twin(case):
     pb = T.Problem(m.x, m.cells, m.facet_cells, m.facet_local, T.Params(case.dt, case.rho, case.mu, case.f))
     for field, nodes, vals in case.bcs:
         (pb.add_bc_u if field == 0 else pb.add_bc_p)(nodes, vals)
+    if getattr(case, "backflow_facets", None) is not None:
+        pb.set_boundary_terms(case.ds_terms, case.backflow_facets, case.beta_backflow)
     return pb
 
 
@@ -105,6 +121,8 @@ def make_ctx(case, device=0):
     ctx.set_params(case.dt, case.rho, case.mu, f=case.f)
     for field, nodes, vals in case.bcs:
         ctx.add_dirichlet(field, nodes, vals)
+    if getattr(case, "backflow_facets", None) is not None:
+        ctx.set_boundary_terms(case.ds_terms, case.backflow_marker, case.beta_backflow)
     return ctx
 
 
