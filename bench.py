@@ -114,15 +114,18 @@ def main():
             dist.barrier()
 
     its_newton, its_krylov = [], []
+    solver.initStressForm()
     for _ in range(args.warmup):
         solver.solveStep()
+        solver.assemble_wss()
         solver.advance()
     sync_all()
     t0 = time.perf_counter()
     ms_asm = ms_solve = ms_pc = 0.0
     for _ in range(args.steps):
-        solver.solveStep()
-        solver.advance()
+        solver.solveStep()     # Newton + FGMRES step (stabilized_schur.py:313-334)
+        solver.assemble_wss()  # per-step wall shear stress (scenario.py:262), on the device
+        solver.advance()       # u_prev <- u_sol, p_prev <- p_sol (scenario.py:306-307), on the device
         st = solver.last_stats
         its_newton.append(st.newton_its)
         its_krylov.append(st.krylov_its)

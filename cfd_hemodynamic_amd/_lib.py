@@ -45,7 +45,7 @@ SYMBOLS = [
     "cfdh_set_options", "cfdh_clear_dirichlet", "cfdh_add_dirichlet", "cfdh_set_state", "cfdh_get_solution",
     "cfdh_get_previous", "cfdh_get_residual", "cfdh_advance", "cfdh_set_time_scheme", "cfdh_set_previous2", "cfdh_get_previous2",
     "cfdh_shift_history", "cfdh_set_boundary_terms", "cfdh_assemble", "cfdh_get_csr", "cfdh_spmv", "cfdh_solve_step",
-    "cfdh_functional", "cfdh_set_global_pressure_space", "cfdh_set_halo", "cfdh_comm_unique_id", "cfdh_comm_init", "cfdh_comm_set_callbacks",
+    "cfdh_functional", "cfdh_wall_shear_stress", "cfdh_set_global_pressure_space", "cfdh_set_halo", "cfdh_comm_unique_id", "cfdh_comm_init", "cfdh_comm_set_callbacks",
     "cfdh_profile_enable", "cfdh_profile_get", "cfdh_profile_reset", "cfdh_info",
 ]
 
@@ -91,6 +91,7 @@ def lib():
     L.cfdh_set_previous2.argtypes = [vp, dp]
     L.cfdh_get_previous2.argtypes = [vp, dp]
     L.cfdh_shift_history.argtypes = [vp]
+    L.cfdh_wall_shear_stress.argtypes = [vp, dp]
     L.cfdh_set_boundary_terms.argtypes = [vp, C.c_int, C.c_int, C.c_double]
     L.cfdh_get_residual.argtypes = [vp, dp, dp]
     L.cfdh_get_previous.argtypes = [vp, dp, dp]
@@ -227,6 +228,14 @@ class Context:
 
     def set_boundary_terms(self, ds_terms=True, backflow_marker=-1, beta=0.0):
         self._chk(self.L.cfdh_set_boundary_terms(self.h, int(bool(ds_terms)), int(backflow_marker), float(beta)))
+
+    def wall_shear_stress(self, download=True):
+        if not download:
+            self._chk(self.L.cfdh_wall_shear_stress(self.h, None))
+            return None
+        out = np.zeros(2 * self.nv)
+        self._chk(self.L.cfdh_wall_shear_stress(self.h, _dp(out)))
+        return out
 
     def set_previous2(self, u_prev2):
         u_prev2 = np.ascontiguousarray(u_prev2, dtype=np.float64).reshape(-1)

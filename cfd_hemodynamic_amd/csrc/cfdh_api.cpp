@@ -420,6 +420,22 @@ int cfdh_functional(cfdh_ctx *c, int kind, int marker, double *out) {
   return k_functional(c, kind, marker, out);
 }
 
+int cfdh_wall_shear_stress(cfdh_ctx *c, double *shear) {
+  ENTER(c);
+  if (!c->wss.p) HIPCHK(c, c->wss.alloc(2 * (size_t)c->nv));
+  CHK(comm_halo(c, c->x.p));
+  CHK(k_wss(c, c->wss.p));
+  if (!shear) return 0;
+  std::vector<double> h(2 * (size_t)c->nv);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->wss.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < c->nv; k++) {
+    const int v = c->iperm[k];
+    shear[2 * (size_t)v] = h[2 * (size_t)k]; shear[2 * (size_t)v + 1] = h[2 * (size_t)k + 1];
+  }
+  return 0;
+}
+
 int cfdh_profile_enable(cfdh_ctx *c, int on) {
   ENTER(c);
   prof_flush(c);

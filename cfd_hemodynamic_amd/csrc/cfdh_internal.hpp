@@ -158,6 +158,7 @@ struct cfdh_ctx {
 
   // state: layout [u owned 2*nvo | p owned nvo | ghosts 3*ng (ux,uy,p)]
   dbuf<double> x, xt, xprev, xprev2, F, dvec;
+  dbuf<double> wss;  // [nv][2] wall shear stress of the last cfdh_wall_shear_stress call (allocated on first use)
   double ts_theta = 0.5, ts_a[3] = {1.0, -1.0, 0.0};  // cfdh_set_time_scheme
   bool ds_terms = true;      // cfdh_set_boundary_terms
   double bf_beta = 0.0;
@@ -297,6 +298,7 @@ int v_scale_inv_dev(cfdh_ctx *c, int n, const double *w, const double *nrm_dev, 
 int v_lincomb(cfdh_ctx *c, int n, const double *Z, int ld, int nvec, const double *y_dev, double *x);  // x += sum y_k Z_k
 int v_pack_state(cfdh_ctx *c, const double *u_user, const double *p_user, double *dst);  // host staging helpers
 int k_functional(cfdh_ctx *c, int kind, int marker, double *out);
+int k_wss(cfdh_ctx *c, double *out);
 
 // ---- comm (cfdh_comm.cpp) ----------------------------------------------------------
 int comm_allreduce_dev(cfdh_ctx *c, double *dev, int n, int op);  // in-stream

@@ -1578,6 +1578,53 @@ __global__ __launch_bounds__(TPB) void l2_kernel(int nc, int nvo, const int *__r
   if (threadIdx.x == 0) { partial[blockIdx.x] = au; partial[gridDim.x + blockIdx.x] = ap; }
 }
 
+// wall shear stress (solverBase.py:163-195): shear[v] += (1/|e|) oint lambda_v Tt ds = Tt/2 for both vertices of each
+// exterior facet, Tt = T - (T.n) n, T = -sigma(u,p) n (the pressure part is purely normal).  A boundary vertex of a
+// 2-D mesh receives two contributions, so the atomic sum is order-independent.
+__global__ __launch_bounds__(TPB) void wss_kernel(int nfac, int nvo, const int *__restrict__ fcell, const int *__restrict__ flocal,
+                                                  const int *__restrict__ cells, const double *__restrict__ coords,
+                                                  const double *__restrict__ x, double mu, double *__restrict__ out) {
+  const int k = blockIdx.x * TPB + threadIdx.x;
+  if (k >= nfac) return;
+  const int e = fcell[k], fl = flocal[k];
+  int vs[3];
+  double X[3][2], u[3][2];
+  for (int a = 0; a < 3; a++) {
+    vs[a] = cells[3 * e + a];
+    X[a][0] = coords[2 * vs[a]]; X[a][1] = coords[2 * vs[a] + 1];
+    const int uo = uoff(vs[a], nvo);
+    u[a][0] = x[uo]; u[a][1] = x[uo + 1];
+  }
+  const double det = (X[1][0] - X[0][0]) * (X[2][1] - X[0][1]) - (X[1][1] - X[0][1]) * (X[2][0] - X[0][0]);
+  double g[3][2];
+  g[0][0] = (X[1][1] - X[2][1]) / det; g[0][1] = (X[2][0] - X[1][0]) / det;
+  g[1][0] = (X[2][1] - X[0][1]) / det; g[1][1] = (X[0][0] - X[2][0]) / det;
+  g[2][0] = (X[0][1] - X[1][1]) / det; g[2][1] = (X[1][0] - X[0][0]) / det;
+  const double gfx = fl == 0 ? g[0][0] : (fl == 1 ? g[1][0] : g[2][0]);
+  const double gfy = fl == 0 ? g[0][1] : (fl == 1 ? g[1][1] : g[2][1]);
+  const double gl = hypot(gfx, gfy);
+  const double n[2] = {-gfx / gl, -gfy / gl};
+  double G[2][2] = {{0, 0}, {0, 0}};  // G_ij = d_i u_j
+  for (int a = 0; a < 3; a++)
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 2; j++) G[i][j] += g[a][i] * u[a][j];
+  const double E01 = 0.5 * (G[0][1] + G[1][0]);
+  const double T[2] = {-2.0 * mu * (G[0][0] * n[0] + E01 * n[1]), -2.0 * mu * (E01 * n[0] + G[1][1] * n[1])};
+  const double Tn = T[0] * n[0] + T[1] * n[1];
+  const double Tt[2] = {0.5 * (T[0] - Tn * n[0]), 0.5 * (T[1] - Tn * n[1])};
+  const int v1 = vs[(fl + 1) % 3], v2 = vs[(fl + 2) % 3];
+  atomicAdd(out + 2 * (size_t)v1, Tt[0]); atomicAdd(out + 2 * (size_t)v1 + 1, Tt[1]);
+  atomicAdd(out + 2 * (size_t)v2, Tt[0]); atomicAdd(out + 2 * (size_t)v2 + 1, Tt[1]);
+}
+int k_wss(cfdh_ctx *c, double *out) {
+  HIPCHK(c, hipMemsetAsync(out, 0, sizeof(double) * 2 * (size_t)c->nv, c->stream));
+  if (c->nfac > 0)
+    hipLaunchKernelGGL(wss_kernel, dim3((c->nfac + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nfac, c->nvo, c->d_fac_cell.p,
+                       c->d_fac_local.p, c->cells.p, c->coords.p, c->x.p, c->mu, out);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int k_functional(cfdh_ctx *c, int kind, int marker, double *out) {
   const int nb = 256;
   if (kind == 0 || kind == 1) {

@@ -149,6 +149,24 @@ class Mesh:
             - (p[:, 1, 1] - p[:, 0, 1]) * (p[:, 2, 0] - p[:, 0, 0])
         )
 
+    def eval_p1(self, values, points, tol=1e-12):
+        """Point evaluation of a scalar P1 field (the bb_tree / compute_colliding_cells / Function.eval
+        sequence of dfg_1.py:213-253 and stenosis.py:163-190): value at each point from the first cell that
+        contains it, NaN when no cell does."""
+        X = self.x[self.cells]
+        d = (X[:, 1, 0] - X[:, 0, 0]) * (X[:, 2, 1] - X[:, 0, 1]) - (X[:, 1, 1] - X[:, 0, 1]) * (X[:, 2, 0] - X[:, 0, 0])
+        vals = np.asarray(values, dtype=np.float64)
+        out = np.full(len(points), np.nan)
+        for k, pt in enumerate(points):
+            l1 = ((pt[0] - X[:, 0, 0]) * (X[:, 2, 1] - X[:, 0, 1]) - (pt[1] - X[:, 0, 1]) * (X[:, 2, 0] - X[:, 0, 0])) / d
+            l2 = ((X[:, 1, 0] - X[:, 0, 0]) * (pt[1] - X[:, 0, 1]) - (X[:, 1, 1] - X[:, 0, 1]) * (pt[0] - X[:, 0, 0])) / d
+            l0 = 1.0 - l1 - l2
+            ok = np.nonzero((l0 >= -tol) & (l1 >= -tol) & (l2 >= -tol))[0]
+            if len(ok):
+                c = ok[0]
+                out[k] = l0[c] * vals[self.cells[c, 0]] + l1[c] * vals[self.cells[c, 1]] + l2[c] * vals[self.cells[c, 2]]
+        return out
+
     def set_facet_markers(self, facets, values):
         self.facet_marker[np.asarray(facets, dtype=np.int64)] = np.asarray(values, dtype=np.int32)
 

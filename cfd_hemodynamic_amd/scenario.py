@@ -111,15 +111,29 @@ class Scenario(ABC):
             print(f"Suggested cores: {(nV + nQ) / 20000:.1f}")
 
     def solve(self, output_folder: str = None, afterStepCallback: Callable[[float], None] = None,
-              device_resident: bool = True, max_steps: int = None) -> str:
+              device_resident: bool = True, max_steps: int = None, write_every: int = 1) -> str:
         mesh, T, solver = self.mesh, self.T, self.solver
         quiet = getattr(self, "quiet", False)
         if output_folder and mesh.comm.rank == 0:
             os.makedirs(output_folder, exist_ok=True)
         mesh.comm.barrier()
         solver.initStressForm()
+        # v / p / u_residual / p_residual / wss time series (scenario.py:208-228): VTU + PVD instead of ADIOS2 VTX.
+        # write_every = 1 is the reference's behaviour (every step); 0 disables the series.
+        writers = []
+        if output_folder and write_every:
+            from .io import VTUWriter
+            writers = [VTUWriter(mesh.comm, f"{output_folder}/v.bp", solver.u_sol, "v"),
+                       VTUWriter(mesh.comm, f"{output_folder}/p.bp", solver.p_sol, "p"),
+                       VTUWriter(mesh.comm, f"{output_folder}/u_residual.bp", solver.u_residual, "u_residual"),
+                       VTUWriter(mesh.comm, f"{output_folder}/p_residual.bp", solver.p_residual, "p_residual"),
+                       VTUWriter(mesh.comm, f"{output_folder}/wss.bp", solver.shear_stress, "shear_stress")]
         t = 0.0
         solver.u_sol.interpolate(self.initial_velocity)
+        if writers:
+            solver.assemble_wss()
+            for w in writers:
+                w.write(t)
         error_log = None
         if self.has_exact_solution:
             error_log = open(f"{output_folder}/err.txt", "w") if (output_folder and mesh.comm.rank == 0) else None
@@ -144,8 +158,10 @@ class Scenario(ABC):
                 error = self.compute_error(u_e, solver.u_sol, mesh)
                 if error_log:
                     error_log.write("t = %.3f: error = %.3g" % (t, error) + "\n")
-            if not fast:
-                solver.assemble_wss()
+            solver.assemble_wss()
+            if writers and i % write_every == 0:
+                for w in writers:
+                    w.write(t)
             if afterStepCallback:
                 afterStepCallback(t)
             if (i + 1) % 10 == 0:
@@ -191,6 +207,8 @@ class Scenario(ABC):
             np.savez(os.path.join(output_folder, "final.npz"), x=mesh.x, cells=mesh.cells,
                      velocity=solver.u_sol.x.array, pressure=solver.p_sol.x.array,
                      wss=solver.shear_stress.x.array)
+        for w in writers:
+            w.close()
         if error_log:
             error_log.close()
         return output_folder

@@ -83,21 +83,10 @@ class DFG1Benchmark(Scenario):
 
     def pressure_difference(self):
         """p(0.15,0.2) - p(0.25,0.2) by point evaluation (dfg_1.py:213-253)."""
-        m = self.mesh
-        p = self.solver.p_sol.x.array
-        out = []
-        for pt in ((0.15, 0.2), (0.25, 0.2)):
-            X = m.x[m.cells]
-            d = (X[:, 1, 0] - X[:, 0, 0]) * (X[:, 2, 1] - X[:, 0, 1]) - (X[:, 1, 1] - X[:, 0, 1]) * (X[:, 2, 0] - X[:, 0, 0])
-            l1 = ((pt[0] - X[:, 0, 0]) * (X[:, 2, 1] - X[:, 0, 1]) - (pt[1] - X[:, 0, 1]) * (X[:, 2, 0] - X[:, 0, 0])) / d
-            l2 = ((X[:, 1, 0] - X[:, 0, 0]) * (pt[1] - X[:, 0, 1]) - (X[:, 1, 1] - X[:, 0, 1]) * (pt[0] - X[:, 0, 0])) / d
-            l0 = 1.0 - l1 - l2
-            ok = np.nonzero((l0 >= -1e-12) & (l1 >= -1e-12) & (l2 >= -1e-12))[0]
-            if len(ok) == 0:
-                return None
-            c = ok[0]
-            out.append(l0[c] * p[m.cells[c, 0]] + l1[c] * p[m.cells[c, 1]] + l2[c] * p[m.cells[c, 2]])
-        return out[0] - out[1]
+        v = self.mesh.eval_p1(self.solver.p_sol.x.array, [(0.15, 0.2), (0.25, 0.2)])
+        if np.isnan(v).any():
+            return None
+        return v[0] - v[1]
 
     def solve(self, output_folder=None, afterStepCallback=None, **kw):
         out_path = super().solve(output_folder, afterStepCallback, **kw)

@@ -14,6 +14,8 @@ outlet like the other open-boundary scenarios (dfg_1.py:79-91); `outlet_pressure
 reproduces the reference literally."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from ..boundaryCondition import BoundaryCondition
@@ -82,6 +84,27 @@ class StenosisSimulation(Scenario):
                 bc_o.initTopological(1, self._ft.find(self.outlet_marker))
                 self._bcp = [bc_o]
         return self._bcp
+
+    def solve(self, output_folder=None, afterStepCallback=None, **kw):
+        result = super().solve(output_folder, afterStepCallback, **kw)
+        self._compute_ffr(output_folder)
+        return result
+
+    def _compute_ffr(self, output_folder):
+        """FFR = p_distal / p_proximal at the channel centreline y = R_in (stenosis.py:163-211)."""
+        p = self.mesh.eval_p1(self.solver.p_sol.x.array, [(0.0, self.R_in), (self.L, self.R_in)])
+        p = np.where(np.isnan(p), 0.0, p)
+        self.p_proximal, self.p_distal = float(p[0]), float(p[1])
+        self.ffr = self.p_distal / self.p_proximal if abs(self.p_proximal) > 1e-12 else float("nan")
+        if self.mesh.comm.rank == 0:
+            txt = "\n".join([f"p_proximal (inlet center):  {self.p_proximal:.6f}",
+                             f"p_distal   (outlet center): {self.p_distal:.6f}",
+                             f"FFR = p_distal / p_proximal: {self.ffr:.6f}"])
+            if not self.quiet:
+                print(f"\n[FFR] {txt}", flush=True)
+            if output_folder:
+                with open(os.path.join(output_folder, "ffr.txt"), "w") as f:
+                    f.write(txt + "\n")
 
     def initial_velocity(self, x):
         return np.zeros((2, x.shape[1]))

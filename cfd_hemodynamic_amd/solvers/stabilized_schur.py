@@ -65,7 +65,7 @@ class Solver(SolverBase):
         self._bcs = []
         self._bc_cache = None
         # lazy host/device synchronisation of the state Functions
-        self._dev_newer = {"sol": False, "res": False}
+        self._dev_newer = {"sol": False, "res": False, "wss": False}
         self._prev_host_dirty = True
         self._prev_dev_newer = False
         self._u_sol.x._pre_access = self._sync_solution
@@ -105,6 +105,22 @@ class Solver(SolverBase):
             self._dev_newer["res"] = False
             ru, rp = self.ctx.get_residual()
             self._store(self.u_residual.x._array, self.p_residual.x._array, ru, rp)
+
+    def _sync_wss(self):
+        if self._dev_newer["wss"]:
+            self._dev_newer["wss"] = False
+            w = self.ctx.wall_shear_stress(download=True)
+            a = self.shear_stress.x._array
+            a[:] = w if self._part is None else self._comm.allgather_owned(w, 2, self.mesh.num_vertices)
+
+    def assemble_wss(self):
+        """solverBase.py:185-195 on the device (cfdh_wall_shear_stress); the host array behind
+        `shear_stress.x.array` is filled when it is read."""
+        if not hasattr(self, "shear_stress"):
+            return
+        self.shear_stress.x._pre_access = self._sync_wss
+        self.ctx.wall_shear_stress(download=False)
+        self._dev_newer["wss"] = True
 
     def _sync_previous(self):
         if self._prev_dev_newer:

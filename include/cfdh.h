@@ -190,6 +190,12 @@ int cfdh_solve_step(cfdh_ctx *ctx, cfdh_stats *stats);
  * Sums/maxima over the owned part; the caller (or the communicator) reduces. */
 int cfdh_functional(cfdh_ctx *ctx, int kind, int marker, double *out);
 
+/* Wall shear stress, the per-step `assemble_wss()` of solverBase.py:163-195,
+ * (1/FacetArea) * inner(w, Tt) * ds with T = -sigma(u_sol, p_sol) n, Tt = T - (T.n) n, assembled on
+ * the device from the current solution into a P1 vector field (zero away from the boundary).
+ * shear: nv x 2 host array, or NULL to compute without downloading. */
+int cfdh_wall_shear_stress(cfdh_ctx *ctx, double *shear);
+
 /* ---- multi-GPU ---------------------------------------------- */
 
 /* Halo plan in local vertex numbers: for neighbour k, send_idx[send_ptr[k]..send_ptr[k+1])

@@ -304,3 +304,21 @@ def test_lid_cavity_config_c2():
         ctx.close()
     assert np.linalg.norm(sols[0][0] - sols[1][0]) <= 1e-7 * np.linalg.norm(sols[1][0])
     assert np.linalg.norm(sols[0][1] - sols[1][1]) <= 1e-6 * np.linalg.norm(sols[1][1])
+
+
+def test_wall_shear_stress_device_matches_host_restatement():
+    """cfdh_wall_shear_stress (the per-step assemble_wss of solverBase.py:163-195 on the device)
+    against the numpy restatement in SolverBase.assemble_wss, after a few scenario steps."""
+    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+    from cfd_hemodynamic_amd.solverBase import SolverBase
+    sc = DFG1Benchmark("stabilized_schur", 0.01, 0.035, m=10, quiet=True)
+    sc.solve(None, device_resident=True)
+    dev = sc.solver.shear_stress.x.array.copy()
+    SolverBase.assemble_wss(sc.solver)
+    host = sc.solver.shear_stress.x.array.copy()
+    assert np.abs(host).max() > 1e-4
+    assert np.abs(dev - host).max() <= 1e-13 * np.abs(host).max()
+    # zero away from the boundary
+    interior = np.ones(sc.mesh.num_vertices, bool)
+    interior[np.unique(sc.mesh.facet_vertices)] = False
+    assert not dev.reshape(-1, 2)[interior].any()

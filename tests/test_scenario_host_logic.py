@@ -120,3 +120,49 @@ def test_poiseuille_steady_state(oracle_backend):
     p = sc.solver.p_sol.x.array.reshape(17, 17)
     slope = (p[8, 4] - p[8, 12]) / 0.5  # interior, away from the inlet/outlet boundary terms
     assert abs(slope - 8.0) < 0.4, slope
+
+
+def test_vtu_series_and_ffr_outputs(oracle_backend, tmp_path):
+    """Output either side of the path (scenario.py:208-228,258-263; stenosis.py:158-211): the five
+    time series are written every step (t=0 included) and read back bit-exactly; FFR = p(L,R)/p(0,R)."""
+    from cfd_hemodynamic_amd.io import read_vtu
+    from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
+    sc = StenosisSimulation(oracle_backend, 0.01, 0.025, ny=4, L=8.0, x_sten=4.0, v_max=50.0, quiet=True)
+    out = str(tmp_path / "run")
+    sc.solve(out)
+    assert sc.num_steps == 3
+    import os
+    for name in ("v", "p", "u_residual", "p_residual", "wss"):
+        pvd = open(os.path.join(out, name + ".pvd")).read()
+        assert pvd.count("<DataSet") == 4  # t = 0 and three steps
+        assert os.path.exists(os.path.join(out, "%s_%06d.vtu" % (name, 3)))
+    v = read_vtu(os.path.join(out, "v_000003.vtu"))
+    assert np.array_equal(v["cells"], sc.mesh.cells)
+    assert np.array_equal(v["points"][:, :2], sc.mesh.x)
+    assert np.array_equal(v["v"][:, :2], sc.solver.u_sol.x.array.reshape(-1, 2)) and not v["v"][:, 2].any()
+    p = read_vtu(os.path.join(out, "p_000003.vtu"))
+    assert np.array_equal(p["p"].ravel(), sc.solver.p_sol.x.array)
+    w = read_vtu(os.path.join(out, "wss_000003.vtu"))
+    assert np.array_equal(w["shear_stress"][:, :2], sc.solver.shear_stress.x.array.reshape(-1, 2))
+    # FFR: pressure at the inlet / outlet centre points; p = 0 at the outlet here, so FFR = 0 and p_proximal > 0
+    txt = open(os.path.join(out, "ffr.txt")).read()
+    assert "FFR = p_distal / p_proximal" in txt
+    assert sc.p_proximal > 0 and abs(sc.p_distal) < 1e-12 and sc.ffr == pytest.approx(0.0, abs=1e-12)
+    # write_every thins the series, 0 disables it
+    sc2 = StenosisSimulation(oracle_backend, 0.01, 0.025, ny=4, L=8.0, x_sten=4.0, v_max=50.0, quiet=True)
+    out2 = str(tmp_path / "run2")
+    sc2.solve(out2, write_every=2)
+    assert open(os.path.join(out2, "v.pvd")).read().count("<DataSet") == 2
+    sc3 = StenosisSimulation(oracle_backend, 0.01, 0.025, ny=4, L=8.0, x_sten=4.0, v_max=50.0, quiet=True)
+    out3 = str(tmp_path / "run3")
+    sc3.solve(out3, write_every=0)
+    assert not os.path.exists(os.path.join(out3, "v.pvd")) and os.path.exists(os.path.join(out3, "final.npz"))
+
+
+def test_p1_point_evaluation():
+    m = create_unit_square(5)
+    f = 2.0 * m.x[:, 0] - 3.0 * m.x[:, 1] + 0.5  # P1 reproduces affine functions exactly
+    pts = [(0.13, 0.77), (1.0, 1.0), (0.0, 0.4), (1.5, 0.5)]
+    v = m.eval_p1(f, pts)
+    assert np.allclose(v[:3], [2 * x - 3 * y + 0.5 for x, y in pts[:3]], atol=1e-13)
+    assert np.isnan(v[3])
