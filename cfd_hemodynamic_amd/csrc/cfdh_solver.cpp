@@ -250,13 +250,16 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
   const bool multi = c->nranks > 1;
   const bool global_p = c->gp_n > 0 && multi;
   if (c->opt.pc_type == 1) {
+    const bool upper = c->opt.schur_full == 2;  // block upper-triangular: z_p = S^-1 r_p, z_u = A^-1 (r_u - A01 z_p)
     switch (stage) {
       case 0:
+        if (upper) return 0;
         // in a partitioned run y_u lands in the halo scratch vector so that its ghosts can be refreshed
         CHK(k_amg_vcycle(c, c->hA, ru, multi ? c->pcw.p : c->pu0.p));
         return 0;
       case 1:
-        if (multi) CHK(k_spmv_block_ghost(c, 3, c->pcw.p, c->pp0.p, rp));   // t_p = r_p - A10 y_u (with ghosts)
+        if (upper) CHK(v_copy(c, nvo, rp, c->pp0.p));
+        else if (multi) CHK(k_spmv_block_ghost(c, 3, c->pcw.p, c->pp0.p, rp));   // t_p = r_p - A10 y_u (with ghosts)
         else CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));
         CHK(k_level_smooth(c, &c->Hlev, c->pp0.p, c->pp1.p, 3));
         CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
@@ -302,7 +305,7 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
 // exchange that follows stage `stage` in a partitioned run
 static int pc_exchange(cfdh_ctx *c, int stage) {
   if (c->nranks <= 1 || c->opt.pc_type != 1) return 0;
-  if (stage == 0) return comm_halo(c, c->pcw.p);
+  if (stage == 0) return c->opt.schur_full == 2 ? 0 : comm_halo(c, c->pcw.p);
   if (stage == 1) return (c->gp_n > 0) ? comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0) : 0;
   if (stage == 2) return c->opt.schur_full ? comm_halo(c, c->pcw.p) : 0;
   return 0;

@@ -73,7 +73,9 @@ typedef struct cfdh_options {
    * stabilized_schur.py:231-264) */
   int32_t cheb_degree;      /* Jacobi-Chebyshev sweeps per A00 solve */
   double cheb_ratio;        /* lambda_max / lambda_min targeted */
-  int32_t schur_full;       /* 1: FULL factorisation (2 A00 solves), 0: LOWER+diag */
+  int32_t schur_full;       /* 2 (default): block UPPER-triangular factor (one A00 solve), 1: FULL
+                             * factorisation as PC_FIELDSPLIT_SCHUR_FACT_FULL, stabilized_schur.py:225 (two A00
+                             * solves), 0: LOWER.  All are right preconditioners of the same FGMRES. */
   int32_t amg_smooth_degree;
   double amg_smooth_ratio;
   double amg_theta;         /* strength threshold of the aggregation */

@@ -5,7 +5,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from util import dfg_case, make_ctx
 m = int(sys.argv[1]); nsteps = int(sys.argv[2])
 case = dfg_case(m); nv = case.nv
-for extra in [dict(), dict(amg_max_coarse=2000), dict(amg_max_coarse=2000, schur_full=0), dict(amg_max_coarse=3000), dict(ksp_restart=30)]:
+for extra in [dict(), dict(schur_full=2), dict(schur_full=0)]:
     ctx = make_ctx(case)
     o = ctx.default_options()
     for k, v in extra.items(): setattr(o, k, v)
@@ -16,5 +16,5 @@ for extra in [dict(), dict(amg_max_coarse=2000), dict(amg_max_coarse=2000, schur
     for s in range(nsteps):
         ts = time.time(); st = ctx.solve_step(); ctx.advance(); tl.append(time.time() - ts)
         kits += st.krylov_its; nits += st.newton_its; ref += st.pc_refreshes
-    print(extra, "krylov", kits, "newton", nits, "ms/step(last 10)", round(1e3 * np.mean(tl[-10:]), 2), "first step s", round(tl[0], 2), "refreshes", ref, "levels", ctx.info(6), flush=True)
+    print(extra, "krylov", kits, "newton", nits, "ms/step(last 10)", round(1e3 * np.mean(tl[-10:]), 2), "first step s", round(tl[0], 2), "refreshes", ref, "levels", ctx.info(6), "drag", ctx.functional(0, 5) * 500, flush=True)
     ctx.close()
