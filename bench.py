@@ -206,7 +206,9 @@ def main():
         "config": {"workload": "dfg_1 (DFG 2D-1, Re=20) block-structured mesh m=%d: %d vertices, %d P1/P1 DOF, "
                                "dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)"
                                % (args.m, nv, ndof, dt),
-                   "parallelism": "element partition x%d (RCB), halo + dot all-reduce on %s" % (world, args.comm)},
+                   "parallelism": "element partition x%d (RCB), halo + dot all-reduce on %s" % (
+                       world, (comm.backend if comm is not None else args.comm) + (
+                           " [fallback: %s]" % comm.fallback_reason if getattr(comm, "fallback_reason", None) else ""))},
         "ms_assemble_per_step": ms_asm / args.steps,
         "ms_solve_per_step": ms_solve / args.steps,
         "ms_pc_setup_per_step": ms_pc / args.steps,

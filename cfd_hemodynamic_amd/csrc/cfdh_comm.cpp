@@ -94,6 +94,7 @@ extern "C" int cfdh_comm_init(cfdh_ctx *c, const void *id128, int rank, int nran
 
 extern "C" int cfdh_comm_set_callbacks(cfdh_ctx *c, cfdh_allreduce_fn ar, cfdh_exchange_fn ex, void *user, int rank, int nranks) {
   if (!c || !ar || !ex || nranks < 1) return cfdh_fail(c, CFDH_E_ARG, "bad comm callbacks");
+  if (c->nccl_comm) comm_finalize(c);  // the callbacks replace an RCCL communicator
   c->cb_ar = ar; c->cb_ex = ex; c->cb_user = user;
   c->rank = rank; c->nranks = nranks;
   return global_counts(c);

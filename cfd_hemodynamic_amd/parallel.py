@@ -198,9 +198,51 @@ class PartComm:
             uid = _lib.rccl_unique_id() if self.rank == 0 else bytes(128)
             t = torch.tensor(list(uid), dtype=torch.uint8)
             dist.broadcast(t, src=0)
-            ctx.comm_init_rccl(bytes(t.tolist()), self.rank, self.size)
+            err = None
+            try:
+                ctx.comm_init_rccl(bytes(t.tolist()), self.rank, self.size)
+            except RuntimeError as e:
+                err = str(e)
+            if self.allreduce(0.0 if err is None else 1.0, "max") > 0:  # every rank takes the same branch
+                self.fall_back_to_host(ctx, "RCCL communicator init failed: %s" % (err or "on another rank"))
         else:
             self._attach_host(ctx)
+
+    def fall_back_to_host(self, ctx, why):
+        """Replace the RCCL communicator by the host-staged exchange (collective: all ranks call it)."""
+        if self.rank == 0:
+            print("[cfdh] WARNING: %s -- falling back to host-staged exchange over torch.distributed" % why, flush=True)
+        self.backend = "host"
+        self.fallback_reason = why
+        self._attach_host(ctx)
+
+    def selfcheck(self, ctx, mesh):
+        """One halo exchange and one all-reduce of the attached communicator against values known on the
+        host (collective).  Needs a context with parameters and state set.  Returns None or the defect."""
+        part = self.part
+        gid = part.l2g.astype(np.float64)
+        f = 1.0 + 1e-6 * gid                       # nodal field known on every rank
+        u = np.stack([f, -0.5 * f], axis=1)
+        u[part.nvo:] = -7.0                        # ghosts: to be overwritten by the exchange
+        p = 3.0 * f
+        p[part.nvo:] = -7.0
+        ctx.set_state(u=u.ravel(), p=p)
+        ctx.assemble(False)                        # refreshes the halo of the iterate
+        gu, gp = ctx.get_solution()
+        bad = None
+        if not (np.array_equal(gu.reshape(-1, 2)[:, 0], f) and np.array_equal(gu.reshape(-1, 2)[:, 1], -0.5 * f)
+                and np.array_equal(gp, 3.0 * f)):
+            bad = "halo exchange delivered wrong ghost values"
+        # ||u||_L2 over the whole mesh through the library's all-reduce vs the host value
+        fg = 1.0 + 1e-6 * np.arange(mesh.num_vertices)
+        fc = fg[mesh.cells]
+        ff = (fc ** 2).sum(axis=1) + fc[:, 0] * fc[:, 1] + fc[:, 0] * fc[:, 2] + fc[:, 1] * fc[:, 2]
+        ref = np.sqrt(1.25 * (mesh.cell_areas() / 6.0 * ff).sum())
+        got = ctx.functional(2)
+        if bad is None and not abs(got - ref) <= 1e-10 * ref:
+            bad = "all-reduce gave %r, expected %r" % (got, ref)
+        worst = self.allreduce(0.0 if bad is None else 1.0, "max")
+        return bad if bad else ("defect on another rank" if worst > 0 else None)
 
     def _attach_host(self, ctx):
         import torch

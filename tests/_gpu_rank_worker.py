@@ -20,15 +20,17 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out = sys.argv[1]
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    comm = PartComm(rank, world, "host")
+    comm = PartComm(rank, world, os.environ.get("CFDH_TEST_BACKEND", "host"))
     tight = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
-    sc = DFG1Benchmark("stabilized_schur", 0.01, 0.05, m=16, quiet=True, device=0, comm=comm, options=tight)
+    sc = DFG1Benchmark(os.environ.get("CFDH_TEST_SOLVER", "stabilized_schur"), 0.01, 0.05, m=16, quiet=True, device=0,
+                       comm=comm, options=tight)
     sc.solve(None)
     u = sc.solver.u_sol.x.array.copy()   # gathers the owned slices of every rank
     p = sc.solver.p_sol.x.array.copy()
     if rank == 0:
         np.savez(out, u=u, p=p, drag=sc.drag, lift=sc.lift, norm_v=sc.norm_v, norm_p=sc.norm_p, steps=sc.num_steps,
-                 krylov=sum(s.krylov_its for _, s in sc.step_stats))
+                 krylov=sum(s.krylov_its for _, s in sc.step_stats), backend=comm.backend,
+                 fallback=str(getattr(comm, "fallback_reason", "")))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -20,15 +20,20 @@ def _free_port():
     return p
 
 
-def _run(world, out):
+def _run(world, out, timeout=600, **extra_env):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="2", CFDH_HOST_THREADS="2")
+                   OMP_NUM_THREADS="2", CFDH_HOST_THREADS="2", **extra_env)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    try:
+        outs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        raise
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
     return np.load(out)
@@ -67,3 +72,29 @@ def test_rccl_binding_single_rank():
     st = ctx.solve_step()
     assert st.reason > 0
     ctx.close()
+
+
+def test_partitioned_bdf2_matches_single_rank(tmp_path):
+    """The BDF2 variant through the same partition / halo plan (u_prev2 travels with the shift on each rank)."""
+    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+    tight = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
+    ref = DFG1Benchmark("stabilized_schur_bdf2", 0.01, 0.05, m=16, quiet=True, options=tight)
+    ref.solve(None)
+    u0, p0 = ref.solver.u_sol.x.array.copy(), ref.solver.p_sol.x.array.copy()
+    r = _run(2, str(tmp_path / "bdf2.npz"), CFDH_TEST_SOLVER="stabilized_schur_bdf2")
+    assert int(r["steps"]) == ref.num_steps
+    assert np.linalg.norm(r["u"] - u0) <= 1e-9 * np.linalg.norm(u0)
+    assert np.linalg.norm(r["p"] - p0) <= 1e-8 * np.linalg.norm(p0)
+    assert abs(float(r["drag"]) - ref.drag) <= 1e-8 * abs(ref.drag)
+
+
+def test_rccl_failure_falls_back_to_host_exchange(tmp_path):
+    """Two ranks on ONE GPU cannot form an RCCL communicator (duplicate device): the init error must be
+    caught on every rank and the job must continue, correctly, on the host-staged exchange."""
+    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+    tight = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
+    ref = DFG1Benchmark("stabilized_schur", 0.01, 0.05, m=16, quiet=True, options=tight)
+    ref.solve(None)
+    r = _run(2, str(tmp_path / "fb.npz"), timeout=240, CFDH_TEST_BACKEND="rccl")
+    assert str(r["backend"]) == "host" and "RCCL" in str(r["fallback"])
+    assert np.linalg.norm(r["u"] - ref.solver.u_sol.x.array) <= 1e-9 * np.linalg.norm(ref.solver.u_sol.x.array)
