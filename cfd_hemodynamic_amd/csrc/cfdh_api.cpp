@@ -29,7 +29,7 @@ int cfdh_default_options(cfdh_options *o) {
   o->ksp_rtol = 1e-5; o->ksp_atol = 1e-50; o->ksp_max_it = 1000; o->ksp_restart = 200;
   o->cheb_degree = 3; o->cheb_ratio = 10.0; o->schur_full = 2;
   o->amg_smooth_degree = 1; o->amg_smooth_ratio = 8.0; o->amg_theta = 0.08; o->amg_max_coarse = 1000;
-  o->pc_refresh = 0; o->remove_p_mean = 1; o->verbose = 0; o->pc_type = 1;
+  o->pc_refresh = 0; o->remove_p_mean = 1; o->verbose = 0; o->pc_type = 1; o->cc_smooth_degree = 2;
   return 0;
 }
 
@@ -96,7 +96,7 @@ int cfdh_set_params(cfdh_ctx *c, double dt, double rho, double mu, double mu_fac
 
 int cfdh_set_options(cfdh_ctx *c, const cfdh_options *o) {
   if (!c || !o) return CFDH_E_ARG;
-  if (o->ksp_restart < 1 || o->ksp_restart > 1000 || o->cheb_degree < 1 || !(o->cheb_ratio > 1) || o->amg_smooth_degree < 1 ||
+  if (o->ksp_restart < 1 || o->ksp_restart > 1000 || o->cheb_degree < 1 || o->cc_smooth_degree < 1 || !(o->cheb_ratio > 1) || o->amg_smooth_degree < 1 ||
       !(o->amg_smooth_ratio > 1) || o->amg_max_coarse < 8 || o->amg_max_coarse > 2000)
     return cfdh_fail(c, CFDH_E_ARG, "option out of range");
   const bool pc_changed = o->amg_theta != c->opt.amg_theta || o->amg_max_coarse != c->opt.amg_max_coarse ||

@@ -85,6 +85,7 @@ typedef struct cfdh_options {
   int32_t verbose;
   int32_t pc_type;          /* 0: SELFP Schur matrix + Chebyshev(A00) (the reference's SELFP, :235);
                              * 1: Cahouet-Chabard Schur approximation + AMG(A00) (mesh-independent) */
+  int32_t cc_smooth_degree; /* pc_type 1: Chebyshev steps on the mass-like operator H (default 2) */
 } cfdh_options;
 
 typedef struct cfdh_stats {

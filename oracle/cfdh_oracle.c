@@ -120,6 +120,7 @@ typedef struct {
   int amg_smooth_degree;
   double amg_smooth_ratio, amg_theta;
   int amg_max_coarse;
+  int cc_smooth_degree; /* pc_kind 2: Chebyshev steps on H */
   int schur_upper; /* pc_kind 2: block upper-triangular factor (z_p = S^-1 r_p; z_u = A^-1 (r_u - A01 z_p)), the GPU default */
 } orc_opts;
 
@@ -1281,7 +1282,7 @@ static void pc_apply(orc_ctx *c, pc_ws *p, const double *r, double *z) {
     }
     /* z_p = (a' L^-1 + b' M_l^-1) H^-1 t_p */
     amg_level *Hl = c->Hlev;
-    cheb_smooth(&Hl->A, Hl->dinv, Hl->lmin, Hl->lmax, 3, p->tp, p->yp, 1, Hl->r, Hl->d0, Hl->d1);
+    cheb_smooth(&Hl->A, Hl->dinv, Hl->lmin, Hl->lmax, o->cc_smooth_degree, p->tp, p->yp, 1, Hl->r, Hl->d0, Hl->d1);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < nv; i++) p->cd0[i] = c->ccMl[i] * p->yp[i];
     amg_vcycle(c->hL, o, 0, p->cd0, p->cd1);
@@ -1401,7 +1402,7 @@ void orc_default_opts(orc_opts *o) {
   o->sub_rtol = 1e-5; o->sub_max_it = 10000; o->sub_restart = 30;
   o->remove_p_mean = 1; o->verbose = 0;
   o->pc_kind = 0; o->cheb_degree = 3; o->cheb_ratio = 10.0; o->amg_smooth_degree = 1; o->amg_smooth_ratio = 8.0;
-  o->amg_theta = 0.08; o->amg_max_coarse = 1000; o->schur_upper = 0;
+  o->amg_theta = 0.08; o->amg_max_coarse = 1000; o->cc_smooth_degree = 2; o->schur_upper = 0;
 }
 
 /* One time step: Newton on the monolithic vector xv (in: initial guess = previous

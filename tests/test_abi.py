@@ -34,6 +34,7 @@ def test_struct_layouts_match_header():
     assert (o.snes_rtol, o.snes_atol, o.snes_stol, o.snes_max_it) == (1e-8, 1e-50, 1e-8, 100)
     assert (o.ksp_rtol, o.ksp_max_it, o.ksp_restart) == (1e-5, 1000, 200)
     assert (o.cheb_degree, o.amg_smooth_degree, o.schur_full, o.remove_p_mean, o.verbose) == (3, 1, 2, 1, 0)
+    assert (o.pc_type, o.cc_smooth_degree) == (1, 2)
     assert ctypes.sizeof(_lib.Stats) == 4 * 4 + 6 * 8
 
 

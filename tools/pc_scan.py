@@ -5,7 +5,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from util import dfg_case, make_ctx
 m = int(sys.argv[1]); nsteps = int(sys.argv[2])
 case = dfg_case(m); nv = case.nv
-for extra in [dict(), dict(schur_full=2), dict(schur_full=0)]:
+for extra in [dict(), dict(cheb_degree=2), dict(cheb_degree=1), dict(cheb_degree=2, amg_smooth_ratio=4.0), dict(amg_theta=0.04), dict(amg_theta=0.15)]:
     ctx = make_ctx(case)
     o = ctx.default_options()
     for k, v in extra.items(): setattr(o, k, v)
