@@ -77,6 +77,7 @@ void cfdh_destroy(cfdh_ctx *c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto &e : c->pc_graphs) for (auto &x : e.exec) if (x) (void)hipGraphExecDestroy(x);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->ev_h) (void)hipEventDestroy(c->ev_h);
   if (c->h_big) (void)hipHostFree(c->h_big);
   hipStream_t s = c->stream;
   delete c;

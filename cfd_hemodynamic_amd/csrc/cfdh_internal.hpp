@@ -168,6 +168,8 @@ struct cfdh_ctx {
   // reductions
   dbuf<double> red_partial, red_out;
   double *h_pinned = nullptr;  // pinned host scratch for scalar read-back
+  double *h_pinned_dev = nullptr;  // the same buffer as the device sees it (kernels write read-back scalars into it)
+  hipEvent_t ev_h = nullptr;   // marks 'Gram-Schmidt coefficients are in h_pinned'
   int red_blocks = 0;
 
   // Krylov workspace
@@ -290,7 +292,7 @@ int v_dot(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host
 int v_norm2(cfdh_ctx *c, int n, const double *x, double *out_host);
 int v_norminf_diff(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host);  // y may be null
 int v_sub_mean(cfdh_ctx *c, int n, double *p);  // remove the (global) mean of p[0..n)
-int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww);
+int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror = false);
 int v_scale_to(cfdh_ctx *c, int n, double a, const double *x, double *y);  // y = a x
 int v_multiaxpy(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, double *w);  // w -= sum h_i V_i
 int v_norm_to_dev(cfdh_ctx *c, int n, const double *w, double *out_dev);  // ||w|| (global) into device scalar

@@ -1303,13 +1303,17 @@ __global__ __launch_bounds__(TPB) void reduce_partial_kernel(int n, const double
 // out[v] = reduce(partial[v*stride .. +nblk)), one block per v; OP 2: sqrt of the sum
 template <int OP>
 __global__ __launch_bounds__(TPB) void reduce_final_kernel(int nblk, int stride, const double *__restrict__ partial,
-                                                           double *__restrict__ out) {
+                                                           double *__restrict__ out, double *__restrict__ mirror = nullptr) {
   __shared__ double sh[4];
   const double *pp = partial + (size_t)blockIdx.x * stride;
   double a = 0;
   for (int i = threadIdx.x; i < nblk; i += TPB) a = (OP == 1) ? fmax(a, pp[i]) : a + pp[i];
   a = (OP == 1) ? block_max(a, sh) : block_sum(a, sh);
-  if (threadIdx.x == 0) out[blockIdx.x] = (OP == 2) ? sqrt(a) : a;
+  if (threadIdx.x == 0) {
+    const double v = (OP == 2) ? sqrt(a) : a;
+    out[blockIdx.x] = v;
+    if (mirror) mirror[blockIdx.x] = v;  // host-mapped copy: the host reads it after an event, no copy kernel
+  }
 }
 
 static int read_scalars(cfdh_ctx *c, const double *dev, int n, double *host) {
@@ -1418,12 +1422,14 @@ __global__ __launch_bounds__(TPB) void multidot_kernel(int n, const double *__re
   }
 }
 // h_dev[0..nvec) = V^T w (and h_dev[nvec] = w.w when with_ww), reduced over all ranks
-int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww) {
+int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror) {
   const int nb = MD_NB, nout = nvec + (with_ww ? 1 : 0);
   if ((size_t)nout * nb > c->red_partial.n) return cfdh_fail(c, CFDH_E_STATE, "multidot workspace too small");
   hipLaunchKernelGGL(multidot_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, w, c->red_partial.p, nb,
                      with_ww ? 1 : 0);
-  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(nout), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, h_dev);
+  // single rank: the h values also land in the host-mapped scratch (c->h_pinned) straight from the kernel
+  double *mir = (mirror && c->nranks <= 1) ? c->h_pinned_dev : nullptr;
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(nout), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, h_dev, mir);
   HIPCHK(c, hipGetLastError());
   return comm_allreduce_dev(c, h_dev, nout, 0);
 }

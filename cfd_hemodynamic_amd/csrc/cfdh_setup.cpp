@@ -352,6 +352,8 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
   HIPCHK(c, c->red_partial.alloc((size_t)c->red_blocks * 260));
   HIPCHK(c, c->red_out.alloc(1024));
   HIPCHK(c, hipHostMalloc((void **)&c->h_pinned, 1024 * sizeof(double)));
+  HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_pinned_dev, c->h_pinned, 0));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming));
   HIPCHK(c, c->dinvA.alloc(2 * (size_t)nvo));
   HIPCHK(c, c->pu0.alloc(2 * (size_t)nvo)); HIPCHK(c, c->pu1.alloc(2 * (size_t)nvo)); HIPCHK(c, c->pu2.alloc(2 * (size_t)nvo));
   HIPCHK(c, c->pr.alloc(2 * (size_t)nvo));
