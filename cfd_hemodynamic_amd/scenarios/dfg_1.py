@@ -20,7 +20,8 @@ class DFG1Benchmark(Scenario):
     wall_marker = 4
     obstacle_marker = 5
 
-    def __init__(self, solver_name, dt, T, f: tuple[float, float] = (0, 0), *, rho=1, mu=1 / 1000, m=18, **solver_kwargs):
+    def __init__(self, solver_name, dt, T, f: tuple[float, float] = (0, 0), *, rho=1, mu=1 / 1000, m=18, mesh_file=None,
+                 **solver_kwargs):
         self._mesh = None
         self._ft = None
         self._bcu = None
@@ -28,6 +29,9 @@ class DFG1Benchmark(Scenario):
         self.mu = mu
         self.rho = rho
         self.m = int(m)
+        # a gmsh file with the reference's markers (inlet 2, outlet 3, walls 4, obstacle 5) takes the place of the
+        # XDMF the reference loads when present (dfg_1.py:42-48); otherwise the block-structured generator
+        self.mesh_file = mesh_file
         self.quiet = bool(solver_kwargs.get("quiet", False))
         super().__init__(solver_name, "dfg_1", rho, mu, dt, T, f, **solver_kwargs)
         self.setup()
@@ -35,7 +39,11 @@ class DFG1Benchmark(Scenario):
     @property
     def mesh(self):
         if not self._mesh:
-            self._mesh, self._ft = create_dfg_channel(self.m)
+            if self.mesh_file:
+                from ..meshio import read_msh
+                self._mesh, self._ft = read_msh(self.mesh_file)
+            else:
+                self._mesh, self._ft = create_dfg_channel(self.m)
         return self._mesh
 
     @property

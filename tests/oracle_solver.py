@@ -40,3 +40,8 @@ class Solver(SolverBase):
         self.p_sol.x.array[:] = self.x_n[2 * self.nv:]
         self.last_stats = st
         self.calls += 1
+
+    def functional(self, kind, marker=0):
+        """Same contract as the product Solver.functional (cfdh_functional kinds 0-3)."""
+        facets = np.nonzero(self.mesh.facet_marker == marker)[0] if kind in (0, 1) else None
+        return self.O.functional(self.x_n, kind, facets)

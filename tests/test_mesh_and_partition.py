@@ -74,3 +74,29 @@ def test_partition_and_halo_plan(nparts):
             qk = list(parts[q].nbr).index(p.rank)
             recv = parts[q].l2g[parts[q].recv_idx[parts[q].recv_ptr[qk]:parts[q].recv_ptr[qk + 1]]]
             assert np.array_equal(sent, recv)
+
+
+def test_gmsh_reader_v41_and_roundtrip(tmp_path):
+    """gmsh .msh ingest (the file form of dfg_1.py:93-181's model_to_mesh): physical line groups become
+    facet tags, the physical surface the cell tag; geometry-only nodes are dropped; v2.2 round trip."""
+    import os
+    from cfd_hemodynamic_amd.meshio import read_msh, write_msh
+    here = os.path.dirname(os.path.abspath(__file__))
+    mesh, ft = read_msh(os.path.join(here, "golden", "two_triangles_v41.msh"))
+    assert mesh.num_vertices == 4 and mesh.num_cells == 2 and mesh.num_facets == 4
+    assert list(mesh.cell_tags) == [1, 1]
+    mid = mesh.facet_midpoints()
+    tag_at = {(round(float(a), 3), round(float(b), 3)): int(t) for (a, b), t in zip(mid, mesh.facet_marker)}
+    # bottom and top are "walls" (4), left is "inlet" (2), right carries no physical group
+    assert tag_at[(0.5, 0.0)] == 4 and tag_at[(0.5, 1.0)] == 4 and tag_at[(0.0, 0.5)] == 2 and tag_at[(1.0, 0.5)] == 0
+    assert len(ft.find(4)) == 2 and len(ft.find(2)) == 1
+    # a generated mesh survives write -> read (coordinates to the last bit, same tags)
+    from cfd_hemodynamic_amd.mesh import create_dfg_channel
+    m0, ft0 = create_dfg_channel(4)
+    p = str(tmp_path / "dfg.msh")
+    write_msh(p, m0, ft0)
+    m1, ft1 = read_msh(p)
+    assert np.array_equal(m1.x, m0.x) and np.array_equal(m1.cells, m0.cells)
+    assert np.array_equal(m1.facet_marker, m0.facet_marker)
+    for mk in (2, 3, 4, 5):
+        assert np.array_equal(np.sort(ft1.find(mk)), np.sort(ft0.find(mk)))

@@ -166,3 +166,21 @@ def test_p1_point_evaluation():
     v = m.eval_p1(f, pts)
     assert np.allclose(v[:3], [2 * x - 3 * y + 0.5 for x, y in pts[:3]], atol=1e-13)
     assert np.isnan(v[3])
+
+
+def test_dfg_scenario_from_msh_file(oracle_backend, tmp_path):
+    """`mesh_file=` (a gmsh .msh with the reference's markers) drives the same scenario as the generator."""
+    from cfd_hemodynamic_amd.mesh import create_dfg_channel
+    from cfd_hemodynamic_amd.meshio import write_msh
+    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+    m0, ft0 = create_dfg_channel(6)
+    path = str(tmp_path / "dfg6.msh")
+    write_msh(path, m0, ft0)
+    a = DFG1Benchmark(oracle_backend, 0.01, 0.025, m=6, quiet=True)
+    a.solve(None)
+    b = DFG1Benchmark(oracle_backend, 0.01, 0.025, mesh_file=path, quiet=True)
+    b.solve(None)
+    # same mesh, same numbering: equal up to the run-to-run round-off of the threaded oracle reductions
+    assert np.array_equal(a.mesh.cells, b.mesh.cells) and np.array_equal(a.mesh.facet_marker, b.mesh.facet_marker)
+    assert np.allclose(a.solver.u_sol.x.array, b.solver.u_sol.x.array, rtol=0, atol=1e-10)
+    assert abs(a.drag - b.drag) < 1e-8 and abs(a.lift - b.lift) < 1e-8 and abs(a.p_diff - b.p_diff) < 1e-8
