@@ -50,11 +50,12 @@ def kernel_bytes(ctx):
         2: ("tau_moments", 12.0 * nc + 32.0 * nvo + 64.0 * nc),
         # Chebyshev step on A00: values 32 B + column 4 B per entry; rowptr 4 + 7 vectors x 16 B per row
         3: ("cheb_step_A00", 36.0 * nnzv + 116.0 * nvo),
-        # level-0 smoother sweep of the pressure hierarchy (scalar CSR): 12 B per entry; rowptr 4 + 5 vectors x 8 B per row
-        4: ("amg_sweep_pressure", 12.0 * spnnz + 44.0 * nvo),
-        # level-0 smoother sweep of the velocity hierarchy, two right-hand sides: 12 B per entry; rowptr 4, weights 8,
+        # level-0 smoother sweep of the pressure hierarchy (SELL-64, fp32 values): 4 B value + 4 B column per entry;
+        # slice pointer ~0, weights 8 + 4 vectors x 8 B per row
+        4: ("amg_sweep_pressure", 8.0 * spnnz + 40.0 * nvo),
+        # level-0 smoother sweep of the velocity hierarchy, two right-hand sides: 8 B per entry; weights 8,
         # 3 vectors x 16 B per row
-        5: ("amg_sweep_velocity_2rhs", 12.0 * ctx.info(8) + 60.0 * nvo),
+        5: ("amg_sweep_velocity_2rhs", 8.0 * ctx.info(8) + 56.0 * nvo),
     }
 
 

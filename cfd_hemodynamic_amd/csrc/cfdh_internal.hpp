@@ -62,7 +62,9 @@ struct CsrDev {
   // entry of slice s (in units of entries); width of slice s = (sptr[s+1]-sptr[s]) / 64.
   int nslice = 0;
   dbuf<int> sptr, scol;
-  dbuf<double> sval, svalw;  // svalw: values scaled by a column weight (Jacobi pre-sweep), optional
+  // SELL values are kept in fp32: they feed preconditioner sweeps only (FGMRES is flexible and measures the
+  // true fp64 residual), and the matrix stream is 60 % of a fine-level sweep's traffic
+  dbuf<float> sval, svalw;  // svalw: values scaled by a column weight (Jacobi pre-sweep), optional
 };
 
 struct AmgLevel {

@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(TPB) void jacobi_post_kernel(int n, const int *__re
 // ---- SELL-64 variants: one lane per row, fully coalesced matrix stream, no cross-lane reduction
 template <int MODE, typename T>
 __global__ __launch_bounds__(TPB) void sell_spmv_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
-                                                        const double *__restrict__ sval, const T *__restrict__ x,
+                                                        const float *__restrict__ sval, const T *__restrict__ x,
                                                         T *__restrict__ y, const T *__restrict__ b) {
   const int row = blockIdx.x * TPB + threadIdx.x;
   if (row >= n) return;
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(TPB) void sell_spmv_kernel(int n, const int *__rest
 #pragma unroll 4
   for (int k = 0; k < w; k++) {
     const int p = p0 + k * 64 + lane;
-    a = vfma(sval[p], x[scol[p]], a);
+    a = vfma((double)sval[p], x[scol[p]], a);
   }
   if (MODE == 0) y[row] = a;
   else if (MODE == 1) y[row] = vsub(b[row], a);
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(TPB) void sell_spmv_kernel(int n, const int *__rest
 }
 template <typename T>
 __global__ __launch_bounds__(TPB) void sell_jacobi_pre_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
-                                                              const double *__restrict__ svalw, const double *__restrict__ wdinv,
+                                                              const float *__restrict__ svalw, const double *__restrict__ wdinv,
                                                               const T *__restrict__ b, T *__restrict__ xa, T *__restrict__ r) {
   const int row = blockIdx.x * TPB + threadIdx.x;
   if (row >= n) return;
@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(TPB) void sell_jacobi_pre_kernel(int n, const int *
 #pragma unroll 4
   for (int k = 0; k < w; k++) {
     const int p = p0 + k * 64 + lane;
-    a = vfma(svalw[p], b[scol[p]], a);   // A (w D^-1 b): the column weight is folded into svalw
+    a = vfma((double)svalw[p], b[scol[p]], a);   // A (w D^-1 b): the column weight is folded into svalw
   }
   const T bi = b[row];
   xa[row] = vscale(wdinv[row], bi);
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(TPB) void sell_jacobi_pre_kernel(int n, const int *
 }
 template <typename T>
 __global__ __launch_bounds__(TPB) void sell_jacobi_post_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
-                                                               const double *__restrict__ sval, const double *__restrict__ wdinv,
+                                                               const float *__restrict__ sval, const double *__restrict__ wdinv,
                                                                const T *__restrict__ b, const T *__restrict__ xin,
                                                                T *__restrict__ xout) {
   const int row = blockIdx.x * TPB + threadIdx.x;
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(TPB) void sell_jacobi_post_kernel(int n, const int 
 #pragma unroll 4
   for (int k = 0; k < w; k++) {
     const int p = p0 + k * 64 + lane;
-    a = vfma(sval[p], xin[scol[p]], a);
+    a = vfma((double)sval[p], xin[scol[p]], a);
   }
   xout[row] = vadd(xin[row], vscale(wdinv[row], vsub(b[row], a)));
 }

@@ -496,14 +496,14 @@ static int upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vecto
     sptr[sl + 1] = sptr[sl] + 64 * w;
   }
   std::vector<int> scol((size_t)sptr[ns], 0);
-  std::vector<double> sval((size_t)sptr[ns], 0.0), svalw;
-  if (colw) svalw.assign((size_t)sptr[ns], 0.0);
+  std::vector<float> sval((size_t)sptr[ns], 0.0f), svalw;
+  if (colw) svalw.assign((size_t)sptr[ns], 0.0f);
   for (int r = 0; r < H.n; r++) {
     const int sl = r >> 6, lane = r & 63;
     for (int k = H.rowptr[r], j = 0; k < H.rowptr[r + 1]; k++, j++) {
       const size_t p = (size_t)sptr[sl] + (size_t)j * 64 + lane;
-      scol[p] = H.col[k]; sval[p] = H.val[k];
-      if (colw) svalw[p] = H.val[k] * (*colw)[H.col[k]];
+      scol[p] = H.col[k]; sval[p] = (float)H.val[k];
+      if (colw) svalw[p] = (float)(H.val[k] * (*colw)[H.col[k]]);
     }
     // padding keeps column 0 with value 0: a harmless in-range gather
   }
