@@ -171,6 +171,8 @@ struct cfdh_ctx {
   dbuf<double> red_partial, red_out;
   double *h_pinned = nullptr;  // pinned host scratch for scalar read-back
   double *h_pinned_dev = nullptr;  // the same buffer as the device sees it (kernels write read-back scalars into it)
+  const double *mirror_src = nullptr;  // device scalars whose host-mapped copy is current (see read_scalars)
+  int mirror_cnt = 0;
   hipEvent_t ev_h = nullptr;   // marks 'Gram-Schmidt coefficients are in h_pinned'
   int red_blocks = 0;
 

@@ -1316,7 +1316,21 @@ __global__ __launch_bounds__(TPB) void reduce_final_kernel(int nblk, int stride,
   }
 }
 
+// Single rank: the final reduction kernel also stores its results into host-mapped memory (h_pinned + 300),
+// so reading them back costs a stream synchronisation instead of a copy kernel (~11 us each).
+#define CFDH_MIRROR_OFF 300
+static double *scalar_mirror(cfdh_ctx *c, const double *out_dev, int cnt) {
+  if (c->nranks > 1 || cnt > 64) { c->mirror_src = nullptr; return nullptr; }
+  c->mirror_src = out_dev; c->mirror_cnt = cnt;
+  return c->h_pinned_dev + CFDH_MIRROR_OFF;
+}
 static int read_scalars(cfdh_ctx *c, const double *dev, int n, double *host) {
+  if (c->mirror_src == dev && n <= c->mirror_cnt) {
+    c->mirror_src = nullptr;  // one shot
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) host[i] = c->h_pinned[CFDH_MIRROR_OFF + i];
+    return 0;
+  }
   HIPCHK(c, hipMemcpyAsync(c->h_pinned, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < n; i++) host[i] = c->h_pinned[i];
@@ -1327,10 +1341,12 @@ static int reduce_dev(cfdh_ctx *c, int op, int n, const double *x, const double 
   const int nb = vgrid(n) > c->red_blocks ? c->red_blocks : vgrid(n);
   if (op == 0) {
     hipLaunchKernelGGL(reduce_partial_kernel<0>, dim3(nb), dim3(TPB), 0, c->stream, n, x, y, c->red_partial.p);
-    hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, out_dev);
+    hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, out_dev,
+                       scalar_mirror(c, out_dev, 1));
   } else {
     hipLaunchKernelGGL(reduce_partial_kernel<1>, dim3(nb), dim3(TPB), 0, c->stream, n, x, y, c->red_partial.p);
-    hipLaunchKernelGGL(reduce_final_kernel<1>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, out_dev);
+    hipLaunchKernelGGL(reduce_final_kernel<1>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, out_dev,
+                       scalar_mirror(c, out_dev, 1));
   }
   HIPCHK(c, hipGetLastError());
   return comm_allreduce_dev(c, out_dev, 1, op);
@@ -1366,6 +1382,7 @@ int v_sub_mean(cfdh_ctx *c, int n, double *p) {
   const int nb = vgrid(n) > c->red_blocks ? c->red_blocks : vgrid(n);
   double *acc = c->red_out.p + 8;  // [sum, count]
   hipLaunchKernelGGL(sum_partial_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, p, c->red_partial.p);
+  c->mirror_src = nullptr;
   hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, acc);
   HIPCHK(c, hipGetLastError());
   double scale = 1.0 / n;
@@ -1500,7 +1517,8 @@ __global__ __launch_bounds__(TPB) void nulltest_kernel(int nvo, const int *__res
 int k_nullspace_test(cfdh_ctx *c, double *nrm) {
   const int nb = vgrid(c->nvo) > c->red_blocks ? c->red_blocks : vgrid(c->nvo);
   hipLaunchKernelGGL(nulltest_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nvo, c->vptr.p, c->A01.p, c->A11.p, c->red_partial.p);
-  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p);
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p,
+                     scalar_mirror(c, c->red_out.p, 1));
   HIPCHK(c, hipGetLastError());
   CHK(comm_allreduce_dev(c, c->red_out.p, 1, 0));
   double s;
@@ -1653,7 +1671,8 @@ int k_functional(cfdh_ctx *c, int kind, int marker, double *out) {
   } else {
     return cfdh_fail(c, CFDH_E_ARG, "unknown functional kind %d", kind);
   }
-  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(2), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p);
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(2), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p,
+                     scalar_mirror(c, c->red_out.p, 2));
   HIPCHK(c, hipGetLastError());
   CHK(comm_allreduce_dev(c, c->red_out.p, 2, 0));
   double v[2];

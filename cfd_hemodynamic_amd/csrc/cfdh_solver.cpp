@@ -258,10 +258,10 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
         CHK(k_amg_vcycle(c, c->hA, ru, multi ? c->pcw.p : c->pu0.p));
         return 0;
       case 1:
-        if (upper) CHK(v_copy(c, nvo, rp, c->pp0.p));
+        if (upper) { /* t_p = r_p: used in place */ }
         else if (multi) CHK(k_spmv_block_ghost(c, 3, c->pcw.p, c->pp0.p, rp));   // t_p = r_p - A10 y_u (with ghosts)
         else CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));
-        CHK(k_level_smooth(c, &c->Hlev, c->pp0.p, c->pp1.p, c->opt.cc_smooth_degree));
+        CHK(k_level_smooth(c, &c->Hlev, upper ? rp : c->pp0.p, c->pp1.p, c->opt.cc_smooth_degree));
         CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
         if (global_p) {
           CHK(v_zero(c, c->gp_n, c->gp_rhs.p));
@@ -275,7 +275,7 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
         } else {
           CHK(k_amg_vcycle(c, c->hL, c->pu1.p, c->pu2.p));
         }
-        CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, c->pp0.p, c->ccPbc.p, zp));
+        CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, upper ? rp : c->pp0.p, c->ccPbc.p, zp));
         if (multi && c->opt.schur_full) CHK(v_copy(c, nvo, zp, c->pcw.p + nu));  // z_p into the halo scratch vector
         return 0;
       default:
