@@ -280,6 +280,7 @@ int k_cheb_a00_coeffs(cfdh_ctx *c);  // x = Cheb_k(A00) b, zero initial guess
 int k_csr_spmv(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mode, const double *b);  // mode 0: y=Ax, 1: y=b-Ax, 2: y+=Ax
 int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x);
 int k_level_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, int degree);
+bool k_cc_cheb2_scale(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, const double *ml, double *y);
 int k_cc_scale(cfdh_ctx *c, int n, const double *ml, const double *z, double *y);
 int k_scatter_global(cfdh_ctx *c, int n, const int *l2g, const double *loc, double *glob);
 int k_gather_global(cfdh_ctx *c, int n, const int *l2g, const double *glob, double *loc);

@@ -1020,6 +1020,42 @@ static int level_cheb(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, bool
 }
 int k_level_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, int degree) { return level_cheb(c, L, b, x, true, degree, false); }
 
+// Two Chebyshev steps from a zero guess on a SELL-64 level in ONE pass over the matrix, with the
+// Cahouet-Chabard scaling fused:  d = w D^-1 b ; r = b - A d ; x = d + (c1 d + c2 D^-1 r) ; y = ml .* x.
+// (svalw carries the column weights w D^-1, as in the Jacobi pre-sweep.)
+__global__ __launch_bounds__(TPB) void sell_cheb2_scale_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                               const float *__restrict__ svalw, const double *__restrict__ wdinv,
+                                                               const double *__restrict__ dinv, const double *__restrict__ b,
+                                                               double *__restrict__ x, const double *__restrict__ ml,
+                                                               double *__restrict__ y, double c1, double c2) {
+  const int row = blockIdx.x * TPB + threadIdx.x;
+  if (row >= n) return;
+  const int sl = row >> 6, lane = row & 63;
+  const int p0 = sptr[sl], w = (sptr[sl + 1] - p0) >> 6;
+  double a = 0.0;
+#pragma unroll 4
+  for (int k = 0; k < w; k++) {
+    const int p = p0 + k * 64 + lane;
+    a = fma((double)svalw[p], b[scol[p]], a);
+  }
+  const double bi = b[row];
+  const double dd = wdinv[row] * bi;
+  const double xv = dd + (c1 * dd + c2 * dinv[row] * (bi - a));
+  x[row] = xv;
+  y[row] = ml[row] * xv;
+}
+// x = Cheb2(H) b and y = ml .* x; false when the level does not qualify (the caller takes the generic path)
+bool k_cc_cheb2_scale(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, const double *ml, double *y) {
+  const int n = L->n;
+  if (!(L->A.nnz <= 12ll * n && n >= 16384)) return false;
+  const double theta = 0.5 * (L->lmax + L->lmin), delta = 0.5 * (L->lmax - L->lmin), sigma = theta / delta;
+  const double rho = 1.0 / sigma, rho_new = 1.0 / (2.0 * sigma - rho);
+  const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+  hipLaunchKernelGGL(sell_cheb2_scale_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, L->A.sptr.p, L->A.scol.p,
+                     L->A.svalw.p, L->wdinv.p, L->dinv.p, b, x, ml, y, c1, c2);
+  return hipGetLastError() == hipSuccess;
+}
+
 // y = Minv b for the dense coarsest inverse: one wave per row
 template <typename T>
 __global__ __launch_bounds__(64) void dense_mv_kernel(int n, const double *__restrict__ Minv, const T *__restrict__ b,

@@ -261,8 +261,10 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
         if (upper) { /* t_p = r_p: used in place */ }
         else if (multi) CHK(k_spmv_block_ghost(c, 3, c->pcw.p, c->pp0.p, rp));   // t_p = r_p - A10 y_u (with ghosts)
         else CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));
-        CHK(k_level_smooth(c, &c->Hlev, upper ? rp : c->pp0.p, c->pp1.p, c->opt.cc_smooth_degree));
-        CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
+        if (!(c->opt.cc_smooth_degree == 2 && k_cc_cheb2_scale(c, &c->Hlev, upper ? rp : c->pp0.p, c->pp1.p, c->ccMl.p, c->pu1.p))) {
+          CHK(k_level_smooth(c, &c->Hlev, upper ? rp : c->pp0.p, c->pp1.p, c->opt.cc_smooth_degree));
+          CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
+        }
         if (global_p) {
           CHK(v_zero(c, c->gp_n, c->gp_rhs.p));
           CHK(k_scatter_global(c, nvo, c->gp_l2g.p, c->pu1.p, c->gp_rhs.p));
