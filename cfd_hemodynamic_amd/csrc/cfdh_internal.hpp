@@ -315,7 +315,8 @@ int comm_finalize(cfdh_ctx *c);
 // ---- solver (cfdh_solver.cpp) ------------------------------------------------------
 int cfdh_pc_update(cfdh_ctx *c, bool force_refresh);
 int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z);
-int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its, int *reason);
+int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its, int *reason, double bnorm = -1.0);
+int v_norm2_pair(cfdh_ctx *c, int n, const double *x, const double *y, double *nx, double *ny);
 int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st);
 int cfdh_download_blocks(cfdh_ctx *c, std::vector<double> &a00, std::vector<double> &a01, std::vector<double> &a10,
                          std::vector<double> &a11);

@@ -1397,6 +1397,21 @@ int v_norm2(cfdh_ctx *c, int n, const double *x, double *out_host) {
   *out_host = sqrt(*out_host);
   return 0;
 }
+// |x| and |y| with one read-back (one host synchronisation instead of two)
+int v_norm2_pair(cfdh_ctx *c, int n, const double *x, const double *y, double *nx, double *ny) {
+  const int nb = vgrid(n) > c->red_blocks ? c->red_blocks : vgrid(n);
+  if ((size_t)2 * nb > c->red_partial.n) return cfdh_fail(c, CFDH_E_STATE, "reduction workspace too small");
+  hipLaunchKernelGGL(reduce_partial_kernel<0>, dim3(nb), dim3(TPB), 0, c->stream, n, x, x, c->red_partial.p);
+  hipLaunchKernelGGL(reduce_partial_kernel<0>, dim3(nb), dim3(TPB), 0, c->stream, n, y, y, c->red_partial.p + nb);
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(2), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p,
+                     scalar_mirror(c, c->red_out.p, 2));
+  HIPCHK(c, hipGetLastError());
+  CHK(comm_allreduce_dev(c, c->red_out.p, 2, 0));
+  double v[2];
+  CHK(read_scalars(c, c->red_out.p, 2, v));
+  *nx = sqrt(v[0]); *ny = sqrt(v[1]);
+  return 0;
+}
 int v_norminf_diff(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host) {
   CHK(reduce_dev(c, 1, n, x, y, c->red_out.p));
   return read_scalars(c, c->red_out.p, 1, out_host);

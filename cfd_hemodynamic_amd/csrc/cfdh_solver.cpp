@@ -383,15 +383,15 @@ static int ensure_krylov(cfdh_ctx *c) {
 // residual norm relative to |b| (KSP defaults: rtol, atol; KSP_NORM_UNPRECONDITIONED
 // for FGMRES).  Classical Gram-Schmidt with one re-orthogonalisation pass; the
 // 2j+3 scalars of an iteration come back in a single read.
-int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reason_out) {
+int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reason_out, double bnorm) {
   CHK(ensure_krylov(c));
   const int n = c->NO, m = c->kry_m;
   const size_t ld = ((size_t)c->NL + 1) & ~(size_t)1;
   const cfdh_options &o = c->opt;
   std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hh(2 * (size_t)(m + 1) + 8);
-  double bn;
+  double bn = bnorm;  // the caller may know |b| already (Newton: |F| of the accepted iterate)
   CHK(v_zero(c, c->NL, x));
-  CHK(v_norm2(c, n, b, &bn));
+  if (!(bn >= 0.0)) CHK(v_norm2(c, n, b, &bn));
   int its = 0, reason = 0;
   if (!std::isfinite(bn)) { *its_out = 0; *reason_out = -9; return 0; }
   if (bn == 0.0) { *its_out = 0; *reason_out = 2; return 0; }
@@ -401,9 +401,7 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
   for (;;) {
     double beta;
     if (first) {
-      CHK(v_copy(c, n, b, V));  // r0 = b
-      beta = bn;
-      first = false;
+      beta = bn;  // r0 = b: v_0 = b / |b| is formed below straight from b
     } else {
       CHK(comm_halo(c, x));
       CHK(k_spmv_full(c, x, w));
@@ -413,7 +411,9 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
     if (beta <= tol) { reason = 2; break; }
     if (its >= o.ksp_max_it) { reason = -3; break; }
     if (!std::isfinite(beta)) { reason = -9; break; }
-    CHK(v_scale(c, n, 1.0 / beta, V));
+    if (first) CHK(v_scale_to(c, n, 1.0 / beta, b, V));
+    else CHK(v_scale(c, n, 1.0 / beta, V));
+    first = false;
     std::fill(g.begin(), g.end(), 0.0);
     g[0] = beta;
     int j = 0;
@@ -553,12 +553,12 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
     st->ms_pc_setup += wall_ms() - t0;
     t0 = wall_ms();
     int kits = 0, kreason = 0;
-    CHK(cfdh_fgmres(c, c->F.p, d, &kits, &kreason));
+    CHK(cfdh_fgmres(c, c->F.p, d, &kits, &kreason, fn));
     if (kreason < 0 && c->pc_its_ref > 0) {
       // a lagged hierarchy that stopped working: rebuild once and retry
       CHK(cfdh_pc_update(c, true));
       st->krylov_its += kits;
-      CHK(cfdh_fgmres(c, c->F.p, d, &kits, &kreason));
+      CHK(cfdh_fgmres(c, c->F.p, d, &kits, &kreason, fn));
     }
     st->krylov_its += kits;
     st->ms_solve += wall_ms() - t0;
@@ -583,8 +583,7 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
     st->ms_assemble += wall_ms() - t0;
     if (!ok) { reason = CFDH_DIVERGED_LINE_SEARCH; break; }
     double dn, xn;
-    CHK(v_norm2(c, n, d, &dn));
-    CHK(v_norm2(c, n, xt, &xn));
+    CHK(v_norm2_pair(c, n, d, xt, &dn, &xn));
     std::swap(c->x.p, c->xt.p);
     x = c->x.p; xt = c->xt.p;
     st->newton_its = it + 1;
