@@ -135,11 +135,13 @@ class Scenario(ABC):
             for w in writers:
                 w.write(t)
         error_log = None
+        self.errors = []  # (t, relative L2 velocity error) when the scenario has an exact solution
         if self.has_exact_solution:
             error_log = open(f"{output_folder}/err.txt", "w") if (output_folder and mesh.comm.rank == 0) else None
             u_e = Function(solver.V)
             u_e.interpolate(lambda x: self.exact_velocity(t)(x))
             error = self.compute_error(solver.u_sol, u_e, mesh)
+            self.errors.append((t, error))
             if error_log:
                 error_log.write("t = %.3f: error = %.3g" % (t, error) + "\n")
         fast = device_resident and hasattr(solver, "advance") and hasattr(solver, "functional")
@@ -156,6 +158,7 @@ class Scenario(ABC):
             if self.has_exact_solution:
                 u_e.interpolate(self.exact_velocity(t))
                 error = self.compute_error(u_e, solver.u_sol, mesh)
+                self.errors.append((t, error))
                 if error_log:
                     error_log.write("t = %.3f: error = %.3g" % (t, error) + "\n")
             solver.assemble_wss()

@@ -322,3 +322,36 @@ def test_wall_shear_stress_device_matches_host_restatement():
     interior = np.ones(sc.mesh.num_vertices, bool)
     interior[np.unique(sc.mesh.facet_vertices)] = False
     assert not dev.reshape(-1, 2)[interior].any()
+
+
+def test_taylor_green_exact_solution_scenario(monkeypatch):
+    """Analytic scenario (2-D counterpart of the reference's taylor_green.py): time-dependent Dirichlet data
+    for u AND p from the exact solution, error log of the harness.  The device path must reproduce the
+    error history of the oracle-driven harness and stay at the discretisation level."""
+    import sys
+    import types
+
+    import oracle_solver
+    from cfd_hemodynamic_amd.scenarios.taylor_green import TaylorGreenSimulation
+    mod = types.ModuleType("cfd_hemodynamic_amd.solvers._oracle_double")
+    mod.Solver = oracle_solver.Solver
+    monkeypatch.setitem(sys.modules, "cfd_hemodynamic_amd.solvers._oracle_double", mod)
+    kw = dict(nx=32, quiet=True, options=dict(snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-9))
+    g = TaylorGreenSimulation("stabilized_schur", 0.002, 0.04, **kw)
+    g.solve(None, device_resident=True)
+    o = TaylorGreenSimulation("_oracle_double", 0.002, 0.04, nx=32, quiet=True,
+                              options=dict(snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-11))
+    o.solve(None)
+    eg, eo = np.array(g.errors), np.array(o.errors)
+    assert eg.shape == eo.shape == (21, 2) and eg[0, 1] == 0.0
+    assert np.abs(eg[:, 1] - eo[:, 1]).max() < 1e-7
+    assert eg[-1, 1] < 2.5e-3          # measured 1.92e-3 (dominated by the one-step lag of the boundary data)
+    assert np.abs(g.solver.u_sol.x.array - o.solver.u_sol.x.array).max() < 1e-8
+    # halving dt nearly halves the error (first order: the callback updates the Dirichlet data one step late,
+    # SURVEY.md Appendix B 6), refining the mesh at fixed dt does not make it worse
+    c = TaylorGreenSimulation("stabilized_schur", 0.004, 0.04, nx=32, quiet=True)
+    c.solve(None)
+    assert 1.4 < c.errors[-1][1] / eg[-1, 1] < 2.2
+    b = TaylorGreenSimulation("stabilized_schur_bdf2", 0.002, 0.04, nx=32, quiet=True)
+    b.solve(None)
+    assert b.errors[-1][1] < 4e-3
