@@ -98,7 +98,7 @@ int cfdh_set_params(cfdh_ctx *c, double dt, double rho, double mu, double mu_fac
 int cfdh_set_options(cfdh_ctx *c, const cfdh_options *o) {
   if (!c || !o) return CFDH_E_ARG;
   if (o->ksp_restart < 1 || o->ksp_restart > 1000 || o->cheb_degree < 1 || o->cc_smooth_degree < 1 || !(o->cheb_ratio > 1) || o->amg_smooth_degree < 1 ||
-      !(o->amg_smooth_ratio > 1) || o->amg_max_coarse < 8 || o->amg_max_coarse > 2000)
+      !(o->amg_smooth_ratio > 1) || o->amg_max_coarse < 8 || o->amg_max_coarse > 4000)
     return cfdh_fail(c, CFDH_E_ARG, "option out of range");
   const bool pc_changed = o->amg_theta != c->opt.amg_theta || o->amg_max_coarse != c->opt.amg_max_coarse ||
                           o->amg_smooth_ratio != c->opt.amg_smooth_ratio || o->pc_type != c->opt.pc_type;
