@@ -34,7 +34,14 @@ bool load_nccl(std::string &why) {
   // runtime that is then also ours) before loading the ROCm one
   const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
   void *h = nullptr;
-  for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD); if (h) break; }
+  // CFDH_RCCL_LIB selects a specific build of the library (the tests point it at a shared-memory stand-in
+  // so that this file's RCCL branch runs with several ranks on the one-GPU development box)
+  if (const char *e = getenv("CFDH_RCCL_LIB")) {
+    h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { why = std::string("CFDH_RCCL_LIB: cannot dlopen ") + e + ": " + dlerror(); return false; }
+  }
+  if (!h)
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD); if (h) break; }
   if (!h)
     for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
   if (!h) { why = std::string("cannot dlopen librccl: ") + dlerror(); return false; }

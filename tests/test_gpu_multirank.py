@@ -98,3 +98,25 @@ def test_rccl_failure_falls_back_to_host_exchange(tmp_path):
     r = _run(2, str(tmp_path / "fb.npz"), timeout=240, CFDH_TEST_BACKEND="rccl")
     assert str(r["backend"]) == "host" and "RCCL" in str(r["fallback"])
     assert np.linalg.norm(r["u"] - ref.solver.u_sol.x.array) <= 1e-9 * np.linalg.norm(ref.solver.u_sol.x.array)
+
+
+def test_rccl_code_path_with_shared_memory_stand_in(tmp_path):
+    """The RCCL branch of cfdh_comm.cpp (ncclCommInitRank, grouped ncclSend/ncclRecv halo with its counts and
+    offsets, in-stream ncclAllReduce, enum values) with 2 and 3 ranks: CFDH_RCCL_LIB points the library at
+    tests/fake_rccl (same entry points, data through POSIX shared memory), so the code that runs on the
+    multi-GPU node is the code tested here; only the transport underneath the NCCL API differs."""
+    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+    fake = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "fake_rccl"), "-s"])
+    tight = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
+    ref = DFG1Benchmark("stabilized_schur", 0.01, 0.05, m=16, quiet=True, options=tight)
+    ref.solve(None)
+    u0, p0 = ref.solver.u_sol.x.array.copy(), ref.solver.p_sol.x.array.copy()
+    for world in (2, 3):
+        r = _run(world, str(tmp_path / ("rccl%d.npz" % world)), timeout=300, CFDH_TEST_BACKEND="rccl", CFDH_RCCL_LIB=fake)
+        assert str(r["backend"]) == "rccl" and str(r["fallback"]) in ("", "None")
+        assert int(r["steps"]) == ref.num_steps
+        assert np.linalg.norm(r["u"] - u0) <= 1e-9 * np.linalg.norm(u0)
+        assert np.linalg.norm(r["p"] - p0) <= 1e-8 * np.linalg.norm(p0)
+        assert abs(float(r["drag"]) - ref.drag) <= 1e-8 * abs(ref.drag)
