@@ -17,7 +17,7 @@ for _ in range(20):
     ctx.assemble(True)
 v = rng.standard_normal(3 * nv)
 ms, n = ctx.profile_get(0)
-print("variant", os.environ.get("CFDH_ASM_VARIANT"), "asm avg us", 1e3 * ms / n, "GB/s(624B/vtx)", 624.0 * nv / (ms / n * 1e-3) / 1e9, flush=True)
+print("asm avg us", 1e3 * ms / n, "GB/s(624B/vtx)", 624.0 * nv / (ms / n * 1e-3) / 1e9, flush=True)
 ms, n = ctx.profile_get(2)
 print("  moments avg us", 1e3 * ms / max(n, 1))
-np.save("gpurun_out/asm_ref_%s.npy" % os.environ.get("CFDH_ASM_VARIANT", "0"), ref[:100000])
+
