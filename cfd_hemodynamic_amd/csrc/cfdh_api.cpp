@@ -401,6 +401,42 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
   HIPCHK(c, c->gp_l2g.upload(l2g, c->stream));
   HIPCHK(c, c->gp_rhs.alloc(n)); HIPCHK(c, c->gp_sol.alloc(n));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->gp_allgather = false;
+  if (c->nranks > 1 && c->nccl_comm) {
+    // gather plan.  One all-reduce of an owner map (rank+1 at the owned global ids) tells every rank who owns
+    // what; parts send their owned values in ascending global-id order, so the position of global vertex g in
+    // the gathered buffer follows from the map alone.
+    std::vector<double> own(n, 0.0);
+    for (int k = 0; k < c->nvo; k++) own[l2g[k]] = (double)(c->rank + 1);
+    HIPCHK(c, c->gp_rhs.upload(own, c->stream));
+    CHK(comm_allreduce_dev(c, c->gp_rhs.p, n, 0));
+    HIPCHK(c, hipMemcpyAsync(own.data(), c->gp_rhs.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int> cnt(c->nranks, 0), src(n);
+    for (int g = 0; g < n; g++) {
+      const int r = (int)own[g] - 1;
+      if (own[g] != (double)(r + 1) || r < 0 || r >= c->nranks)
+        return cfdh_fail(c, CFDH_E_ARG, "global vertex %d is owned by %g parts (expected exactly one)", g, own[g]);
+      cnt[r]++;
+    }
+    int maxcnt = 0;
+    for (int r = 0; r < c->nranks; r++) maxcnt = std::max(maxcnt, cnt[r]);
+    if (cnt[c->rank] != c->nvo) return cfdh_fail(c, CFDH_E_STATE, "owner map disagrees with nv_owned");
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (int g = 0; g < n; g++) { const int r = (int)own[g] - 1; src[g] = r * maxcnt + cnt[r]++; }
+    std::vector<std::pair<int, int>> byg(c->nvo);
+    for (int k = 0; k < c->nvo; k++) byg[k] = {l2g[k], k};
+    std::sort(byg.begin(), byg.end());
+    std::vector<int> sidx(c->nvo);
+    for (int k = 0; k < c->nvo; k++) sidx[k] = byg[k].second;
+    HIPCHK(c, c->gp_send_idx.upload(sidx, c->stream));
+    HIPCHK(c, c->gp_src_idx.upload(src, c->stream));
+    HIPCHK(c, c->gp_sendbuf.alloc((size_t)maxcnt)); HIPCHK(c, c->gp_recvbuf.alloc((size_t)maxcnt * c->nranks));
+    HIPCHK(c, c->gp_sendbuf.zero(c->stream));  // the padding beyond nv_owned stays zero
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->gp_maxcnt = maxcnt;
+    c->gp_allgather = true;
+  }
   c->gp_n = n;
   c->gp_dirty = true;
   c->pc_valid = false;
@@ -469,6 +505,8 @@ int64_t cfdh_info(const cfdh_ctx *c, int what) {
     case 6: return (int64_t)(c->opt.pc_type == 1 ? c->hL.lev.size() : c->hS.lev.size());
     case 7: return c->nblk;
     case 8: return c->hA.fine_nnz;
+    case 9: return c->gp_allgather ? c->gp_maxcnt : 0;
+    case 10: return c->nccl_comm ? 1 : 0;
     default: return -1;
   }
 }

@@ -20,6 +20,7 @@ struct NcclApi {
   int (*CommInitRank)(nccl_comm_t *, int, nccl_uid, int) = nullptr;
   int (*CommDestroy)(nccl_comm_t) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
   int (*Send)(const void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
   int (*Recv)(void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
@@ -49,7 +50,7 @@ bool load_nccl(std::string &why) {
   *(void **)(&g_nccl.field) = dlsym(h, name);                     \
   if (!g_nccl.field) { why = std::string("missing symbol ") + name; return false; }
   SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
-  SYM(AllReduce, "ncclAllReduce") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart")
+  SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart")
   SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
   g_nccl.lib = h;
@@ -102,6 +103,7 @@ extern "C" int cfdh_comm_init(cfdh_ctx *c, const void *id128, int rank, int nran
 extern "C" int cfdh_comm_set_callbacks(cfdh_ctx *c, cfdh_allreduce_fn ar, cfdh_exchange_fn ex, void *user, int rank, int nranks) {
   if (!c || !ar || !ex || nranks < 1) return cfdh_fail(c, CFDH_E_ARG, "bad comm callbacks");
   if (c->nccl_comm) comm_finalize(c);  // the callbacks replace an RCCL communicator
+  if (c->gp_allgather) { c->gp_allgather = false; c->pc_graph_valid = false; }  // back to the all-reduce of the padded vector
   c->cb_ar = ar; c->cb_ex = ex; c->cb_user = user;
   c->rank = rank; c->nranks = nranks;
   return global_counts(c);
@@ -135,6 +137,13 @@ int comm_allreduce_dev(cfdh_ctx *c, double *dev, int n, int op) {
   if (c->cb_ar(c->cb_user, h, n, op) != 0) return cfdh_fail(c, CFDH_E_COMM, "allreduce callback failed");
   HIPCHK(c, hipMemcpyAsync(dev, h, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));  // h is reused by the next call
+  return 0;
+}
+
+// recv[r * count + i] = send_r[i] for every rank r (in-stream)
+int comm_allgather_dev(cfdh_ctx *c, const double *send, double *recv, int count) {
+  if (!c->nccl_comm) return cfdh_fail(c, CFDH_E_COMM, "all-gather needs an RCCL communicator");
+  NCCLCHK(c, g_nccl.AllGather(send, recv, (size_t)count, NCCL_FLOAT64, (nccl_comm_t)c->nccl_comm, c->stream));
   return 0;
 }
 

@@ -206,6 +206,13 @@ struct cfdh_ctx {
   AmgHier hLg;                        // its hierarchy (identical on every rank)
   dbuf<int> gp_l2g;                   // [nvo] global id of owned vertex (internal numbering)
   dbuf<double> gp_rhs, gp_sol;        // [gp_n]
+  // RCCL runs: the owned slices travel by all-gather (half the bytes of the all-reduce of a zero-padded vector):
+  // every rank sends its owned values ordered by global id, padded to the largest part
+  bool gp_allgather = false;
+  int gp_maxcnt = 0;
+  dbuf<int> gp_send_idx;              // [nvo] local (internal) index of the k-th owned vertex in global-id order
+  dbuf<int> gp_src_idx;               // [gp_n] position of global vertex g in the gathered buffer
+  dbuf<double> gp_sendbuf, gp_recvbuf;  // [gp_maxcnt], [nranks * gp_maxcnt]
   dbuf<double> pcw;                   // [NL] scratch vector with ghost tail for the coupling products
   double *h_big = nullptr;            // pinned staging of the host-callback all-reduce
   size_t h_big_n = 0;
@@ -308,7 +315,8 @@ int k_functional(cfdh_ctx *c, int kind, int marker, double *out);
 int k_wss(cfdh_ctx *c, double *out);
 
 // ---- comm (cfdh_comm.cpp) ----------------------------------------------------------
-int comm_allreduce_dev(cfdh_ctx *c, double *dev, int n, int op);  // in-stream
+int comm_allreduce_dev(cfdh_ctx *c, double *dev, int n, int op);
+int comm_allgather_dev(cfdh_ctx *c, const double *send, double *recv, int count);  // RCCL communicators only  // in-stream
 int comm_halo(cfdh_ctx *c, double *vec);                          // fill the ghost tail of vec
 int comm_finalize(cfdh_ctx *c);
 

@@ -265,13 +265,16 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
           CHK(k_level_smooth(c, &c->Hlev, upper ? rp : c->pp0.p, c->pp1.p, c->opt.cc_smooth_degree));
           CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
         }
-        if (global_p) {
+        if (global_p && c->gp_allgather) {
+          CHK(k_gather_global(c, nvo, c->gp_send_idx.p, c->pu1.p, c->gp_sendbuf.p));  // owned values in global-id order
+        } else if (global_p) {
           CHK(v_zero(c, c->gp_n, c->gp_rhs.p));
           CHK(k_scatter_global(c, nvo, c->gp_l2g.p, c->pu1.p, c->gp_rhs.p));
         }
         return 0;
       case 2:
         if (global_p) {
+          if (c->gp_allgather) CHK(k_gather_global(c, c->gp_n, c->gp_src_idx.p, c->gp_recvbuf.p, c->gp_rhs.p));
           CHK(k_amg_vcycle(c, c->hLg, c->gp_rhs.p, c->gp_sol.p));  // the same global V-cycle on every rank
           CHK(k_gather_global(c, nvo, c->gp_l2g.p, c->gp_sol.p, c->pu2.p));
         } else {
@@ -308,7 +311,11 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
 static int pc_exchange(cfdh_ctx *c, int stage) {
   if (c->nranks <= 1 || c->opt.pc_type != 1) return 0;
   if (stage == 0) return c->opt.schur_full == 2 ? 0 : comm_halo(c, c->pcw.p);
-  if (stage == 1) return (c->gp_n > 0) ? comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0) : 0;
+  if (stage == 1) {
+    if (c->gp_n <= 0) return 0;
+    if (c->gp_allgather) return comm_allgather_dev(c, c->gp_sendbuf.p, c->gp_recvbuf.p, c->gp_maxcnt);
+    return comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0);
+  }
   if (stage == 2) return c->opt.schur_full ? comm_halo(c, c->pcw.p) : 0;
   return 0;
 }

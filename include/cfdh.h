@@ -232,12 +232,14 @@ int cfdh_comm_set_callbacks(cfdh_ctx *ctx, cfdh_allreduce_fn ar, cfdh_exchange_f
 
 /* HIP-event timing of the hot kernels on the library's stream.
  * kind 0: fused residual+Jacobian assembly, 1: monolithic SpMV, 2: tau moments,
- * 3: A00 SpMV (Chebyshev sweep), 4: scalar CSR SpMV on Sp. */
+ * 3: A00 SpMV (Chebyshev sweep, pc_type 0), 4: level-0 sweep of the pressure hierarchy,
+ * 5: level-0 sweep of the velocity hierarchy (two right-hand sides). */
 int cfdh_profile_enable(cfdh_ctx *ctx, int on);
 int cfdh_profile_get(cfdh_ctx *ctx, int kind, double *total_ms, int64_t *launches);
 int cfdh_profile_reset(cfdh_ctx *ctx);
 /* sizes for roofline accounting: 0 nv_owned, 1 nv, 2 nc, 3 vertex-graph nnz,
- * 4 Sp nnz, 5 incidences, 6 AMG levels */
+ * 4 Sp nnz, 5 incidences, 6 AMG levels, 7 assembly workgroups, 8 velocity-proxy nnz;
+ * communicator state: 9 padded part size of the pressure all-gather (0: all-reduce path), 10: RCCL attached */
 int64_t cfdh_info(const cfdh_ctx *ctx, int what);
 
 #ifdef __cplusplus

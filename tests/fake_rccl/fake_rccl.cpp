@@ -3,7 +3,7 @@
 // One MI355X is all the development box has, and RCCL refuses two ranks on one device, so the RCCL branch
 // of cfd_hemodynamic_amd/csrc/cfdh_comm.cpp (dlopen + ncclCommInitRank, the grouped ncclSend/ncclRecv halo,
 // the in-stream ncclAllReduce with its counts, offsets and enum values) could otherwise never run with more
-// than one rank before the multi-GPU node does.  This library exports the nine NCCL entry points libcfdh
+// than one rank before the multi-GPU node does.  This library exports the ten NCCL entry points libcfdh
 // binds and implements them for processes of ONE host: buffers are staged device -> shared memory -> device
 // with the semantics of the real calls (stream-ordered, p2p matched per (src, dst) in issue order,
 // all-reduce in rank order).  Selected with CFDH_RCCL_LIB=<this .so>; never loaded by the product otherwise.
@@ -143,6 +143,19 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
   }
   barrier(c);  // everybody has read before anybody stages the next call
   if (hipMemcpy(recv, acc.data(), count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return 1;
+  return 0;
+}
+
+int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t stream) {
+  Comm *c = (Comm *)comm;
+  if (dtype != 8) return 4;
+  if (count > RED_DOUBLES) return 5;
+  if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+  if (hipMemcpy(c->red + (size_t)c->rank * RED_DOUBLES, send, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  barrier(c);
+  for (int r = 0; r < c->nranks; r++)
+    if (hipMemcpy((double *)recv + (size_t)r * count, c->red + (size_t)r * RED_DOUBLES, count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return 1;
+  barrier(c);
   return 0;
 }
 

@@ -97,6 +97,7 @@ def test_rccl_failure_falls_back_to_host_exchange(tmp_path):
     ref.solve(None)
     r = _run(2, str(tmp_path / "fb.npz"), timeout=240, CFDH_TEST_BACKEND="rccl")
     assert str(r["backend"]) == "host" and "RCCL" in str(r["fallback"])
+    assert int(r["rccl_attached"]) == 0 and int(r["allgather"]) == 0
     assert np.linalg.norm(r["u"] - ref.solver.u_sol.x.array) <= 1e-9 * np.linalg.norm(ref.solver.u_sol.x.array)
 
 
@@ -116,6 +117,9 @@ def test_rccl_code_path_with_shared_memory_stand_in(tmp_path):
     for world in (2, 3):
         r = _run(world, str(tmp_path / ("rccl%d.npz" % world)), timeout=300, CFDH_TEST_BACKEND="rccl", CFDH_RCCL_LIB=fake)
         assert str(r["backend"]) == "rccl" and str(r["fallback"]) in ("", "None")
+        # the NCCL-API communicator is attached and the pressure right-hand side travels by (padded) all-gather
+        nv_global = len(u0) // 2
+        assert int(r["rccl_attached"]) == 1 and -(-nv_global // world) <= int(r["allgather"]) <= nv_global // world + 2
         assert int(r["steps"]) == ref.num_steps
         assert np.linalg.norm(r["u"] - u0) <= 1e-9 * np.linalg.norm(u0)
         assert np.linalg.norm(r["p"] - p0) <= 1e-8 * np.linalg.norm(p0)
