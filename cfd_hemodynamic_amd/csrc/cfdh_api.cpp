@@ -435,7 +435,28 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
     HIPCHK(c, c->gp_sendbuf.zero(c->stream));  // the padding beyond nv_owned stays zero
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->gp_maxcnt = maxcnt;
-    c->gp_allgather = true;
+    // known-answer pass through the gather: every rank sends the global ids of its owned vertices and must find
+    // g at position g afterwards; otherwise the all-reduce of the padded vector stays in charge
+    {
+      std::vector<double> ids((size_t)maxcnt, 0.0), back(n);
+      for (int k = 0; k < c->nvo; k++) ids[k] = (double)byg[k].first;
+      HIPCHK(c, c->gp_sendbuf.upload(ids, c->stream));
+      CHK(comm_allgather_dev(c, c->gp_sendbuf.p, c->gp_recvbuf.p, maxcnt));
+      CHK(k_gather_global(c, n, c->gp_src_idx.p, c->gp_recvbuf.p, c->gp_rhs.p));
+      HIPCHK(c, hipMemcpyAsync(back.data(), c->gp_rhs.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, c->gp_sendbuf.zero(c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      bool ok = true;
+      for (int g = 0; g < n && ok; g++) ok = back[g] == (double)g;
+      double bad = ok ? 0.0 : 1.0;  // every rank takes the same decision
+      HIPCHK(c, hipMemcpyAsync(c->red_out.p + 16, &bad, sizeof(double), hipMemcpyHostToDevice, c->stream));
+      CHK(comm_allreduce_dev(c, c->red_out.p + 16, 1, 1));
+      HIPCHK(c, hipMemcpyAsync(&bad, c->red_out.p + 16, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->gp_allgather = bad == 0.0;
+      if (!c->gp_allgather && c->rank == 0)
+        fprintf(stderr, "[cfdh] WARNING: all-gather self-check failed; the pressure right-hand side is all-reduced instead\n");
+    }
   }
   c->gp_n = n;
   c->gp_dirty = true;

@@ -139,6 +139,16 @@ class Solver(SolverBase):
         self._bc_cache = None
         self._upload_bcs()
         if self._part is not None:
+            # one known-answer exchange + reduction through the communicator before trusting it (multi-GPU
+            # RCCL cannot be rehearsed on the one-GPU development box); host-staged exchange as the safety net
+            if not getattr(self, "_comm_checked", False):
+                self._comm_checked = True
+                bad = self._comm.selfcheck(self.ctx, self.mesh)
+                if bad and self._comm.backend == "rccl":
+                    self._comm.fall_back_to_host(self.ctx, bad)
+                    bad = self._comm.selfcheck(self.ctx, self.mesh)
+                if bad:
+                    raise RuntimeError("communicator self-check failed: " + bad)
             # the pressure part of the preconditioner is solved globally (replicated) on every rank
             pnodes = np.unique(np.concatenate([bc.dofs for bc in self.bcp_d])) if self.bcp_d else np.zeros(0, np.int32)
             if not getattr(self, "_ds_terms", True):
@@ -151,16 +161,6 @@ class Solver(SolverBase):
                 open_f = ~(fixed[fv[:, 0]] & fixed[fv[:, 1]])
                 pnodes = np.unique(np.concatenate([pnodes, fv[open_f].ravel()])).astype(np.int32)
             self.ctx.set_global_pressure_space(self.mesh.x, self.mesh.cells, self._part.owned_global, pnodes)
-            # one known-answer exchange + reduction through the communicator before trusting it (multi-GPU
-            # RCCL cannot be rehearsed on the one-GPU development box); host-staged exchange as the safety net
-            if not getattr(self, "_comm_checked", False):
-                self._comm_checked = True
-                bad = self._comm.selfcheck(self.ctx, self.mesh)
-                if bad and self._comm.backend == "rccl":
-                    self._comm.fall_back_to_host(self.ctx, bad)
-                    bad = self._comm.selfcheck(self.ctx, self.mesh)
-                if bad:
-                    raise RuntimeError("communicator self-check failed: " + bad)
         # x_n = (u_prev, p_prev): initial guess of the first step (stabilized_schur.py:216-223)
         self._sync_previous()
         up, pp = self._loc_u(self._u_prev.x._array), self._loc_p(self._p_prev.x._array)
