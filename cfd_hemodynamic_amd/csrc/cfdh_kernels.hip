@@ -1170,7 +1170,18 @@ template <typename T>
 static int amg_cycle_jacobi(cfdh_ctx *c, AmgHier &H, size_t lev, const T *b, T *x, int prof) {
   AmgLevel *L = H.lev[lev];
   if (lev + 1 == H.lev.size()) {
-    hipLaunchKernelGGL((dense_mv_kernel<T>), dim3(H.coarse_n), dim3(64), 0, c->stream, H.coarse_n, H.coarse_inv.p, b, x);
+    if (H.coarse_n > 0) {
+      hipLaunchKernelGGL((dense_mv_kernel<T>), dim3(H.coarse_n), dim3(64), 0, c->stream, H.coarse_n, H.coarse_inv.p, b, x);
+    } else {
+      // near-diagonal coarsest level (coarsening stalled, cfdh_amg_setup): two damped-Jacobi sweeps
+      const int n = L->n;
+      dim3 block(TPB), gridC((unsigned)((8ll * n + TPB - 1) / TPB));
+      T *xa = (T *)L->d0.p, *r = (T *)L->r.p;
+      hipLaunchKernelGGL((jacobi_pre_kernel<T>), gridC, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p,
+                         L->wdinv.p, b, xa, r);
+      hipLaunchKernelGGL((jacobi_post_kernel<T>), gridC, block, 0, c->stream, n, L->A.rowptr.p, L->A.col.p, L->A.val.p,
+                         L->wdinv.p, b, (const T *)xa, x);
+    }
     HIPCHK(c, hipGetLastError());
     return 0;
   }
@@ -1212,9 +1223,12 @@ static int amg_cycle_jacobi(cfdh_ctx *c, AmgHier &H, size_t lev, const T *b, T *
 static int amg_cycle_cheb(cfdh_ctx *c, AmgHier &H, size_t lev, const double *b, double *x, bool prof) {
   AmgLevel *L = H.lev[lev];
   if (lev + 1 == H.lev.size()) {
-    hipLaunchKernelGGL((dense_mv_kernel<double>), dim3(H.coarse_n), dim3(64), 0, c->stream, H.coarse_n, H.coarse_inv.p, b, x);
-    HIPCHK(c, hipGetLastError());
-    return 0;
+    if (H.coarse_n > 0) {
+      hipLaunchKernelGGL((dense_mv_kernel<double>), dim3(H.coarse_n), dim3(64), 0, c->stream, H.coarse_n, H.coarse_inv.p, b, x);
+      HIPCHK(c, hipGetLastError());
+      return 0;
+    }
+    return level_cheb(c, L, b, x, true, c->opt.amg_smooth_degree > 2 ? c->opt.amg_smooth_degree : 2, false);  // near-diagonal coarsest level: smoothing only
   }
   AmgLevel *N = H.lev[lev + 1];
   const int deg = c->opt.amg_smooth_degree;

@@ -631,7 +631,24 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
     A.n = Ac.n; A.m = Ac.m;
     A.rowptr.swap(Ac.rowptr); A.col.swap(Ac.col); A.val.swap(Ac.val);
   }
-  // coarsest level: dense inverse; a singular (constant null vector) operator is
+  // coarsest level.  Coarsening can stall on a level that is still large: where the mass term dominates
+  // (rho/dt M against mu K on the aggregates) the positive mass and negative stiffness couplings cancel, no
+  // connection is strong any more and the operator is close to diagonal.  Such a level needs no coarser
+  // correction -- it is closed with two damped-Jacobi sweeps instead of a dense inverse (which would cost
+  // O(n^3) on the host for n in the ten thousands).
+  H.coarse_n = 0;
+  if (A.n > 2500) {
+    H.valid = true;
+    H.fine_nnz = A0.nnz();
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->opt.verbose) {
+      fprintf(stderr, "[cfdh] AMG hierarchy (ncol %d, smoothed coarsest level):", ncol);
+      for (AmgLevel *l : H.lev) fprintf(stderr, " (%d, nnz %d)", l->n, l->A.nnz);
+      fprintf(stderr, "\n");
+    }
+    return 0;
+  }
+  // otherwise: dense inverse; a singular (constant null vector) operator is
   // regularised with alpha * 1 1^T so that the inverse acts as a pseudo-inverse
   {
     int n = A.n;

@@ -355,3 +355,28 @@ def test_taylor_green_exact_solution_scenario(monkeypatch):
     b = TaylorGreenSimulation("stabilized_schur_bdf2", 0.002, 0.04, nx=32, quiet=True)
     b.solve(None)
     assert b.errors[-1][1] < 4e-3
+
+
+def test_stalled_coarsening_is_closed_by_smoothing_not_a_dense_inverse():
+    """When no connection is strong (here forced with amg_theta close to 1; in partitioned runs it happens on
+    mass-dominated coarse levels) the hierarchy ends on a large level.  That level must be closed with smoothing
+    sweeps: a dense inverse of a 10^4-row operator would hang the setup.  The solve then either converges or
+    reports the reference's non-convergence error -- quickly."""
+    import time
+    case = dfg_case(48)
+    assert case.nv > 2500
+    ctx = make_ctx(case)
+    o = ctx.default_options()
+    o.amg_theta, o.ksp_max_it = 0.95, 60
+    ctx.set_options(o)
+    z2, z1 = np.zeros(2 * case.nv), np.zeros(case.nv)
+    ctx.set_state(u_prev=z2, p_prev=z1, u=z2, p=z1)
+    t0 = time.time()
+    try:
+        st = ctx.solve_step()
+        assert st.reason > 0
+    except RuntimeError as e:
+        assert "Did not converge" in str(e)
+    assert time.time() - t0 < 30.0
+    assert ctx.info(6) == 1  # a one-level "hierarchy"
+    ctx.close()
