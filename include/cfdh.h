@@ -233,7 +233,8 @@ int cfdh_comm_set_callbacks(cfdh_ctx *ctx, cfdh_allreduce_fn ar, cfdh_exchange_f
 /* HIP-event timing of the hot kernels on the library's stream.
  * kind 0: fused residual+Jacobian assembly, 1: monolithic SpMV, 2: tau moments,
  * 3: A00 SpMV (Chebyshev sweep, pc_type 0), 4: level-0 sweep of the pressure hierarchy,
- * 5: level-0 sweep of the velocity hierarchy (two right-hand sides). */
+ * 5: level-0 sweep of the velocity hierarchy (two right-hand sides),
+ * 7: EMPTY event pairs recorded when profiling is switched on (the per-launch overhead of the method). */
 int cfdh_profile_enable(cfdh_ctx *ctx, int on);
 int cfdh_profile_get(cfdh_ctx *ctx, int kind, double *total_ms, int64_t *launches);
 int cfdh_profile_reset(cfdh_ctx *ctx);
