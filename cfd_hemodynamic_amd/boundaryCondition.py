@@ -44,7 +44,9 @@ class BoundaryCondition:
         bc = dirichletbc(self._f_V, dofs)
 
         def update(inner_self):
-            self._f_V.interpolate(self.f)
+            # the reference re-interpolates the whole field (:48-51); the values are read at `dofs` only,
+            # so the re-interpolation is restricted to them (identical Dirichlet data, O(boundary) work)
+            self._f_V.interpolate_at(self.f, dofs)
 
         bc.update = MethodType(update, bc)
         return bc

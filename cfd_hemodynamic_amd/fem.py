@@ -100,6 +100,19 @@ class Function:
             vals = vals.reshape(V.bs, -1)
             self.x.array[:] = vals.T.reshape(-1)
 
+    def interpolate_at(self, fn, blocks):
+        """`interpolate(fn)` restricted to the vertex blocks `blocks`: the same values there, nothing touched
+        elsewhere.  Used for Dirichlet data, which are only ever read at the constrained dofs -- re-interpolating a
+        whole 10^6-dof field before every step (boundaryCondition.py:48-51) costs ~0.5 ms per condition on the host."""
+        V = self.function_space
+        dst = self.x.array.reshape(-1, V.bs)
+        if isinstance(fn, Function):
+            dst[blocks] = fn.x.array.reshape(-1, V.bs)[blocks]
+            return
+        X = V.mesh.geometry.x.T[:, blocks]
+        vals = np.asarray(fn(X), dtype=np.float64)
+        dst[blocks] = vals.reshape(-1, 1) if V.bs == 1 else vals.reshape(V.bs, -1).T
+
     def vector_values(self):
         """[nv, bs] view."""
         return self.x._array.reshape(-1, self.function_space.bs)

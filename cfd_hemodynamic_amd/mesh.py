@@ -57,9 +57,10 @@ class _Geometry:
     def x(self):
         """[nv,3] coordinates (z=0), as DOLFINx exposes them."""
         m = self._mesh
-        out = np.zeros((m.num_vertices, 3))
-        out[:, :2] = m.x
-        return out
+        if getattr(self, "_x3", None) is None or self._x3.shape[0] != m.num_vertices:
+            self._x3 = np.zeros((m.num_vertices, 3))
+            self._x3[:, :2] = m.x
+        return self._x3
 
 
 class Mesh:
