@@ -77,6 +77,7 @@ void cfdh_destroy(cfdh_ctx *c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto &e : c->pc_graphs) for (auto &x : e.exec) if (x) (void)hipGraphExecDestroy(x);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->ev_h) (void)hipEventDestroy(c->ev_h);
   if (c->h_big) (void)hipHostFree(c->h_big);
   hipStream_t s = c->stream;
@@ -143,10 +144,20 @@ int cfdh_add_dirichlet(cfdh_ctx *c, int field, int64_t n, const int32_t *nodes, 
 }
 
 // user arrays (u [nv][2], p [nv], user numbering) -> internal vector layout
+// Host <-> device field transfers of the literal reference loop (scenario.py:306-307 copies the state through the
+// host every step): staged through one pinned buffer (pageable copies run at a fraction of the PCIe rate) and
+// permuted between the caller's numbering and the internal layout with all host threads.
+typedef std::vector<double> hvec;
+static int stage_buffer(cfdh_ctx *c, double **h) {
+  if (!c->h_stage) HIPCHK(c, hipHostMalloc((void **)&c->h_stage, sizeof(double) * (size_t)c->NL));
+  *h = c->h_stage;
+  return 0;
+}
 static void pack_vec(const cfdh_ctx *c, const double *u, const double *p, std::vector<double> &out, const std::vector<double> *keep) {
   const int nvo = c->nvo, nv = c->nv;
   out.resize((size_t)c->NL);
   if (keep) out = *keep;
+#pragma omp parallel for schedule(static) num_threads(cfdh_host_threads()) if (nv > 20000)
   for (int k = 0; k < nv; k++) {
     const int v = c->iperm[k];
     const size_t uo = k < nvo ? 2 * (size_t)k : 3 * (size_t)k, po = k < nvo ? 2 * (size_t)nvo + k : 3 * (size_t)k + 2;
@@ -156,6 +167,7 @@ static void pack_vec(const cfdh_ctx *c, const double *u, const double *p, std::v
 }
 static void unpack_vec(const cfdh_ctx *c, const std::vector<double> &in, double *u, double *p) {
   const int nvo = c->nvo, nv = c->nv;
+#pragma omp parallel for schedule(static) num_threads(cfdh_host_threads()) if (nv > 20000)
   for (int k = 0; k < nv; k++) {
     const int v = c->iperm[k];
     const size_t uo = k < nvo ? 2 * (size_t)k : 3 * (size_t)k, po = k < nvo ? 2 * (size_t)nvo + k : 3 * (size_t)k + 2;
@@ -164,13 +176,19 @@ static void unpack_vec(const cfdh_ctx *c, const std::vector<double> &in, double 
   }
 }
 static int download_vec(cfdh_ctx *c, const double *dev, std::vector<double> &h) {
+  double *st;
+  CHK(stage_buffer(c, &st));
   h.resize((size_t)c->NL);
-  HIPCHK(c, hipMemcpyAsync(h.data(), dev, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(st, dev, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(h.data(), st, sizeof(double) * h.size());
   return 0;
 }
 static int upload_vec(cfdh_ctx *c, const std::vector<double> &h, double *dev) {
-  HIPCHK(c, hipMemcpyAsync(dev, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
+  double *st;
+  CHK(stage_buffer(c, &st));
+  memcpy(st, h.data(), sizeof(double) * h.size());
+  HIPCHK(c, hipMemcpyAsync(dev, st, sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }

@@ -170,6 +170,7 @@ struct cfdh_ctx {
   // reductions
   dbuf<double> red_partial, red_out;
   double *h_pinned = nullptr;  // pinned host scratch for scalar read-back
+  double *h_stage = nullptr;   // pinned staging of whole fields (set_state / get_* of the host-copy loop), NL doubles
   double *h_pinned_dev = nullptr;  // the same buffer as the device sees it (kernels write read-back scalars into it)
   const double *mirror_src = nullptr;  // device scalars whose host-mapped copy is current (see read_scalars)
   int mirror_cnt = 0;
@@ -323,6 +324,7 @@ int comm_finalize(cfdh_ctx *c);
 // ---- solver (cfdh_solver.cpp) ------------------------------------------------------
 int cfdh_pc_update(cfdh_ctx *c, bool force_refresh);
 int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z);
+int cfdh_host_threads();  // cfdh_setup.cpp: thread count of the host loops (CFDH_HOST_THREADS, default 8)
 int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its, int *reason, double bnorm = -1.0);
 int v_norm2_pair(cfdh_ctx *c, int n, const double *x, const double *y, double *nx, double *ny);
 int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st);
