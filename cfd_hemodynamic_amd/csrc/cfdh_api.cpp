@@ -419,6 +419,30 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
   HIPCHK(c, c->gp_l2g.upload(l2g, c->stream));
   HIPCHK(c, c->gp_rhs.alloc(n)); HIPCHK(c, c->gp_sol.alloc(n));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  // global ids of all local vertices (ghost ids through one halo exchange) and the inverse map: the overlapping
+  // velocity preconditioner matches the matrix rows it receives from the owners of its ghosts by global id
+  c->h_gid.clear(); c->h_g2l.clear();
+  if (c->nranks > 1 && c->ng > 0 && c->nnbr > 0) {
+    std::vector<double> hv((size_t)c->NL, -1.0);
+    for (int k = 0; k < c->nvo; k++) hv[2 * (size_t)k] = (double)l2g[k];
+    if (!c->pcw.p) HIPCHK(c, c->pcw.alloc(c->NL));
+    HIPCHK(c, c->pcw.upload(hv, c->stream));
+    CHK(comm_halo(c, c->pcw.p));
+    HIPCHK(c, hipMemcpyAsync(hv.data(), c->pcw.p, sizeof(double) * hv.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->pcw.zero(c->stream));
+    c->h_gid.assign(c->nv, -1);
+    c->h_g2l.assign(n, -1);
+    bool ok = true;
+    for (int k = 0; k < c->nvo; k++) c->h_gid[k] = l2g[k];
+    for (int i = 0; i < c->ng; i++) {
+      const double gd = hv[3 * (size_t)c->nvo + 3 * (size_t)i];
+      if (!(gd >= 0 && gd < n)) { ok = false; break; }
+      c->h_gid[c->nvo + i] = (int)gd;
+    }
+    if (ok) for (int k = 0; k < c->nv; k++) c->h_g2l[c->h_gid[k]] = k;
+    else { c->h_gid.clear(); c->h_g2l.clear(); }
+  }
   c->gp_allgather = false;
   if (c->nranks > 1 && c->nccl_comm) {
     // gather plan.  One all-reduce of an owner map (rank+1 at the owned global ids) tells every rank who owns

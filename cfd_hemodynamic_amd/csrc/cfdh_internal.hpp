@@ -188,7 +188,7 @@ struct cfdh_ctx {
   dbuf<double> pu0, pu1, pu2, pr, pp0, pp1;  // PC work vectors
   dbuf<double> prand;                        // fixed start vector of the power iteration
   dbuf<double> cheb_coef;                    // [1/theta, (c1,c2) per step] of the A00 Chebyshev solve
-  struct PcGraph { const double *r; double *z; hipGraphExec_t exec[4]; };
+  struct PcGraph { const double *r; double *z; hipGraphExec_t exec[5]; };
   std::vector<PcGraph> pc_graphs;            // one captured preconditioner application per Krylov slot
   bool pc_graph_valid = false, capturing = false, use_graph = true;
   AmgHier hS;               // SELFP Schur matrix Sp (pc_type 0)
@@ -209,6 +209,13 @@ struct cfdh_ctx {
   dbuf<double> gp_rhs, gp_sol;        // [gp_n]
   // RCCL runs: the owned slices travel by all-gather (half the bytes of the all-reduce of a zero-padded vector):
   // every rank sends its owned values ordered by global id, padded to the largest part
+  // restricted additive Schwarz with one layer of overlap for the velocity block of a partitioned run: the local
+  // hierarchy covers owned + ghost vertices (ghost rows come from their owners), the residual is halo-exchanged
+  // before the cycle and only the owned part of the result is kept
+  bool ras = false;
+  std::vector<int> h_gid;              // [nv] global id of every local vertex (internal numbering)
+  std::vector<int> h_g2l;              // [gp_n] local internal index of a global vertex, -1 if not local
+  dbuf<double> ras_b, ras_x;           // [2 nv] extended right-hand side / solution of the velocity cycle
   bool gp_allgather = false;
   int gp_maxcnt = 0;
   dbuf<int> gp_send_idx;              // [nvo] local (internal) index of the k-th owned vertex in global-id order
@@ -290,6 +297,7 @@ int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x);
 int k_level_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, int degree);
 bool k_cc_cheb2_scale(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, const double *ml, double *y);
 int k_cc_scale(cfdh_ctx *c, int n, const double *ml, const double *z, double *y);
+int k_ext_pack(cfdh_ctx *c, const double *vec, double *out);  // [u | p | ghost triplets] -> nv contiguous (ux,uy) pairs
 int k_scatter_global(cfdh_ctx *c, int n, const int *l2g, const double *loc, double *glob);
 int k_gather_global(cfdh_ctx *c, int n, const int *l2g, const double *glob, double *loc);
 int k_cc_combine(cfdh_ctx *c, int n, double alpha, double beta, const double *t, const double *z, const double *r, const unsigned char *pbc, double *out);

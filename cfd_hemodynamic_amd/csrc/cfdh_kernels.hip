@@ -1269,6 +1269,21 @@ __global__ __launch_bounds__(TPB) void gather_global_kernel(int n, const int *__
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i < n) loc[i] = glob[l2g[i]];
 }
+// velocity part of a halo-layout vector ([u owned | p owned | (ux,uy,p) per ghost]) as nv contiguous pairs
+__global__ __launch_bounds__(TPB) void ext_pack_kernel(int nvo, int nv, const double *__restrict__ vec, double2 *__restrict__ out) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= nv) return;
+  if (i < nvo) out[i] = make_double2(vec[2 * (size_t)i], vec[2 * (size_t)i + 1]);
+  else {
+    const double *t = vec + 3 * (size_t)nvo + 3 * (size_t)(i - nvo);
+    out[i] = make_double2(t[0], t[1]);
+  }
+}
+int k_ext_pack(cfdh_ctx *c, const double *vec, double *out) {
+  hipLaunchKernelGGL(ext_pack_kernel, dim3((c->nv + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nvo, c->nv, vec, (double2 *)out);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 int k_scatter_global(cfdh_ctx *c, int n, const int *l2g, const double *loc, double *glob) {
   hipLaunchKernelGGL(scatter_global_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, l2g, loc, glob);
   HIPCHK(c, hipGetLastError());

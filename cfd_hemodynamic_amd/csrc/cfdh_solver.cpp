@@ -98,20 +98,69 @@ static int build_cc_host(cfdh_ctx *c) {
   const int nvo = c->nvo;
   const std::vector<int> &vp = c->h_vptr, &vc = c->h_vcol;
   // --- scalar proxy of A00
+  // Partitioned run with the upper-triangular factor: restricted additive Schwarz with one layer of overlap.  The
+  // local operator is the principal submatrix on owned + ghost vertices; the ghost rows are fetched from their
+  // owners (entry k of every owned row travels in round k of the ordinary halo exchange, tagged with the global
+  // column id).  With exact subdomain solves this brings the iteration count of 4-8 strips back to the
+  // single-domain one; without overlap (block Jacobi) it grows by half.
+  const bool ras = c->nranks > 1 && c->gp_n > 0 && c->opt.schur_full == 2 && (int)c->h_gid.size() == c->nv && c->ng > 0;
   {
+    const int nloc = ras ? c->nv : nvo;
     CsrHost Ah;
-    Ah.n = Ah.m = nvo;
-    Ah.rowptr.assign(nvo + 1, 0);
+    Ah.n = Ah.m = nloc;
+    Ah.rowptr.assign(nloc + 1, 0);
+    int maxlen = 0;
     for (int i = 0; i < nvo; i++) {
       for (int k = vp[i]; k < vp[i + 1]; k++) {
         const int w = vc[k];
-        if (w >= nvo) continue;
+        if (w >= nloc) continue;
         const double v = 0.5 * (a00[4 * (size_t)k] + a00[4 * (size_t)k + 3]);
         if (v == 0.0 && w != i) continue;
         Ah.col.push_back(w); Ah.val.push_back(v);
       }
       Ah.rowptr[i + 1] = (int)Ah.col.size();
+      maxlen = std::max(maxlen, Ah.rowptr[i + 1] - Ah.rowptr[i]);
     }
+    if (ras) {
+      double ml = (double)maxlen;  // rounds = longest owned row over all ranks
+      HIPCHK(c, hipMemcpyAsync(c->red_out.p + 20, &ml, sizeof(double), hipMemcpyHostToDevice, c->stream));
+      CHK(comm_allreduce_dev(c, c->red_out.p + 20, 1, 1));
+      HIPCHK(c, hipMemcpyAsync(&ml, c->red_out.p + 20, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      const int rounds = (int)ml;
+      if (!c->pcw.p) { HIPCHK(c, c->pcw.alloc(c->NL)); }
+      std::vector<std::vector<std::pair<int, double>>> grow(c->ng);
+      std::vector<double> hv((size_t)c->NL);
+      for (int k = 0; k < rounds; k++) {
+        std::fill(hv.begin(), hv.end(), -1.0);
+        for (int i = 0; i < nvo; i++) {
+          const int p = Ah.rowptr[i] + k;
+          if (p < Ah.rowptr[i + 1]) { hv[2 * (size_t)i] = (double)c->h_gid[Ah.col[p]]; hv[2 * (size_t)i + 1] = Ah.val[p]; }
+        }
+        HIPCHK(c, c->pcw.upload(hv, c->stream));
+        CHK(comm_halo(c, c->pcw.p));
+        HIPCHK(c, hipMemcpyAsync(hv.data() + 3 * (size_t)nvo, c->pcw.p + 3 * (size_t)nvo, sizeof(double) * 3 * (size_t)c->ng,
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int g = 0; g < c->ng; g++) {
+          const double gd = hv[3 * (size_t)nvo + 3 * (size_t)g];
+          if (!(gd >= 0)) continue;
+          const int loc = c->h_g2l[(int)gd];
+          if (loc >= 0) grow[g].push_back({loc, hv[3 * (size_t)nvo + 3 * (size_t)g + 1]});
+        }
+      }
+      HIPCHK(c, c->pcw.zero(c->stream));
+      for (int g = 0; g < c->ng; g++) {
+        auto &r = grow[g];
+        std::sort(r.begin(), r.end());
+        bool diag = false;
+        for (auto &e : r) { Ah.col.push_back(e.first); Ah.val.push_back(e.second); diag |= e.first == nvo + g; }
+        if (!diag) return cfdh_fail(c, CFDH_E_COMM, "ghost row %d arrived without its diagonal", g);
+        Ah.rowptr[nvo + g + 1] = (int)Ah.col.size();
+      }
+      if (!c->ras_b.p) { HIPCHK(c, c->ras_b.alloc(2 * (size_t)c->nv)); HIPCHK(c, c->ras_x.alloc(2 * (size_t)c->nv)); }
+    }
+    c->ras = ras;
     CHK(cfdh_amg_setup(c, c->hA, Ah, false, 2));
   }
   // --- pressure Laplacian hierarchy (once per Dirichlet set)
@@ -283,13 +332,22 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
         CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, upper ? rp : c->pp0.p, c->ccPbc.p, zp));
         if (multi && c->opt.schur_full) CHK(v_copy(c, nvo, zp, c->pcw.p + nu));  // z_p into the halo scratch vector
         return 0;
-      default:
+      case 3:
         if (c->opt.schur_full) {
           if (multi) CHK(k_spmv_block_ghost(c, 2, c->pcw.p, c->pu0.p, ru));  // t_u = r_u - A01 z_p (with ghosts)
           else CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));
-          CHK(k_amg_vcycle(c, c->hA, c->pu0.p, zu));
+          if (multi && c->ras) CHK(v_copy(c, nu, c->pu0.p, c->pcw.p));       // t_u into the halo scratch vector; cycle in stage 4
+          else CHK(k_amg_vcycle(c, c->hA, c->pu0.p, zu));
         } else {
           CHK(v_copy(c, nu, multi ? c->pcw.p : c->pu0.p, zu));              // block lower-triangular variant
+        }
+        return 0;
+      default:
+        if (multi && c->ras && c->opt.schur_full) {
+          // restricted additive Schwarz: cycle on owned + ghost vertices, keep the owned part
+          CHK(k_ext_pack(c, c->pcw.p, c->ras_b.p));
+          CHK(k_amg_vcycle(c, c->hA, c->ras_b.p, c->ras_x.p));
+          CHK(v_copy(c, nu, c->ras_x.p, zu));
         }
         return 0;
     }
@@ -317,6 +375,7 @@ static int pc_exchange(cfdh_ctx *c, int stage) {
     return comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0);
   }
   if (stage == 2) return c->opt.schur_full ? comm_halo(c, c->pcw.p) : 0;
+  if (stage == 3) return (c->ras && c->opt.schur_full) ? comm_halo(c, c->pcw.p) : 0;  // residual of the overlap layer
   return 0;
 }
 
@@ -330,7 +389,7 @@ int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z) {
   const bool multi = c->nranks > 1 && c->opt.pc_type == 1;
   if (multi && !c->pcw.p) { HIPCHK(c, c->pcw.alloc(c->NL)); HIPCHK(c, c->pcw.zero(c->stream)); }
   if (!graph) {
-    for (int st = 0; st < 4; st++) { CHK(pc_stage(c, r, z, st)); CHK(pc_exchange(c, st)); }
+    for (int st = 0; st < 5; st++) { CHK(pc_stage(c, r, z, st)); CHK(pc_exchange(c, st)); }
   } else {
     if (!c->pc_graph_valid) {
       for (auto &e : c->pc_graphs) for (auto &x : e.exec) if (x) (void)hipGraphExecDestroy(x);
@@ -340,15 +399,15 @@ int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z) {
     cfdh_ctx::PcGraph *pg = nullptr;
     for (auto &e : c->pc_graphs) if (e.r == r && e.z == z) { pg = &e; break; }
     if (!pg) {
-      cfdh_ctx::PcGraph ng{r, z, {nullptr, nullptr, nullptr, nullptr}};
+      cfdh_ctx::PcGraph ng{r, z, {nullptr, nullptr, nullptr, nullptr, nullptr}};
       // one rank: all four stages in one graph; partitioned: one graph per stage
-      for (int gidx = 0; gidx < (multi ? 4 : 1); gidx++) {
+      for (int gidx = 0; gidx < (multi ? 5 : 1); gidx++) {
         hipGraph_t g = nullptr;
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         c->capturing = true;
         int rc = 0;
         if (multi) rc = pc_stage(c, r, z, gidx);
-        else for (int st = 0; st < 4 && !rc; st++) rc = pc_stage(c, r, z, st);
+        else for (int st = 0; st < 5 && !rc; st++) rc = pc_stage(c, r, z, st);
         c->capturing = false;
         hipError_t e = hipStreamEndCapture(c->stream, &g);
         if (rc) return rc;
@@ -363,7 +422,7 @@ int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z) {
     if (!multi) {
       HIPCHK(c, hipGraphLaunch(pg->exec[0], c->stream));
     } else {
-      for (int st = 0; st < 4; st++) { HIPCHK(c, hipGraphLaunch(pg->exec[st], c->stream)); CHK(pc_exchange(c, st)); }
+      for (int st = 0; st < 5; st++) { HIPCHK(c, hipGraphLaunch(pg->exec[st], c->stream)); CHK(pc_exchange(c, st)); }
     }
   }
   if (c->singular) CHK(v_sub_mean(c, nvo, z + 2 * (size_t)nvo));
