@@ -113,6 +113,7 @@ def test_rccl_code_path_with_shared_memory_stand_in(tmp_path):
     tight = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
     ref = DFG1Benchmark("stabilized_schur", 0.01, 0.05, m=16, quiet=True, options=tight)
     ref.solve(None)
+    ref_krylov = sum(st.krylov_its for _, st in ref.step_stats)
     u0, p0 = ref.solver.u_sol.x.array.copy(), ref.solver.p_sol.x.array.copy()
     for world in (2, 3):
         r = _run(world, str(tmp_path / ("rccl%d.npz" % world)), timeout=300, CFDH_TEST_BACKEND="rccl", CFDH_RCCL_LIB=fake)
@@ -124,3 +125,5 @@ def test_rccl_code_path_with_shared_memory_stand_in(tmp_path):
         assert np.linalg.norm(r["u"] - u0) <= 1e-9 * np.linalg.norm(u0)
         assert np.linalg.norm(r["p"] - p0) <= 1e-8 * np.linalg.norm(p0)
         assert abs(float(r["drag"]) - ref.drag) <= 1e-8 * abs(ref.drag)
+        # overlapping velocity cycles + replicated pressure cycle: the iteration count stays close to one rank's
+        assert int(r["krylov"]) <= 1.5 * ref_krylov
