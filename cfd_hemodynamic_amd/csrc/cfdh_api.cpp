@@ -576,6 +576,8 @@ int64_t cfdh_info(const cfdh_ctx *c, int what) {
     case 8: return c->hA.fine_nnz;
     case 9: return c->gp_allgather ? c->gp_maxcnt : 0;
     case 10: return c->nccl_comm ? 1 : 0;
+    case 11: return c->dl0.on ? c->dl0.n1 : 0;
+    case 12: return c->ras ? 1 : 0;
     default: return -1;
   }
 }

@@ -82,6 +82,11 @@ struct AmgHier {
   int coarse_n = 0, ncol = 1;
   long long fine_nnz = 0;
   bool valid = false;
+  // host copies of the finest level (operator, prolongator, Jacobi weights): kept on request so that a
+  // partitioned run can cut its rows of the replicated pressure hierarchy out of them
+  bool keep_host0 = false;
+  CsrHost h_A0, h_P0;
+  std::vector<double> h_wdinv0;
   void clear() {
     for (AmgLevel *l : lev) delete l;
     lev.clear();
@@ -188,7 +193,7 @@ struct cfdh_ctx {
   dbuf<double> pu0, pu1, pu2, pr, pp0, pp1;  // PC work vectors
   dbuf<double> prand;                        // fixed start vector of the power iteration
   dbuf<double> cheb_coef;                    // [1/theta, (c1,c2) per step] of the A00 Chebyshev solve
-  struct PcGraph { const double *r; double *z; hipGraphExec_t exec[5]; };
+  struct PcGraph { const double *r; double *z; hipGraphExec_t exec[6]; };
   std::vector<PcGraph> pc_graphs;            // one captured preconditioner application per Krylov slot
   bool pc_graph_valid = false, capturing = false, use_graph = true;
   AmgHier hS;               // SELFP Schur matrix Sp (pc_type 0)
@@ -216,6 +221,16 @@ struct cfdh_ctx {
   std::vector<int> h_gid;              // [nv] global id of every local vertex (internal numbering)
   std::vector<int> h_g2l;              // [gp_n] local internal index of a global vertex, -1 if not local
   dbuf<double> ras_b, ras_x;           // [2 nv] extended right-hand side / solution of the velocity cycle
+  // distributed finest level of the replicated pressure hierarchy: every rank smooths its own rows (owned rows,
+  // owned + ghost columns), the coarse right-hand side is all-reduced and levels >= 1 stay replicated
+  struct DistL0 {
+    bool on = false;
+    int n1 = 0;
+    CsrDev A;      // owned rows x local (owned + ghost) columns
+    CsrDev P;      // local rows (owned + ghost) x coarse columns
+    CsrDev PT;     // coarse rows x owned columns (restriction of the owned residual)
+    dbuf<double> wdinv, b, xa, r, x1;
+  } dl0;
   bool gp_allgather = false;
   int gp_maxcnt = 0;
   dbuf<int> gp_send_idx;              // [nvo] local (internal) index of the k-th owned vertex in global-id order
@@ -274,7 +289,8 @@ int cfdh_fail(cfdh_ctx *c, int code, const char *fmt, ...);
 int cfdh_build_mesh(cfdh_ctx *c, int64_t nv, int64_t nvo, int64_t nc, const int32_t *cells, const double *coords,
                     int64_t nfac, const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker);
 int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A, bool singular, int ncol);
-int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol);
+int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol, std::vector<double> *w_out = nullptr);
+int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D);
 
 // ---- kernels (cfdh_kernels.hip) ----------------------------------------------------
 void prof_begin(cfdh_ctx *c, int kind);
@@ -297,6 +313,8 @@ int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x);
 int k_level_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, int degree);
 bool k_cc_cheb2_scale(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, const double *ml, double *y);
 int k_cc_scale(cfdh_ctx *c, int n, const double *ml, const double *z, double *y);
+int k_dl0_down(cfdh_ctx *c, const double *halo_vec);  // distributed level 0 of the pressure cycle: down sweep + restriction
+int k_dl0_up(cfdh_ctx *c, double *out);               // replicated coarse cycle, prolongation, post-smoothing
 int k_ext_pack(cfdh_ctx *c, const double *vec, double *out);  // [u | p | ghost triplets] -> nv contiguous (ux,uy) pairs
 int k_scatter_global(cfdh_ctx *c, int n, const int *l2g, const double *loc, double *glob);
 int k_gather_global(cfdh_ctx *c, int n, const int *l2g, const double *glob, double *loc);

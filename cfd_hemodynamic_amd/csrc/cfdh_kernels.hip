@@ -1241,6 +1241,42 @@ static int amg_cycle_cheb(cfdh_ctx *c, AmgHier &H, size_t lev, const double *b, 
   return 0;
 }
 
+// ---- distributed finest level of the replicated pressure hierarchy (cfdh_ctx::DistL0)
+// b_loc = pressure slot of a halo-layout vector on owned + ghost vertices; xa = w D^-1 b on all of them
+__global__ __launch_bounds__(TPB) void dl0_pack_kernel(int nvo, int nv, const double *__restrict__ vec, const double *__restrict__ wdinv,
+                                                       double *__restrict__ b, double *__restrict__ xa) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= nv) return;
+  const double v = i < nvo ? vec[2 * (size_t)nvo + i] : vec[3 * (size_t)nvo + 3 * (size_t)(i - nvo) + 2];
+  b[i] = v;
+  xa[i] = wdinv[i] * v;
+}
+// pre-smoothing on the owned rows and the owned part of the coarse right-hand side: lev[1].b = P_owned^T (b - A xa)
+int k_dl0_down(cfdh_ctx *c, const double *halo_vec) {
+  cfdh_ctx::DistL0 &d = c->dl0;
+  AmgLevel *N = c->hLg.lev[1];
+  const int nvo = c->nvo, nv = c->nv;
+  hipLaunchKernelGGL(dl0_pack_kernel, dim3((nv + TPB - 1) / TPB), dim3(TPB), 0, c->stream, nvo, nv, halo_vec, d.wdinv.p, d.b.p, d.xa.p);
+  dim3 block(TPB), grid((unsigned)((8ll * nvo + TPB - 1) / TPB));
+  hipLaunchKernelGGL((jacobi_pre_kernel<double>), grid, block, 0, c->stream, nvo, d.A.rowptr.p, d.A.col.p, d.A.val.p, d.wdinv.p,
+                     (const double *)d.b.p, d.xa.p, d.r.p);
+  HIPCHK(c, hipGetLastError());
+  return csr_spmv_t<double>(c, d.PT, d.r.p, N->b.p, 0, (const double *)nullptr);
+}
+// replicated coarse cycle from level 1, prolongation to owned + ghost rows, post-smoothing of the owned rows -> out
+int k_dl0_up(cfdh_ctx *c, double *out) {
+  cfdh_ctx::DistL0 &d = c->dl0;
+  AmgLevel *N = c->hLg.lev[1];
+  const int nvo = c->nvo;
+  CHK(amg_cycle_jacobi<double>(c, c->hLg, 1, (const double *)N->b.p, N->x.p, 0));
+  CHK(csr_spmv_t<double>(c, d.P, (const double *)N->x.p, d.x1.p, 3, (const double *)d.xa.p));  // x1 = xa + P x_c
+  dim3 block(TPB), grid((unsigned)((8ll * nvo + TPB - 1) / TPB));
+  hipLaunchKernelGGL((jacobi_post_kernel<double>), grid, block, 0, c->stream, nvo, d.A.rowptr.p, d.A.col.p, d.A.val.p, d.wdinv.p,
+                     (const double *)d.b.p, (const double *)d.x1.p, out);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 // x = V(H) b; for ncol == 2 b and x hold interleaved pairs
 int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x) {
   if (!H.valid || H.lev.empty()) return cfdh_fail(c, CFDH_E_STATE, "AMG hierarchy not built");

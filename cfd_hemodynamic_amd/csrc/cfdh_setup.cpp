@@ -542,7 +542,9 @@ static bool dense_inverse(std::vector<double> &a, int n) {
 }
 
 // device copy of one operator with its Jacobi diagonal, spectral bound and work vectors
-int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol) {
+int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D) { return upload_csr(c, H, D); }
+
+int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol, std::vector<double> *w_out) {
   L.n = A.n;
   std::vector<double> dinv(A.n, 1.0);
   for (int i = 0; i < A.n; i++)
@@ -563,6 +565,7 @@ int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, i
     }
     HIPCHK(c, L.wdinv.upload(w, c->stream));
     CHK(upload_csr(c, A, L.A, &w));
+    if (w_out) *w_out = w;
   }
   const size_t nn = (size_t)A.n * ncol;
   HIPCHK(c, L.x.alloc(nn)); HIPCHK(c, L.b.alloc(nn)); HIPCHK(c, L.r.alloc(nn));
@@ -579,7 +582,9 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
   for (;;) {
     AmgLevel *L = new AmgLevel();
     H.lev.push_back(L);
-    CHK(cfdh_level_setup(c, *L, A, o.amg_smooth_ratio, ncol));
+    const bool keep0 = H.keep_host0 && H.lev.size() == 1;
+    CHK(cfdh_level_setup(c, *L, A, o.amg_smooth_ratio, ncol, keep0 ? &H.h_wdinv0 : nullptr));
+    if (keep0) H.h_A0 = A;
     const double lm = L->lmax / 1.1;
     if (A.n <= o.amg_max_coarse || (int)H.lev.size() >= maxlev) break;
     std::vector<int> agg;
@@ -627,6 +632,7 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
     spgemm_host(A, P, AP);
     spgemm_host(R, AP, Ac);
     CHK(upload_csr(c, P, L->P));
+    if (H.keep_host0 && H.lev.size() == 1) H.h_P0 = P;
     CHK(upload_csr(c, R, L->R));
     A.n = Ac.n; A.m = Ac.m;
     A.rowptr.swap(Ac.rowptr); A.col.swap(Ac.col); A.val.swap(Ac.val);

@@ -203,8 +203,65 @@ static int build_cc_host(cfdh_ctx *c) {
     HIPCHK(c, c->ccPbc.upload(pbc, c->stream));
   }
   if (c->gp_n > 0 && (c->gp_dirty || !c->hLg.valid)) {
+    const bool dist = c->nranks > 1 && (int)c->h_gid.size() == c->nv && c->ng > 0;
+    c->hLg.keep_host0 = dist;
     CHK(cfdh_amg_setup(c, c->hLg, c->gp_L, c->gp_singular, 1));
     c->gp_dirty = false;
+    // Distributed finest level: this rank's rows of the global level-0 operator / prolongator (the hierarchy is
+    // geometry-only and identical on all ranks, so no exchange is needed to build them).  The cycle is then the
+    // SAME arithmetic as the replicated one -- Jacobi sweeps are row-local once the ghost values are there.
+    cfdh_ctx::DistL0 &d = c->dl0;
+    d.on = false;
+    if (dist && c->hLg.lev.size() >= 2) {
+      const CsrHost &A0 = c->hLg.h_A0, &P0 = c->hLg.h_P0;
+      const std::vector<double> &w0 = c->hLg.h_wdinv0;
+      const int nv = c->nv, n1 = c->hLg.lev[1]->n;
+      bool ok = (int)w0.size() == c->gp_n && A0.n == c->gp_n && P0.n == c->gp_n && P0.m == n1;
+      CsrHost Al, Pl, Pt;
+      Al.n = nvo; Al.m = nv; Al.rowptr.assign(nvo + 1, 0);
+      for (int i = 0; i < nvo && ok; i++) {
+        const int g = c->h_gid[i];
+        for (int k = A0.rowptr[g]; k < A0.rowptr[g + 1]; k++) {
+          const int loc = c->h_g2l[A0.col[k]];
+          if (loc < 0) { ok = false; break; }  // a neighbour of an owned vertex is always local (one-cell overlap)
+          Al.col.push_back(loc); Al.val.push_back(A0.val[k]);
+        }
+        Al.rowptr[i + 1] = (int)Al.col.size();
+      }
+      Pl.n = nv; Pl.m = n1; Pl.rowptr.assign(nv + 1, 0);
+      std::vector<int> cnt(n1 + 1, 0);
+      for (int i = 0; i < nv && ok; i++) {
+        const int g = c->h_gid[i];
+        for (int k = P0.rowptr[g]; k < P0.rowptr[g + 1]; k++) {
+          Pl.col.push_back(P0.col[k]); Pl.val.push_back(P0.val[k]);
+          if (i < nvo) cnt[P0.col[k] + 1]++;
+        }
+        Pl.rowptr[i + 1] = (int)Pl.col.size();
+      }
+      if (ok) {
+        Pt.n = n1; Pt.m = nvo; Pt.rowptr.assign(n1 + 1, 0);
+        for (int I = 0; I < n1; I++) Pt.rowptr[I + 1] = Pt.rowptr[I] + cnt[I + 1];
+        Pt.col.resize(Pt.rowptr[n1]); Pt.val.resize(Pt.rowptr[n1]);
+        std::vector<int> fill(Pt.rowptr.begin(), Pt.rowptr.end() - 1);
+        for (int i = 0; i < nvo; i++)  // ascending owned index within every coarse row: fixed summation order
+          for (int k = Pl.rowptr[i]; k < Pl.rowptr[i + 1]; k++) { const int q = fill[Pl.col[k]]++; Pt.col[q] = i; Pt.val[q] = Pl.val[k]; }
+        std::vector<double> wl(nv);
+        for (int i = 0; i < nv; i++) wl[i] = w0[c->h_gid[i]];
+        CHK(cfdh_upload_csr(c, Al, d.A)); CHK(cfdh_upload_csr(c, Pl, d.P)); CHK(cfdh_upload_csr(c, Pt, d.PT));
+        HIPCHK(c, d.wdinv.upload(wl, c->stream));
+        HIPCHK(c, d.b.alloc(nv)); HIPCHK(c, d.xa.alloc(nv)); HIPCHK(c, d.r.alloc(nvo)); HIPCHK(c, d.x1.alloc(nv));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        d.n1 = n1;
+        d.on = true;
+      }
+      double bad = d.on ? 0.0 : 1.0;  // all ranks or none
+      HIPCHK(c, hipMemcpyAsync(c->red_out.p + 21, &bad, sizeof(double), hipMemcpyHostToDevice, c->stream));
+      CHK(comm_allreduce_dev(c, c->red_out.p + 21, 1, 1));
+      HIPCHK(c, hipMemcpyAsync(&bad, c->red_out.p + 21, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      d.on = bad == 0.0;
+      c->hLg.h_A0 = CsrHost(); c->hLg.h_P0 = CsrHost(); c->hLg.h_wdinv0.clear();
+    }
   }
   // --- H
   c->cc_alpha = c->rho * c->ts_a[0] / (c->ts_theta * c->dt);  // = 2 rho/dt for the midpoint scheme
@@ -300,7 +357,12 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
   const bool global_p = c->gp_n > 0 && multi;
   if (c->opt.pc_type == 1) {
     const bool upper = c->opt.schur_full == 2;  // block upper-triangular: z_p = S^-1 r_p, z_u = A^-1 (r_u - A01 z_p)
-    switch (stage) {
+    // logical stages: 0 first velocity cycle, 1 H solve, 2 pressure cycle, 3 coupling product, 4 overlapping velocity
+    // cycle; a partitioned run with the distributed pressure level inserts the down sweep (10) after the H solve
+    const bool dist = global_p && c->dl0.on;
+    int ls = stage;
+    if (dist) ls = stage <= 1 ? stage : (stage == 2 ? 10 : stage - 1);
+    switch (ls) {
       case 0:
         if (upper) return 0;
         // in a partitioned run y_u lands in the halo scratch vector so that its ghosts can be refreshed
@@ -314,15 +376,21 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
           CHK(k_level_smooth(c, &c->Hlev, upper ? rp : c->pp0.p, c->pp1.p, c->opt.cc_smooth_degree));
           CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
         }
-        if (global_p && c->gp_allgather) {
+        if (dist) {
+          CHK(v_copy(c, nvo, c->pu1.p, c->pcw.p + nu));  // right-hand side into the pressure slot of the halo scratch vector
+        } else if (global_p && c->gp_allgather) {
           CHK(k_gather_global(c, nvo, c->gp_send_idx.p, c->pu1.p, c->gp_sendbuf.p));  // owned values in global-id order
         } else if (global_p) {
           CHK(v_zero(c, c->gp_n, c->gp_rhs.p));
           CHK(k_scatter_global(c, nvo, c->gp_l2g.p, c->pu1.p, c->gp_rhs.p));
         }
         return 0;
+      case 10:
+        return k_dl0_down(c, c->pcw.p);  // pre-smoothing of the owned rows, owned part of the coarse right-hand side
       case 2:
-        if (global_p) {
+        if (dist) {
+          CHK(k_dl0_up(c, c->pu2.p));    // replicated coarse cycle, prolongation, post-smoothing of the owned rows
+        } else if (global_p) {
           if (c->gp_allgather) CHK(k_gather_global(c, c->gp_n, c->gp_src_idx.p, c->gp_recvbuf.p, c->gp_rhs.p));
           CHK(k_amg_vcycle(c, c->hLg, c->gp_rhs.p, c->gp_sol.p));  // the same global V-cycle on every rank
           CHK(k_gather_global(c, nvo, c->gp_l2g.p, c->gp_sol.p, c->pu2.p));
@@ -368,15 +436,21 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
 // exchange that follows stage `stage` in a partitioned run
 static int pc_exchange(cfdh_ctx *c, int stage) {
   if (c->nranks <= 1 || c->opt.pc_type != 1) return 0;
-  if (stage == 0) return c->opt.schur_full == 2 ? 0 : comm_halo(c, c->pcw.p);
-  if (stage == 1) {
-    if (c->gp_n <= 0) return 0;
-    if (c->gp_allgather) return comm_allgather_dev(c, c->gp_sendbuf.p, c->gp_recvbuf.p, c->gp_maxcnt);
-    return comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0);
+  const bool dist = c->gp_n > 0 && c->dl0.on;
+  int ls = stage;
+  if (dist) ls = stage <= 1 ? stage : (stage == 2 ? 10 : stage - 1);
+  switch (ls) {
+    case 0: return c->opt.schur_full == 2 ? 0 : comm_halo(c, c->pcw.p);
+    case 1:
+      if (c->gp_n <= 0) return 0;
+      if (dist) return comm_halo(c, c->pcw.p);  // right-hand side of the pressure cycle on the ghost layer
+      if (c->gp_allgather) return comm_allgather_dev(c, c->gp_sendbuf.p, c->gp_recvbuf.p, c->gp_maxcnt);
+      return comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0);
+    case 10: return comm_allreduce_dev(c, c->hLg.lev[1]->b.p, c->dl0.n1, 0);  // coarse right-hand side of the replicated levels
+    case 2: return c->opt.schur_full ? comm_halo(c, c->pcw.p) : 0;
+    case 3: return (c->ras && c->opt.schur_full) ? comm_halo(c, c->pcw.p) : 0;  // residual of the overlap layer
+    default: return 0;
   }
-  if (stage == 2) return c->opt.schur_full ? comm_halo(c, c->pcw.p) : 0;
-  if (stage == 3) return (c->ras && c->opt.schur_full) ? comm_halo(c, c->pcw.p) : 0;  // residual of the overlap layer
-  return 0;
 }
 
 // z = P^-1 r.  The kernels of one application have fixed shapes, so every stage is captured into a
@@ -389,7 +463,7 @@ int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z) {
   const bool multi = c->nranks > 1 && c->opt.pc_type == 1;
   if (multi && !c->pcw.p) { HIPCHK(c, c->pcw.alloc(c->NL)); HIPCHK(c, c->pcw.zero(c->stream)); }
   if (!graph) {
-    for (int st = 0; st < 5; st++) { CHK(pc_stage(c, r, z, st)); CHK(pc_exchange(c, st)); }
+    for (int st = 0; st < 6; st++) { CHK(pc_stage(c, r, z, st)); CHK(pc_exchange(c, st)); }
   } else {
     if (!c->pc_graph_valid) {
       for (auto &e : c->pc_graphs) for (auto &x : e.exec) if (x) (void)hipGraphExecDestroy(x);
@@ -399,15 +473,15 @@ int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z) {
     cfdh_ctx::PcGraph *pg = nullptr;
     for (auto &e : c->pc_graphs) if (e.r == r && e.z == z) { pg = &e; break; }
     if (!pg) {
-      cfdh_ctx::PcGraph ng{r, z, {nullptr, nullptr, nullptr, nullptr, nullptr}};
+      cfdh_ctx::PcGraph ng{r, z, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
       // one rank: all four stages in one graph; partitioned: one graph per stage
-      for (int gidx = 0; gidx < (multi ? 5 : 1); gidx++) {
+      for (int gidx = 0; gidx < (multi ? 6 : 1); gidx++) {
         hipGraph_t g = nullptr;
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         c->capturing = true;
         int rc = 0;
         if (multi) rc = pc_stage(c, r, z, gidx);
-        else for (int st = 0; st < 5 && !rc; st++) rc = pc_stage(c, r, z, st);
+        else for (int st = 0; st < 6 && !rc; st++) rc = pc_stage(c, r, z, st);
         c->capturing = false;
         hipError_t e = hipStreamEndCapture(c->stream, &g);
         if (rc) return rc;
@@ -422,7 +496,7 @@ int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z) {
     if (!multi) {
       HIPCHK(c, hipGraphLaunch(pg->exec[0], c->stream));
     } else {
-      for (int st = 0; st < 5; st++) { HIPCHK(c, hipGraphLaunch(pg->exec[st], c->stream)); CHK(pc_exchange(c, st)); }
+      for (int st = 0; st < 6; st++) { HIPCHK(c, hipGraphLaunch(pg->exec[st], c->stream)); CHK(pc_exchange(c, st)); }
     }
   }
   if (c->singular) CHK(v_sub_mean(c, nvo, z + 2 * (size_t)nvo));

@@ -240,7 +240,9 @@ int cfdh_profile_get(cfdh_ctx *ctx, int kind, double *total_ms, int64_t *launche
 int cfdh_profile_reset(cfdh_ctx *ctx);
 /* sizes for roofline accounting: 0 nv_owned, 1 nv, 2 nc, 3 vertex-graph nnz,
  * 4 Sp nnz, 5 incidences, 6 AMG levels, 7 assembly workgroups, 8 velocity-proxy nnz;
- * communicator state: 9 padded part size of the pressure all-gather (0: all-reduce path), 10: RCCL attached */
+ * communicator state: 9 padded part size of the pressure all-gather (0: all-reduce path), 10: RCCL attached,
+ * 11: size of the replicated coarse level below the distributed finest pressure level (0: fully replicated cycle),
+ * 12: overlapping (restricted additive Schwarz) velocity cycle in use */
 int64_t cfdh_info(const cfdh_ctx *ctx, int what);
 
 #ifdef __cplusplus

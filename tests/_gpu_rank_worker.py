@@ -31,6 +31,7 @@ def main():
         np.savez(out, u=u, p=p, drag=sc.drag, lift=sc.lift, norm_v=sc.norm_v, norm_p=sc.norm_p, steps=sc.num_steps,
                  krylov=sum(s.krylov_its for _, s in sc.step_stats), backend=comm.backend,
                  allgather=sc.solver.ctx.info(9), rccl_attached=sc.solver.ctx.info(10),
+                 dist_coarse=sc.solver.ctx.info(11), ras=sc.solver.ctx.info(12),
                  fallback=str(getattr(comm, "fallback_reason", "")))
     dist.barrier()
     dist.destroy_process_group()

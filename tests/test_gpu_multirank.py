@@ -125,5 +125,7 @@ def test_rccl_code_path_with_shared_memory_stand_in(tmp_path):
         assert np.linalg.norm(r["u"] - u0) <= 1e-9 * np.linalg.norm(u0)
         assert np.linalg.norm(r["p"] - p0) <= 1e-8 * np.linalg.norm(p0)
         assert abs(float(r["drag"]) - ref.drag) <= 1e-8 * abs(ref.drag)
-        # overlapping velocity cycles + replicated pressure cycle: the iteration count stays close to one rank's
+        # overlapping velocity cycle; pressure cycle with the finest level distributed and the coarse levels replicated
+        assert int(r["ras"]) == 1 and int(r["dist_coarse"]) > 0
+        # ... so the iteration count stays close to one rank's
         assert int(r["krylov"]) <= 1.5 * ref_krylov
