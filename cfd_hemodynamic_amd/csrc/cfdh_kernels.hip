@@ -1554,6 +1554,9 @@ __global__ __launch_bounds__(TPB) void multidot_kernel(int n, const double *__re
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(TPB) void mirror_copy_kernel(int n, const double *__restrict__ src, double *__restrict__ dst) {
+  for (int i = threadIdx.x; i < n; i += TPB) dst[i] = src[i];
+}
 // h_dev[0..nvec) = V^T w (and h_dev[nvec] = w.w when with_ww), reduced over all ranks
 int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror) {
   const int nb = MD_NB, nout = nvec + (with_ww ? 1 : 0);
@@ -1564,7 +1567,12 @@ int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const doub
   double *mir = (mirror && c->nranks <= 1) ? c->h_pinned_dev : nullptr;
   hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(nout), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, h_dev, mir);
   HIPCHK(c, hipGetLastError());
-  return comm_allreduce_dev(c, h_dev, nout, 0);
+  CHK(comm_allreduce_dev(c, h_dev, nout, 0));
+  if (mirror && c->nranks > 1) {  // partitioned: publish the REDUCED coefficients the same way (behind the all-reduce)
+    hipLaunchKernelGGL(mirror_copy_kernel, dim3(1), dim3(TPB), 0, c->stream, nout, (const double *)h_dev, c->h_pinned_dev);
+    HIPCHK(c, hipGetLastError());
+  }
+  return 0;
 }
 __global__ __launch_bounds__(TPB) void scale_to_kernel(int n, double a, const double *__restrict__ x, double *__restrict__ y) {
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) y[i] = a * x[i];

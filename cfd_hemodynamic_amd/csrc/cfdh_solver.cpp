@@ -567,17 +567,11 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       // pass only when cancellation demands it (|w'|^2 < 1e-5 |w|^2, judged from
       // |w'|^2 = |w|^2 - |h|^2): h = [V^T w ; w.w] comes from ONE fused multi-dot
       CHK(v_multidot(c, n, V, (int)ld, j + 1, w, hd, true, true));
-      if (c->nranks <= 1) {
-        // the final reduction wrote h into the host-mapped scratch: wait for THAT only, the update of w
-        // below overlaps with the host's Hessenberg bookkeeping and the next launches
-        HIPCHK(c, hipEventRecord(c->ev_h, c->stream));
-        CHK(v_multiaxpy(c, n, V, (int)ld, j + 1, hd, w));
-        HIPCHK(c, hipEventSynchronize(c->ev_h));
-      } else {
-        CHK(v_multiaxpy(c, n, V, (int)ld, j + 1, hd, w));
-        HIPCHK(c, hipMemcpyAsync(c->h_pinned, hd, sizeof(double) * (j + 2), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-      }
+      // h (all-reduced in a partitioned run) sits in the host-mapped scratch: wait for THAT only, the update of w
+      // below overlaps with the host's Hessenberg bookkeeping and the next launches
+      HIPCHK(c, hipEventRecord(c->ev_h, c->stream));
+      CHK(v_multiaxpy(c, n, V, (int)ld, j + 1, hd, w));
+      HIPCHK(c, hipEventSynchronize(c->ev_h));
       double ww = c->h_pinned[j + 1], hh2 = 0.0;
       for (int i = 0; i <= j; i++) { hh[i] = c->h_pinned[i]; hh2 += hh[i] * hh[i]; }
       double nrm2 = ww - hh2;
