@@ -1425,6 +1425,20 @@ static double *scalar_mirror(cfdh_ctx *c, const double *out_dev, int cnt) {
   c->mirror_src = out_dev; c->mirror_cnt = cnt;
   return c->h_pinned_dev + CFDH_MIRROR_OFF;
 }
+__global__ __launch_bounds__(TPB) void mirror_copy_kernel(int n, const double *__restrict__ src, double *__restrict__ dst) {
+  for (int i = threadIdx.x; i < n; i += TPB) dst[i] = src[i];
+}
+// all-reduce of n freshly reduced scalars; in a partitioned run the REDUCED values are then published to the
+// host-mapped scratch by a one-block kernel behind the collective (one rank: the reduction kernel did it already)
+static int finish_scalars(cfdh_ctx *c, double *out_dev, int n, int op) {
+  CHK(comm_allreduce_dev(c, out_dev, n, op));
+  if (c->nranks > 1 && n <= 64) {
+    hipLaunchKernelGGL(mirror_copy_kernel, dim3(1), dim3(TPB), 0, c->stream, n, (const double *)out_dev, c->h_pinned_dev + CFDH_MIRROR_OFF);
+    HIPCHK(c, hipGetLastError());
+    c->mirror_src = out_dev; c->mirror_cnt = n;
+  }
+  return 0;
+}
 static int read_scalars(cfdh_ctx *c, const double *dev, int n, double *host) {
   if (c->mirror_src == dev && n <= c->mirror_cnt) {
     c->mirror_src = nullptr;  // one shot
@@ -1450,7 +1464,7 @@ static int reduce_dev(cfdh_ctx *c, int op, int n, const double *x, const double 
                        scalar_mirror(c, out_dev, 1));
   }
   HIPCHK(c, hipGetLastError());
-  return comm_allreduce_dev(c, out_dev, 1, op);
+  return finish_scalars(c, out_dev, 1, op);
 }
 
 int v_dot(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host) {
@@ -1471,7 +1485,7 @@ int v_norm2_pair(cfdh_ctx *c, int n, const double *x, const double *y, double *n
   hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(2), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p,
                      scalar_mirror(c, c->red_out.p, 2));
   HIPCHK(c, hipGetLastError());
-  CHK(comm_allreduce_dev(c, c->red_out.p, 2, 0));
+  CHK(finish_scalars(c, c->red_out.p, 2, 0));
   double v[2];
   CHK(read_scalars(c, c->red_out.p, 2, v));
   *nx = sqrt(v[0]); *ny = sqrt(v[1]);
@@ -1553,9 +1567,6 @@ __global__ __launch_bounds__(TPB) void multidot_kernel(int n, const double *__re
           (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
     __syncthreads();
   }
-}
-__global__ __launch_bounds__(TPB) void mirror_copy_kernel(int n, const double *__restrict__ src, double *__restrict__ dst) {
-  for (int i = threadIdx.x; i < n; i += TPB) dst[i] = src[i];
 }
 // h_dev[0..nvec) = V^T w (and h_dev[nvec] = w.w when with_ww), reduced over all ranks
 int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror) {
@@ -1644,7 +1655,7 @@ int k_nullspace_test(cfdh_ctx *c, double *nrm) {
   hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p,
                      scalar_mirror(c, c->red_out.p, 1));
   HIPCHK(c, hipGetLastError());
-  CHK(comm_allreduce_dev(c, c->red_out.p, 1, 0));
+  CHK(finish_scalars(c, c->red_out.p, 1, 0));
   double s;
   CHK(read_scalars(c, c->red_out.p, 1, &s));
   *nrm = sqrt(s);
@@ -1798,7 +1809,7 @@ int k_functional(cfdh_ctx *c, int kind, int marker, double *out) {
   hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(2), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p,
                      scalar_mirror(c, c->red_out.p, 2));
   HIPCHK(c, hipGetLastError());
-  CHK(comm_allreduce_dev(c, c->red_out.p, 2, 0));
+  CHK(finish_scalars(c, c->red_out.p, 2, 0));
   double v[2];
   CHK(read_scalars(c, c->red_out.p, 2, v));
   if (kind == 0) *out = v[0];
