@@ -290,7 +290,7 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv, int64_t nvo, int64_t nc, const int3
                     int64_t nfac, const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker);
 int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A, bool singular, int ncol);
 int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol, std::vector<double> *w_out = nullptr);
-int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D);
+int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<double> *colw = nullptr);
 
 // ---- kernels (cfdh_kernels.hip) ----------------------------------------------------
 void prof_begin(cfdh_ctx *c, int kind);

@@ -1257,9 +1257,13 @@ int k_dl0_down(cfdh_ctx *c, const double *halo_vec) {
   AmgLevel *N = c->hLg.lev[1];
   const int nvo = c->nvo, nv = c->nv;
   hipLaunchKernelGGL(dl0_pack_kernel, dim3((nv + TPB - 1) / TPB), dim3(TPB), 0, c->stream, nvo, nv, halo_vec, d.wdinv.p, d.b.p, d.xa.p);
-  dim3 block(TPB), grid((unsigned)((8ll * nvo + TPB - 1) / TPB));
-  hipLaunchKernelGGL((jacobi_pre_kernel<double>), grid, block, 0, c->stream, nvo, d.A.rowptr.p, d.A.col.p, d.A.val.p, d.wdinv.p,
-                     (const double *)d.b.p, d.xa.p, d.r.p);
+  dim3 block(TPB), grid((unsigned)((8ll * nvo + TPB - 1) / TPB)), gridS((unsigned)((nvo + TPB - 1) / TPB));
+  if (d.A.nnz <= 12ll * nvo && nvo >= 16384)  // short regular rows: SELL-64 (as the replicated level 0 would use)
+    hipLaunchKernelGGL((sell_jacobi_pre_kernel<double>), gridS, block, 0, c->stream, nvo, d.A.sptr.p, d.A.scol.p, d.A.svalw.p,
+                       d.wdinv.p, (const double *)d.b.p, d.xa.p, d.r.p);
+  else
+    hipLaunchKernelGGL((jacobi_pre_kernel<double>), grid, block, 0, c->stream, nvo, d.A.rowptr.p, d.A.col.p, d.A.val.p, d.wdinv.p,
+                       (const double *)d.b.p, d.xa.p, d.r.p);
   HIPCHK(c, hipGetLastError());
   return csr_spmv_t<double>(c, d.PT, d.r.p, N->b.p, 0, (const double *)nullptr);
 }
@@ -1269,10 +1273,18 @@ int k_dl0_up(cfdh_ctx *c, double *out) {
   AmgLevel *N = c->hLg.lev[1];
   const int nvo = c->nvo;
   CHK(amg_cycle_jacobi<double>(c, c->hLg, 1, (const double *)N->b.p, N->x.p, 0));
-  CHK(csr_spmv_t<double>(c, d.P, (const double *)N->x.p, d.x1.p, 3, (const double *)d.xa.p));  // x1 = xa + P x_c
-  dim3 block(TPB), grid((unsigned)((8ll * nvo + TPB - 1) / TPB));
-  hipLaunchKernelGGL((jacobi_post_kernel<double>), grid, block, 0, c->stream, nvo, d.A.rowptr.p, d.A.col.p, d.A.val.p, d.wdinv.p,
-                     (const double *)d.b.p, (const double *)d.x1.p, out);
+  if (d.P.nnz <= 12ll * c->nv && c->nv >= 16384)
+    hipLaunchKernelGGL((sell_spmv_kernel<3, double>), dim3((unsigned)((c->nv + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, c->nv,
+                       d.P.sptr.p, d.P.scol.p, d.P.sval.p, (const double *)N->x.p, d.x1.p, (const double *)d.xa.p);
+  else
+    CHK(csr_spmv_t<double>(c, d.P, (const double *)N->x.p, d.x1.p, 3, (const double *)d.xa.p));  // x1 = xa + P x_c
+  dim3 block(TPB), grid((unsigned)((8ll * nvo + TPB - 1) / TPB)), gridS((unsigned)((nvo + TPB - 1) / TPB));
+  if (d.A.nnz <= 12ll * nvo && nvo >= 16384)
+    hipLaunchKernelGGL((sell_jacobi_post_kernel<double>), gridS, block, 0, c->stream, nvo, d.A.sptr.p, d.A.scol.p, d.A.sval.p,
+                       d.wdinv.p, (const double *)d.b.p, (const double *)d.x1.p, out);
+  else
+    hipLaunchKernelGGL((jacobi_post_kernel<double>), grid, block, 0, c->stream, nvo, d.A.rowptr.p, d.A.col.p, d.A.val.p, d.wdinv.p,
+                       (const double *)d.b.p, (const double *)d.x1.p, out);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

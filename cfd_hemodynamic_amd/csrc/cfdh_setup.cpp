@@ -542,7 +542,7 @@ static bool dense_inverse(std::vector<double> &a, int n) {
 }
 
 // device copy of one operator with its Jacobi diagonal, spectral bound and work vectors
-int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D) { return upload_csr(c, H, D); }
+int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<double> *colw) { return upload_csr(c, H, D, colw); }
 
 int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol, std::vector<double> *w_out) {
   L.n = A.n;

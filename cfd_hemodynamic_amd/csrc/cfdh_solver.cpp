@@ -247,7 +247,7 @@ static int build_cc_host(cfdh_ctx *c) {
           for (int k = Pl.rowptr[i]; k < Pl.rowptr[i + 1]; k++) { const int q = fill[Pl.col[k]]++; Pt.col[q] = i; Pt.val[q] = Pl.val[k]; }
         std::vector<double> wl(nv);
         for (int i = 0; i < nv; i++) wl[i] = w0[c->h_gid[i]];
-        CHK(cfdh_upload_csr(c, Al, d.A)); CHK(cfdh_upload_csr(c, Pl, d.P)); CHK(cfdh_upload_csr(c, Pt, d.PT));
+        CHK(cfdh_upload_csr(c, Al, d.A, &wl)); CHK(cfdh_upload_csr(c, Pl, d.P)); CHK(cfdh_upload_csr(c, Pt, d.PT));
         HIPCHK(c, d.wdinv.upload(wl, c->stream));
         HIPCHK(c, d.b.alloc(nv)); HIPCHK(c, d.xa.alloc(nv)); HIPCHK(c, d.r.alloc(nvo)); HIPCHK(c, d.x1.alloc(nv));
         HIPCHK(c, hipStreamSynchronize(c->stream));
