@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--m", type=int, default=200, help="DFG mesh parameter (m=200: 336,474 vertices, 1,009,422 DOF)")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--prof-steps", type=int, default=2, help="extra steps with HIP-event kernel timing (after the timed region)")
-    ap.add_argument("--host-loop-steps", type=int, default=5, help="extra steps with the reference's host-copy loop (PCIe-inclusive rate)")
+    ap.add_argument("--host-loop-steps", type=int, default=10, help="extra steps with the reference's host-copy loop (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "host"])
     ap.add_argument("--verbose", type=int, default=0)
