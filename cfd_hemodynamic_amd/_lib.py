@@ -41,7 +41,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp)
 
 # every symbol include/cfdh.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "cfdh_create", "cfdh_destroy", "cfdh_last_error", "cfdh_abi_version", "cfdh_set_params", "cfdh_default_options",
+    "cfdh_create", "cfdh_set_facet_markers", "cfdh_destroy", "cfdh_last_error", "cfdh_abi_version", "cfdh_set_params", "cfdh_default_options",
     "cfdh_set_options", "cfdh_clear_dirichlet", "cfdh_add_dirichlet", "cfdh_set_state", "cfdh_get_solution",
     "cfdh_get_previous", "cfdh_get_residual", "cfdh_advance", "cfdh_set_time_scheme", "cfdh_set_previous2", "cfdh_get_previous2",
     "cfdh_shift_history", "cfdh_set_boundary_terms", "cfdh_assemble", "cfdh_get_csr", "cfdh_spmv", "cfdh_solve_step",
@@ -76,6 +76,7 @@ def lib():
     L = C.CDLL(_SO)
     vp = C.c_void_p
     L.cfdh_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, ip, dp, C.c_int64, ip, ip, ip]
+    L.cfdh_set_facet_markers.argtypes = [vp, C.c_int64, ip]
     L.cfdh_destroy.argtypes = [vp]
     L.cfdh_destroy.restype = None
     L.cfdh_last_error.argtypes = [vp]
@@ -225,6 +226,11 @@ class Context:
 
     def set_time_scheme(self, theta, a0, a1, a2):
         self._chk(self.L.cfdh_set_time_scheme(self.h, float(theta), float(a0), float(a1), float(a2)))
+
+    def set_facet_markers(self, markers):
+        """Markers of the exterior facets in the order given to the constructor (Solver.setup's facet_tags)."""
+        m = np.ascontiguousarray(markers, dtype=np.int32)
+        self._chk(self.L.cfdh_set_facet_markers(self.h, len(m), _ip(m)))
 
     def set_boundary_terms(self, ds_terms=True, backflow_marker=-1, beta=0.0):
         self._chk(self.L.cfdh_set_boundary_terms(self.h, int(bool(ds_terms)), int(backflow_marker), float(beta)))

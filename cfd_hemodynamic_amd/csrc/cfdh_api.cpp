@@ -102,7 +102,8 @@ int cfdh_set_options(cfdh_ctx *c, const cfdh_options *o) {
       !(o->amg_smooth_ratio > 1) || o->amg_max_coarse < 8 || o->amg_max_coarse > 4000)
     return cfdh_fail(c, CFDH_E_ARG, "option out of range");
   const bool pc_changed = o->amg_theta != c->opt.amg_theta || o->amg_max_coarse != c->opt.amg_max_coarse ||
-                          o->amg_smooth_ratio != c->opt.amg_smooth_ratio || o->pc_type != c->opt.pc_type;
+                          o->amg_smooth_ratio != c->opt.amg_smooth_ratio || o->pc_type != c->opt.pc_type ||
+                          o->schur_full != c->opt.schur_full;  // the velocity hierarchy covers owned + ghost vertices only for schur_full == 2 (ras)
   c->opt = *o;
   if (pc_changed) c->pc_valid = false;
   c->pc_graph_valid = false;  // degrees / schur_full are baked into the captured graph
@@ -255,6 +256,20 @@ int cfdh_set_time_scheme(cfdh_ctx *c, double theta, double a0, double a1, double
   return 0;
 }
 
+// per-cell facet bits of the assembly kernel: bits 0-2 exterior facet, bits 3-5 backflow facet (marker == bf_marker)
+static int upload_cell_facet_flags(cfdh_ctx *c) {
+  std::vector<unsigned char> cflag((size_t)c->nc, 0);
+  for (int k = 0; k < c->nfac; k++) {
+    cflag[c->fac_cell[k]] |= (unsigned char)(1u << c->fac_local[k]);
+    if (c->bf_marker >= 0 && c->fac_marker[k] == c->bf_marker) cflag[c->fac_cell[k]] |= (unsigned char)(8u << c->fac_local[k]);
+  }
+  HIPCHK(c, c->cflag.upload(cflag, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->jac_valid = false;
+  c->pc_valid = false;
+  return 0;
+}
+
 int cfdh_set_boundary_terms(cfdh_ctx *c, int ds_terms, int backflow_marker, double beta) {
   ENTER(c);
   if (beta < 0) return cfdh_fail(c, CFDH_E_ARG, "backflow beta must be >= 0");
@@ -262,15 +277,20 @@ int cfdh_set_boundary_terms(cfdh_ctx *c, int ds_terms, int backflow_marker, doub
   const bool changed = (ds_terms != 0) != c->ds_terms || beta != c->bf_beta || backflow_marker != c->bf_marker;
   c->ds_terms = ds_terms != 0; c->bf_beta = beta; c->bf_marker = backflow_marker;
   if (!changed) return 0;
-  std::vector<unsigned char> cflag((size_t)c->nc, 0);
-  for (int k = 0; k < c->nfac; k++) {
-    cflag[c->fac_cell[k]] |= (unsigned char)(1u << c->fac_local[k]);
-    if (backflow_marker >= 0 && c->fac_marker[k] == backflow_marker) cflag[c->fac_cell[k]] |= (unsigned char)(8u << c->fac_local[k]);
+  return upload_cell_facet_flags(c);
+}
+
+int cfdh_set_facet_markers(cfdh_ctx *c, int64_t nfacets, const int32_t *markers) {
+  ENTER(c);
+  if (nfacets != c->nfac_user) return cfdh_fail(c, CFDH_E_ARG, "cfdh_set_facet_markers: %lld markers for the %d exterior facets of cfdh_create", (long long)nfacets, c->nfac_user);
+  if (nfacets > 0 && !markers) return cfdh_fail(c, CFDH_E_ARG, "null marker array");
+  for (int k = 0; k < c->nfac; k++) c->fac_marker[k] = markers[c->fac_user[k]];
+  if (c->nfac) {
+    HIPCHK(c, c->d_fac_marker.upload(c->fac_marker, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  HIPCHK(c, c->cflag.upload(cflag, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->jac_valid = false;
-  c->pc_valid = false;
+  // the backflow term follows the outlet marker: refresh the per-cell flags (invalidates Jacobian and preconditioner)
+  if (c->bf_marker >= 0) return upload_cell_facet_flags(c);
   return 0;
 }
 
@@ -516,7 +536,8 @@ int cfdh_solve_step(cfdh_ctx *c, cfdh_stats *stats) {
 }
 
 int cfdh_functional(cfdh_ctx *c, int kind, int marker, double *out) {
-  if (!c || !out) return CFDH_E_ARG;
+  if (!out) return CFDH_E_ARG;
+  ENTER(c);
   return k_functional(c, kind, marker, out);
 }
 
@@ -559,6 +580,7 @@ int cfdh_profile_reset(cfdh_ctx *c) {
   ENTER(c);
   prof_flush(c);
   for (auto &p : c->prof) { p.total_ms = 0; p.launches = 0; }
+  c->n_allreduce = c->n_halo = c->n_host_sync = c->n_krylov = c->n_allgather = 0;
   return 0;
 }
 
@@ -578,6 +600,12 @@ int64_t cfdh_info(const cfdh_ctx *c, int what) {
     case 10: return c->nccl_comm ? 1 : 0;
     case 11: return c->dl0.on ? c->dl0.n1 : 0;
     case 12: return c->ras ? 1 : 0;
+    case 13: return c->n_allreduce;
+    case 14: return c->n_halo;
+    case 15: return c->n_host_sync;
+    case 16: return c->n_krylov;
+    case 17: return c->n_allgather;
+    case 18: return c->nranks;
     default: return -1;
   }
 }

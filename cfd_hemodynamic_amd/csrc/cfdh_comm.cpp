@@ -118,6 +118,7 @@ int comm_finalize(cfdh_ctx *c) {
 // in-stream reduction of n doubles at `dev` over all ranks; op 0 sum, 1 max
 int comm_allreduce_dev(cfdh_ctx *c, double *dev, int n, int op) {
   if (c->nranks <= 1) return 0;
+  c->n_allreduce++;
   if (c->nccl_comm) {
     NCCLCHK(c, g_nccl.AllReduce(dev, dev, (size_t)n, NCCL_FLOAT64, op == 0 ? NCCL_SUM : NCCL_MAX, (nccl_comm_t)c->nccl_comm, c->stream));
     return 0;
@@ -143,6 +144,7 @@ int comm_allreduce_dev(cfdh_ctx *c, double *dev, int n, int op) {
 // recv[r * count + i] = send_r[i] for every rank r (in-stream)
 int comm_allgather_dev(cfdh_ctx *c, const double *send, double *recv, int count) {
   if (!c->nccl_comm) return cfdh_fail(c, CFDH_E_COMM, "all-gather needs an RCCL communicator");
+  c->n_allgather++;
   NCCLCHK(c, g_nccl.AllGather(send, recv, (size_t)count, NCCL_FLOAT64, (nccl_comm_t)c->nccl_comm, c->stream));
   return 0;
 }
@@ -152,15 +154,21 @@ int comm_halo(cfdh_ctx *c, double *vec) {
   if (c->nranks <= 1 || c->ng == 0) return 0;
   if (c->nnbr == 0) return cfdh_fail(c, CFDH_E_STATE, "ghost vertices present but cfdh_set_halo was not called");
   CHK(k_halo_pack(c, vec));
+  c->n_halo++;
   double *tail = vec + 3 * (size_t)c->nvo;
   if (c->nccl_comm) {
     NCCLCHK(c, g_nccl.GroupStart());
-    for (int k = 0; k < c->nnbr; k++) {
+    // an error inside the group must not leave it open: remember the first one, always close, then report
+    int first = 0;
+    const char *what = "";
+    for (int k = 0; k < c->nnbr && !first; k++) {
       const size_t ns = (size_t)(c->send_ptr[k + 1] - c->send_ptr[k]), nr = (size_t)(c->recv_ptr[k + 1] - c->recv_ptr[k]);
-      if (ns) NCCLCHK(c, g_nccl.Send(c->send_buf.p + 3 * c->send_ptr[k], 3 * ns, NCCL_FLOAT64, c->nbr_rank[k], (nccl_comm_t)c->nccl_comm, c->stream));
-      if (nr) NCCLCHK(c, g_nccl.Recv(tail + 3 * c->recv_ptr[k], 3 * nr, NCCL_FLOAT64, c->nbr_rank[k], (nccl_comm_t)c->nccl_comm, c->stream));
+      if (ns && (first = g_nccl.Send(c->send_buf.p + 3 * c->send_ptr[k], 3 * ns, NCCL_FLOAT64, c->nbr_rank[k], (nccl_comm_t)c->nccl_comm, c->stream))) { what = "ncclSend"; break; }
+      if (nr && (first = g_nccl.Recv(tail + 3 * c->recv_ptr[k], 3 * nr, NCCL_FLOAT64, c->nbr_rank[k], (nccl_comm_t)c->nccl_comm, c->stream))) { what = "ncclRecv"; break; }
     }
-    NCCLCHK(c, g_nccl.GroupEnd());
+    const int endrc = g_nccl.GroupEnd();
+    if (first) return cfdh_fail(c, CFDH_E_COMM, "%s (halo exchange): %s", what, g_nccl.GetErrorString(first));
+    if (endrc) return cfdh_fail(c, CFDH_E_COMM, "ncclGroupEnd (halo exchange): %s", g_nccl.GetErrorString(endrc));
     return 0;
   }
   if (!c->cb_ex) return cfdh_fail(c, CFDH_E_COMM, "multi-rank context without communicator");

@@ -117,6 +117,8 @@ struct cfdh_ctx {
   std::vector<int> cell_user;     // internal cell -> user cell
   std::vector<double> h_coords;   // internal order [nv][2]
   std::vector<int> fac_cell, fac_local, fac_marker;  // internal cell ids
+  std::vector<int> fac_user;  // index of the kept facet in the caller's facet list (cfdh_create order)
+  int nfac_user = 0;
 
   bool params_set = false;
   double dt = 0, rho = 0, mu = 0, muf = 0, f[2] = {0, 0};
@@ -269,6 +271,9 @@ struct cfdh_ctx {
   size_t ev_next = 0;
 
   cfdh_stats last_stats;
+  // communication / synchronisation counters (cfdh_info 13..17): all-reduces, halo exchanges, host synchronisations
+  // of the solve, FGMRES iterations, all-gathers -- cumulative, reset by cfdh_profile_reset
+  long long n_allreduce = 0, n_halo = 0, n_host_sync = 0, n_krylov = 0, n_allgather = 0;
 };
 
 // ---- error helpers -----------------------------------------------------------

@@ -1454,11 +1454,13 @@ static int finish_scalars(cfdh_ctx *c, double *out_dev, int n, int op) {
 static int read_scalars(cfdh_ctx *c, const double *dev, int n, double *host) {
   if (c->mirror_src == dev && n <= c->mirror_cnt) {
     c->mirror_src = nullptr;  // one shot
+    c->n_host_sync++;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; i++) host[i] = c->h_pinned[CFDH_MIRROR_OFF + i];
     return 0;
   }
   HIPCHK(c, hipMemcpyAsync(c->h_pinned, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  c->n_host_sync++;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < n; i++) host[i] = c->h_pinned[i];
   return 0;
@@ -1530,13 +1532,9 @@ int v_sub_mean(cfdh_ctx *c, int n, double *p) {
   double scale = 1.0 / n;
   if (c->nranks > 1) {
     CHK(comm_allreduce_dev(c, acc, 1, 0));
-    // global count: every rank knows only its own n; reduce it once per call on the host side
-    double cnt = (double)n;
-    HIPCHK(c, hipMemcpyAsync(acc + 1, &cnt, sizeof(double), hipMemcpyHostToDevice, c->stream));
-    CHK(comm_allreduce_dev(c, acc + 1, 1, 0));
-    double tot;
-    CHK(read_scalars(c, acc + 1, 1, &tot));
-    scale = 1.0 / tot;
+    // global number of pressure dofs: constant, reduced once when the communicator is attached (global_counts)
+    if (n != c->nvo || !(c->nvo_global > 0)) return cfdh_fail(c, CFDH_E_STATE, "v_sub_mean: global count unknown");
+    scale = 1.0 / c->nvo_global;
   }
   hipLaunchKernelGGL(sub_scalar_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, p, acc, scale);
   HIPCHK(c, hipGetLastError());
@@ -1799,7 +1797,8 @@ int k_wss(cfdh_ctx *c, double *out) {
 int k_functional(cfdh_ctx *c, int kind, int marker, double *out) {
   const int nb = 256;
   if (kind == 0 || kind == 1) {
-    if (c->nfac == 0) { *out = 0; return 0; }
+    // a part without exterior facets (nfac == 0) still launches: the kernel then only writes zero partials, and the
+    // rank takes part in the reduction below like every other one (skipping it would desynchronise the collectives)
     hipLaunchKernelGGL(draglift_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nfac, marker, c->nvo, c->d_fac_cell.p,
                        c->d_fac_local.p, c->d_fac_marker.p, c->cells.p, c->cell_owned.p, c->coords.p, c->x.p, c->mu,
                        c->red_partial.p);

@@ -98,11 +98,13 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
       cmap[e] = k; c->cell_user[k] = e;
       for (int a = 0; a < 3; a++) c->h_cells[3 * k + a] = c->perm[cells[3 * e + a]];
     }
-    c->fac_cell.clear(); c->fac_local.clear(); c->fac_marker.clear();
+    c->fac_cell.clear(); c->fac_local.clear(); c->fac_marker.clear(); c->fac_user.clear();
+    c->nfac_user = nfac;
     for (int k = 0; k < nfac; k++)
       if (cmap[fcell[k]] >= 0) {
         c->fac_cell.push_back(cmap[fcell[k]]); c->fac_local.push_back(flocal[k]);
         c->fac_marker.push_back(fmarker ? fmarker[k] : 0);
+        c->fac_user.push_back(k);
       }
     c->nfac = (int)c->fac_cell.size();
   }

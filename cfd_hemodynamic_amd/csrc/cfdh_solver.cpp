@@ -326,15 +326,11 @@ int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
   CHK(k_cheb_a00_coeffs(c));
   if (refresh_amg || !c->pc_valid) {
     c->pc_graph_valid = false;  // the hierarchies' buffers and coefficients are baked into the graphs
-    if (c->opt.pc_type == 1) {
-      CHK(build_cc_host(c));
-    } else {
-      CsrHost S;
-      CHK(build_schur_host(c, S));
-      bool any_pbc = false;
-      for (int i = 0; i < c->nvo; i++) any_pbc |= (c->h_bcflag[i] & 4u) != 0;
-      CHK(cfdh_amg_setup(c, c->hS, S, c->singular != 0 || !any_pbc, 1));
-    }
+    CsrHost S;
+    CHK(build_schur_host(c, S));
+    bool any_pbc = false;
+    for (int i = 0; i < c->nvo; i++) any_pbc |= (c->h_bcflag[i] & 4u) != 0;
+    CHK(cfdh_amg_setup(c, c->hS, S, c->singular != 0 || !any_pbc, 1));
     c->pc_valid = true;
     c->pc_its_ref = 0;
     c->steps_since_refresh = 0;
@@ -410,7 +406,7 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
           CHK(v_copy(c, nu, multi ? c->pcw.p : c->pu0.p, zu));              // block lower-triangular variant
         }
         return 0;
-      default:
+      case 4:
         if (multi && c->ras && c->opt.schur_full) {
           // restricted additive Schwarz: cycle on owned + ghost vertices, keep the owned part
           CHK(k_ext_pack(c, c->pcw.p, c->ras_b.p));
@@ -418,6 +414,8 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
           CHK(v_copy(c, nu, c->ras_x.p, zu));
         }
         return 0;
+      default:
+        return 0;  // stage slot unused by this configuration
     }
   }
   if (stage != 0) return 0;  // pc_type 0 is rank-local: one stage
@@ -571,6 +569,7 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       // below overlaps with the host's Hessenberg bookkeeping and the next launches
       HIPCHK(c, hipEventRecord(c->ev_h, c->stream));
       CHK(v_multiaxpy(c, n, V, (int)ld, j + 1, hd, w));
+      c->n_host_sync++;
       HIPCHK(c, hipEventSynchronize(c->ev_h));
       double ww = c->h_pinned[j + 1], hh2 = 0.0;
       for (int i = 0; i <= j; i++) { hh[i] = c->h_pinned[i]; hh2 += hh[i] * hh[i]; }
@@ -623,6 +622,7 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
     HIPCHK(c, hipStreamSynchronize(c->stream));  // y is a host temporary
     (void)done;
   }
+  c->n_krylov += its;
   *its_out = its;
   *reason_out = reason;
   return 0;

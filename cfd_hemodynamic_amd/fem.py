@@ -147,7 +147,7 @@ class DirichletBC:
         self.dofs = np.asarray(dofs, dtype=np.int32)
         self.function_space = g.function_space
 
-    def update(self):  # replaced per instance by BoundaryCondition.getBC
+    def update(self):  # constant data; boundaryCondition._SourcedBC refreshes from its source
         return None
 
 

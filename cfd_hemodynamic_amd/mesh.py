@@ -36,6 +36,26 @@ class _SerialComm:
         return [v]
 
 
+class PartCommView:
+    """`mesh.comm` of a partitioned run.  Every rank holds the whole (replicated) mesh and the harness only ever
+    reduces values that are already global (fields gathered through `x.array`, functionals reduced inside the
+    library), so `allreduce` is the identity; `rank` and `barrier` are the launcher's, which is what the
+    rank-0 guards around printing and file output need."""
+
+    def __init__(self, part_comm):
+        self._pc = part_comm
+        self.rank, self.size = part_comm.rank, part_comm.size
+
+    def barrier(self):
+        self._pc.barrier()
+
+    def allreduce(self, v, op=None):
+        return v
+
+    def gather(self, v, root=0):
+        return [v] if self.rank == root else None
+
+
 class _Topology:
     def __init__(self, mesh):
         self._mesh = mesh

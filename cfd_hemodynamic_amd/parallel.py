@@ -120,10 +120,12 @@ class PartComm:
     itself (the unique id is broadcast through torch.distributed); backend 'host':
     host-staged exchange over the torch.distributed default group (gloo)."""
 
-    def __init__(self, rank=0, size=1, backend="rccl"):
+    def __init__(self, rank=0, size=1, backend="rccl", partitioner=None):
         self.rank, self.size, self.backend = int(rank), int(size), backend
         self.part = None
         self._keep = None
+        # partitioner(x[nv,2], nparts) -> owner[nv]; default: recursive coordinate bisection
+        self.partitioner = partitioner or partition_vertices_rcb
 
     @classmethod
     def from_torch(cls, backend="rccl"):
@@ -133,7 +135,9 @@ class PartComm:
         return cls(dist.get_rank(), dist.get_world_size(), backend)
 
     def make_part(self, mesh):
-        owner = partition_vertices_rcb(mesh.x, self.size)
+        owner = np.asarray(self.partitioner(mesh.x, self.size), dtype=np.int32)
+        if owner.shape != (mesh.num_vertices,) or owner.min() < 0 or owner.max() >= self.size:
+            raise ValueError("partitioner must return one owner rank in [0, size) per vertex")
         self.owner = owner
         self.part = LocalPart(mesh, owner, self.rank)
         return self.part

@@ -51,43 +51,50 @@ class Scenario(ABC):
 
     def __init__(self, solver_name: str, scenario_name: str, rho: float, mu: float, dt: float, T: float, f: list,
                  early_stop_tolerance: float = 1e-3, **solver_kwargs):
-        self.solver_name = solver_name
-        self.scenario_name = scenario_name
+        """Loads `solvers/<solver_name>.py`, keeps the keyword arguments its `Solver.__init__` can take
+        (all of them when it declares **kwargs) and builds the solver on `self.mesh` -- the plugin
+        protocol of /root/reference/src/scenario.py:44-133 (ImportError: no such module, ValueError: module
+        without a `Solver`, RuntimeError: the constructor failed)."""
+        self.solver_name, self.scenario_name = solver_name, scenario_name
         self.early_stop_tolerance = early_stop_tolerance
-        try:
-            solver_module = import_module(f"{__package__}.solvers.{solver_name}")
-        except ImportError as e:
-            raise ImportError(
-                f"Could not import solver '{solver_name}'. Ensure {__package__}/solvers/{solver_name}.py exists "
-                f"and all its dependencies are available.\nUnderlying error: {e}\n"
-                f"Available solvers: {self._list_available_solvers()}") from e
-        if not hasattr(solver_module, "Solver"):
-            raise ValueError(f"Solver module 'solvers/{solver_name}.py' does not define a 'Solver' class.")
-        self.solverClass: type[SolverBase] = solver_module.Solver
-        sig = inspect.signature(self.solverClass.__init__)
-        accepted = sig.parameters
-        has_var_keyword = any(p.kind == inspect.Parameter.VAR_KEYWORD for p in accepted.values())
-        filtered = solver_kwargs if has_var_keyword else {k: v for k, v in solver_kwargs.items() if k in accepted}
-        try:
-            self.solver = self.solverClass(self.mesh, dt, rho, mu, f, initial_velocity=self.initial_velocity, **filtered)
-        except TypeError as e:
-            raise RuntimeError(f"Failed to instantiate solver '{solver_name}': {e}. "
-                               f"Check that the Solver class has the correct constructor signature.") from e
-        except Exception as e:
-            raise RuntimeError(f"Error while initializing solver '{solver_name}': {type(e).__name__}: {e}") from e
-        self.T = T
-        self.has_exact_solution = self.__class__.exact_velocity is not Scenario.exact_velocity
-        self.dt = dt
+        self.dt, self.T = dt, T
+        self.solverClass: type[SolverBase] = self._find_solver_class(solver_name)
+        self.solver = self._build_solver(self.solverClass, (self.mesh, dt, rho, mu, f), solver_kwargs)
+        self.has_exact_solution = type(self).exact_velocity is not Scenario.exact_velocity
         self.step_stats = []
 
     @staticmethod
-    def _list_available_solvers():
-        d = os.path.join(os.path.dirname(__file__), "solvers")
+    def _solver_names() -> list[str]:
+        """Plugin modules present next to this file."""
+        folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "solvers")
+        if not os.path.isdir(folder):
+            return []
+        return sorted(n[:-3] for n in os.listdir(folder) if n.endswith(".py") and n[0] != "_")
+
+    @classmethod
+    def _find_solver_class(cls, name: str):
         try:
-            s = [f[:-3] for f in os.listdir(d) if f.endswith(".py") and not f.startswith("_")]
-            return s if s else ["(none found)"]
-        except OSError:
-            return ["(could not list)"]
+            module = import_module(f"{__package__}.solvers.{name}")
+        except ImportError as exc:
+            known = ", ".join(cls._solver_names()) or "none"
+            raise ImportError(f"no solver plugin '{name}' could be imported from {__package__}/solvers "
+                              f"({exc}); plugins present: {known}") from exc
+        solver_class = getattr(module, "Solver", None)
+        if solver_class is None:
+            raise ValueError(f"{__package__}/solvers/{name}.py has no class named Solver")
+        return solver_class
+
+    def _build_solver(self, solver_class, positional, keywords: dict):
+        params = inspect.signature(solver_class.__init__).parameters
+        if not any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values()):
+            keywords = {k: v for k, v in keywords.items() if k in params}  # silently dropped, as in the reference
+        try:
+            return solver_class(*positional, initial_velocity=self.initial_velocity, **keywords)
+        except TypeError as exc:
+            raise RuntimeError(f"solver '{self.solver_name}' rejected its constructor arguments: {exc}") from exc
+        except Exception as exc:
+            raise RuntimeError(f"solver '{self.solver_name}' failed during construction "
+                               f"({type(exc).__name__}: {exc})") from exc
 
     @property
     def facet_tags(self):
@@ -203,13 +210,15 @@ class Scenario(ABC):
             norm_v, norm_p = self._l2_norms_host()
         self.norm_v, self.norm_p = norm_v, norm_p
         solver.assemble_wss()
-        if output_folder and mesh.comm.rank == 0:
-            with open(os.path.join(output_folder, "norms.txt"), "w") as f:
-                f.write(f"L2 norm of velocity: {norm_v}\n")
-                f.write(f"L2 norm of pressure: {norm_p}\n")
-            np.savez(os.path.join(output_folder, "final.npz"), x=mesh.x, cells=mesh.cells,
-                     velocity=solver.u_sol.x.array, pressure=solver.p_sol.x.array,
-                     wss=solver.shear_stress.x.array)
+        if output_folder:
+            # reading `x.array` gathers the owned slices in a partitioned run: every rank takes part, rank 0 writes
+            fields = dict(velocity=solver.u_sol.x.array, pressure=solver.p_sol.x.array, wss=solver.shear_stress.x.array)
+            if mesh.comm.rank == 0:
+                with open(os.path.join(output_folder, "norms.txt"), "w") as f:
+                    f.write(f"L2 norm of velocity: {norm_v}\n")
+                    f.write(f"L2 norm of pressure: {norm_p}\n")
+                np.savez(os.path.join(output_folder, "final.npz"), x=mesh.x, cells=mesh.cells, **fields)
+            mesh.comm.barrier()
         for w in writers:
             w.close()
         if error_log:

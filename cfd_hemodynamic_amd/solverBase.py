@@ -25,35 +25,18 @@ class SolverBase(ABC):
         self._u_sol = self._p_sol = self._u_prev = self._p_prev = None
         self._V = self._Q = None
 
-    @property
-    def u_sol(self):
-        assert self._u_sol is not None, "Velocity solution function is not initialized. call initVelocitySpace() first."
-        return self._u_sol
+    def _need(self, attr: str, initialiser: str):
+        value = getattr(self, attr)
+        if value is None:
+            raise AssertionError(f"{type(self).__name__}.{attr.lstrip('_')} does not exist before {initialiser}() was called")
+        return value
 
-    @property
-    def p_sol(self):
-        assert self._p_sol is not None, "Pressure solution function is not initialized. call initPressureSpace() first."
-        return self._p_sol
-
-    @property
-    def u_prev(self):
-        assert self._u_prev is not None, "Velocity solution function is not initialized. call initVelocitySpace() first."
-        return self._u_prev
-
-    @property
-    def p_prev(self):
-        assert self._p_prev is not None, "Pressure solution function is not initialized. call initPressureSpace() first."
-        return self._p_prev
-
-    @property
-    def V(self):
-        assert self._V is not None, "Velocity function space is not initialized. call initVelocitySpace() first."
-        return self._V
-
-    @property
-    def Q(self):
-        assert self._Q is not None, "Pressure function space is not initialized. call initPressureSpace() first."
-        return self._Q
+    u_sol = property(lambda self: self._need("_u_sol", "initVelocitySpace"))
+    u_prev = property(lambda self: self._need("_u_prev", "initVelocitySpace"))
+    V = property(lambda self: self._need("_V", "initVelocitySpace"))
+    p_sol = property(lambda self: self._need("_p_sol", "initPressureSpace"))
+    p_prev = property(lambda self: self._need("_p_prev", "initPressureSpace"))
+    Q = property(lambda self: self._need("_Q", "initPressureSpace"))
 
     @abstractmethod
     def setup(self, bcu: list[BoundaryCondition], bcp: list[BoundaryCondition]) -> None:
@@ -63,16 +46,16 @@ class SolverBase(ABC):
     def solveStep(self) -> None:
         pass
 
-    def initVelocitySpace(self, family, cell, deegre, shape=None) -> None:
-        if int(deegre) != 1:
+    def initVelocitySpace(self, family, cell, degree, shape=None) -> None:
+        if int(degree) != 1:
             raise ValueError("only P1 velocity is implemented")
         self._V = FunctionSpace(self.mesh, self.mesh.geometry.dim if shape is None else int(shape[0]))
         self._u_sol = Function(self.V, name="velocity")
         self._u_prev = Function(self.V)
         self.u_residual = Function(self.V, name="u_residual")
 
-    def initPressureSpace(self, family, cell, deegre, shape=None) -> None:
-        if int(deegre) != 1:
+    def initPressureSpace(self, family, cell, degree, shape=None) -> None:
+        if int(degree) != 1:
             raise ValueError("only P1 pressure is implemented")
         self._Q = FunctionSpace(self.mesh, 1)
         self._p_sol = Function(self.Q, name="pressure")

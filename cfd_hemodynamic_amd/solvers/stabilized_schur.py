@@ -42,6 +42,8 @@ class Solver(SolverBase):
         device = int(kwargs.get("device", 0))
         self._part = None
         if self._comm is not None and self._comm.size > 1:
+            from ..mesh import PartCommView
+            mesh.comm = PartCommView(self._comm)  # rank-0 guards of the harness (printing, file output) see the real rank
             part = self._comm.make_part(mesh)
             self._part = part
             self.ctx = _lib.Context(part.x, part.cells, part.facet_cells, part.facet_local, part.facet_marker,
@@ -137,6 +139,12 @@ class Solver(SolverBase):
         self.bcp_d = [bc.getBC(self.Q) for bc in bcp]
         self._bcs = [(0, bc) for bc in self.bcu_d] + [(1, bc) for bc in self.bcp_d]
         self._bc_cache = None
+        if facet_tags is not None:
+            # the reference hands the facet tags over here, not at construction (scenario.py:146-149):
+            # drag/lift by marker and the backflow marker follow them
+            mk = np.zeros(self.mesh.num_facets, dtype=np.int32)
+            mk[np.asarray(facet_tags.indices, dtype=np.int64)] = np.asarray(facet_tags.values, dtype=np.int32)
+            self.ctx.set_facet_markers(mk if self._part is None else mk[self._part.facet_ids])
         self._upload_bcs()
         if self._part is not None:
             # one known-answer exchange + reduction through the communicator before trusting it (multi-GPU

@@ -102,10 +102,18 @@ typedef struct cfdh_stats {
  * size h = mesh.h (stabilized_schur.py:82-88).
  * gdim must be 2.  cells [nc][3]; coords [nv][gdim];
  * exterior facets: owning cell, local facet index (= local index of the
- * opposite vertex), marker (0 = untagged). */
+ * opposite vertex), marker (0 = untagged; facet_marker may be NULL, see
+ * cfdh_set_facet_markers). */
 int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_owned, int64_t nc,
                 const int32_t *cells, const double *coords, int64_t nfacets, const int32_t *facet_cells,
                 const int32_t *facet_local, const int32_t *facet_marker);
+/* (Re)assign the markers of the exterior facets after cfdh_create: the reference hands `facet_tags` / `tags` to
+ * Solver.setup(), not to the constructor (/root/reference/src/scenario.py:137-149;
+ * stabilized_schur_backflow.py:158-163 builds ds_out from them there).  markers[nfacets] in the facet order of
+ * cfdh_create (nfacets must equal its nfacets; a rank keeps the entries of the facets whose cell it holds).
+ * Drag/lift by marker (cfdh_functional) and the backflow marker of cfdh_set_boundary_terms follow the new values;
+ * an active backflow term invalidates Jacobian and preconditioner. */
+int cfdh_set_facet_markers(cfdh_ctx *ctx, int64_t nfacets, const int32_t *markers);
 void cfdh_destroy(cfdh_ctx *ctx);
 const char *cfdh_last_error(const cfdh_ctx *ctx); /* ctx may be NULL after a failed create */
 int cfdh_abi_version(void);
@@ -242,7 +250,9 @@ int cfdh_profile_reset(cfdh_ctx *ctx);
  * 4 Sp nnz, 5 incidences, 6 AMG levels, 7 assembly workgroups, 8 velocity-proxy nnz;
  * communicator state: 9 padded part size of the pressure all-gather (0: all-reduce path), 10: RCCL attached,
  * 11: size of the replicated coarse level below the distributed finest pressure level (0: fully replicated cycle),
- * 12: overlapping (restricted additive Schwarz) velocity cycle in use */
+ * 12: overlapping (restricted additive Schwarz) velocity cycle in use;
+ * counters since cfdh_create / cfdh_profile_reset: 13 all-reduce calls, 14 halo exchanges, 15 host synchronisations
+ * (stream/event waits for scalars), 16 FGMRES iterations, 17 all-gathers; 18: communicator size */
 int64_t cfdh_info(const cfdh_ctx *ctx, int what);
 
 #ifdef __cplusplus

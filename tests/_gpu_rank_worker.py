@@ -20,7 +20,14 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out = sys.argv[1]
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    comm = PartComm(rank, world, os.environ.get("CFDH_TEST_BACKEND", "host"))
+    partitioner = None
+    if os.environ.get("CFDH_TEST_PARTITION") == "interior_island":
+        # rank 1 owns a disc well inside the domain: its part (owned vertices + one layer of cells) has no exterior facet
+        def partitioner(x, nparts):
+            c = 0.5 * (x.min(axis=0) + x.max(axis=0))
+            r = 0.2 * (x.max(axis=0) - x.min(axis=0)).min()
+            return (np.linalg.norm(x - c, axis=1) < r).astype(np.int32)
+    comm = PartComm(rank, world, os.environ.get("CFDH_TEST_BACKEND", "host"), partitioner=partitioner)
     tight = dict(snes_rtol=float(os.environ.get("CFDH_TEST_SNES_RTOL", "1e-12")), snes_stol=0.0,
                  ksp_rtol=float(os.environ.get("CFDH_TEST_KSP_RTOL", "1e-10")))
     case = os.environ.get("CFDH_TEST_CASE", "dfg")
@@ -34,7 +41,14 @@ def main():
     else:
         sc = DFG1Benchmark(os.environ.get("CFDH_TEST_SOLVER", "stabilized_schur"), 0.01, 0.05, m=16, quiet=True, device=0,
                            comm=comm, options=tight)
-    sc.solve(None)
+    outdir = os.environ.get("CFDH_TEST_OUTDIR") or None
+    ctx = sc.solver.ctx
+    ctx.profile_reset()  # zero the communication counters after setup
+    sc.solve(outdir)
+    counters = [ctx.info(k) for k in (13, 14, 15, 16, 17, 18)]
+    # facet functionals are collective: a rank whose part has no exterior facet must still take part
+    fd_all, fl_all = sc.solver.functional(0, 0), sc.solver.functional(1, 0)
+    nfac_local = len(sc.solver._part.facet_cells)
     u = sc.solver.u_sol.x.array.copy()   # gathers the owned slices of every rank
     p = sc.solver.p_sol.x.array.copy()
     if rank == 0:
@@ -42,7 +56,8 @@ def main():
                  krylov=sum(s.krylov_its for _, s in sc.step_stats), backend=comm.backend,
                  allgather=sc.solver.ctx.info(9), rccl_attached=sc.solver.ctx.info(10),
                  dist_coarse=sc.solver.ctx.info(11), ras=sc.solver.ctx.info(12),
-                 fallback=str(getattr(comm, "fallback_reason", "")))
+                 fallback=str(getattr(comm, "fallback_reason", "")), counters=counters, fd_all=fd_all, fl_all=fl_all)
+    np.save(out + ".nfac%d.npy" % rank, np.array([nfac_local]))
     dist.barrier()
     dist.destroy_process_group()
 

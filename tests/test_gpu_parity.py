@@ -146,6 +146,30 @@ def test_reference_default_tolerances_and_divergence_error():
     ctx.close()
 
 
+def test_facet_markers_can_be_set_after_create():
+    """The reference hands facet_tags to Solver.setup(), after the spaces exist (scenario.py:146-149): a context
+    created with untagged facets must give drag/lift by marker once cfdh_set_facet_markers delivered the tags."""
+    from cfd_hemodynamic_amd import _lib
+    case = dfg_case(10)
+    m, nv = case.mesh, case.nv
+    a = make_ctx(case)  # markers given at creation
+    z2, z1 = np.zeros(2 * nv), np.zeros(nv)
+    a.set_state(u_prev=z2, p_prev=z1, u=z2, p=z1)
+    a.solve_step()
+    u, p = a.get_solution()
+    b = _lib.Context(m.x, m.cells, m.facet_cells, m.facet_local, np.zeros_like(m.facet_marker))
+    b.set_params(case.dt, case.rho, case.mu, f=case.f)
+    b.set_state(u_prev=z2, p_prev=z1, u=u, p=p)
+    assert b.functional(0, 5) == 0.0 and b.functional(1, 5) == 0.0  # no facet carries marker 5 yet
+    with pytest.raises(ValueError, match="markers"):
+        b.set_facet_markers(m.facet_marker[:-1])
+    b.set_facet_markers(m.facet_marker)
+    assert b.functional(0, 5) == a.functional(0, 5) != 0.0
+    assert b.functional(1, 5) == a.functional(1, 5)
+    a.close()
+    b.close()
+
+
 def test_solver_class_and_scenario_drop_in():
     """The plugin surface end to end: Scenario loop (device-resident and the reference's literal
     host-copy loop) -> identical results; drag/lift against the oracle-driven loop."""

@@ -63,7 +63,8 @@ def test_time_loop_counts_and_early_stop(oracle_backend):
 
 def test_unknown_solver_and_kwarg_filtering(oracle_backend):
     from cfd_hemodynamic_amd.scenarios.lid_driven2D import LidDriven2DSimulation
-    with pytest.raises(ImportError, match="Could not import solver"):
+    # ImportError for an unknown plugin module, listing the ones present (scenario.py:61-72 of the reference)
+    with pytest.raises(ImportError, match=r"no solver plugin 'does_not_exist'.*stabilized_schur"):
         LidDriven2DSimulation("does_not_exist", 0.01, 0.1, nx=4)
     sc = LidDriven2DSimulation(oracle_backend, 0.01, 0.02, nx=4, quiet=True, some_unused_kwarg=3)
     assert sc.solver.nv == 25
