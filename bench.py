@@ -50,11 +50,20 @@ def kernel_bytes(ctx):
         2: ("tau_moments", 12.0 * nc + 32.0 * nvo + 64.0 * nc),
         # Chebyshev step on A00: values 32 B + column 4 B per entry; rowptr 4 + 7 vectors x 16 B per row
         3: ("cheb_step_A00", 36.0 * nnzv + 116.0 * nvo),
-        # level-0 smoother sweep of the pressure hierarchy (SELL-64, fp32 values): 4 B value + 4 B column per entry;
-        # slice pointer ~0, weights 8 + 4 vectors x 8 B per row
+        # fused AMG cycle, level 0 (SELL-64 / CSR, fp32 values: 4 B value + 4 B column per entry):
+        # up-sweep x = Sb b + Sc x_c: entries of Sb and Sc, b and x per row, the coarse vector once
+        4: ("amg_up0_pressure", 8.0 * ctx.info(19) + 16.0 * nvo + 8.0 * ctx.info(23)),
+        5: ("amg_up0_velocity_2rhs", 8.0 * ctx.info(20) + 32.0 * nvo + 16.0 * ctx.info(24)),
+        # down-sweep b_c = G b: entries of G, row pointer and result per coarse row, the fine vector once
+        8: ("amg_down0_pressure", 8.0 * ctx.info(21) + 12.0 * ctx.info(23) + 8.0 * nvo),
+        9: ("amg_down0_velocity_2rhs", 8.0 * ctx.info(22) + 20.0 * ctx.info(24) + 16.0 * nvo),
+    } if ctx.info(25) else {
+        0: ("asm_residual_jacobian", 624.0 * nvo),
+        1: ("spmv_full_block3x3", 76.0 * nnzv + 52.0 * nvo),
+        2: ("tau_moments", 12.0 * nc + 32.0 * nvo + 64.0 * nc),
+        3: ("cheb_step_A00", 36.0 * nnzv + 116.0 * nvo),
+        # unfused cycle: level-0 Jacobi sweep (SELL-64, fp32 values): 8 B per entry; weights 8 + 4 vectors x 8 B per row
         4: ("amg_sweep_pressure", 8.0 * spnnz + 40.0 * nvo),
-        # level-0 smoother sweep of the velocity hierarchy, two right-hand sides: 8 B per entry; weights 8,
-        # 3 vectors x 16 B per row
         5: ("amg_sweep_velocity_2rhs", 8.0 * ctx.info(8) + 56.0 * nvo),
     }
 
@@ -274,28 +283,49 @@ def main():
             "ms_per_step": 1e3 * tcpu / max(ncpu, 1),
         }
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        # Parity at the bench size: the oracle's state after step `nst` (from rest, PETSc-default tolerances on
-        # both sides) against the HIP path replayed from rest for the same number of steps in a fresh context
-        # (dfg_1.py:183-211 drag/lift, scenario.py:315-324 L2 norm).  Checker use of the oracle only.
+        # Parity at the bench size (checker use of the oracle only; drag/lift: dfg_1.py:183-211, L2 norm: scenario.py:315-324).
+        # (1) the states both sides reached at PETSc-default tolerances: oracle after step `nst` of the timed leg above
+        #     against the HIP path replayed from rest for the same number of steps -- differences = solver noise;
+        # (2) two steps from rest with BOTH sides converged tightly (snes_rtol 1e-12, ksp_rtol 1e-10): this is the
+        #     `parity` entry, north_star's "drag/lift within 1e-6 relative" is read against it.
+        obst = case.markers["ft"].find(5)
+        rel = lambda a, b: abs(a - b) / abs(b)
+
+        def compare(sc_g, x_o):
+            gd, gl = sc_g.drag_lift()
+            gl2 = sc_g.solver.functional(2)
+            od, ol = 500 * O.functional(x_o, 0, obst), 500 * O.functional(x_o, 1, obst)
+            ol2 = O.functional(x_o, 2)
+            xg = np.concatenate([sc_g.solver.u_sol.x.array, sc_g.solver.p_sol.x.array])
+            return {"drag_rel": rel(gd, od), "lift_rel": rel(gl, ol), "l2_rel": rel(gl2, ol2),
+                    "solution_rel": float(np.linalg.norm(xg - x_o) / np.linalg.norm(x_o)),
+                    "gpu": {"drag": gd, "lift": gl, "velocity_l2": gl2},
+                    "oracle": {"drag": od, "lift": ol, "velocity_l2": ol2}}
+
         sc2 = DFG1Benchmark(args.solver, dt, 1.0, m=args.m, quiet=True, device=local_rank, verbose=0)
         for _ in range(nst):
             sc2.solver.solveStep()
             sc2.solver.advance()
-        gd, gl = sc2.drag_lift()
-        gl2 = sc2.solver.functional(2)
-        obst = case.markers["ft"].find(5)
-        od, ol = 500 * O.functional(x, 0, obst), 500 * O.functional(x, 1, obst)
-        ol2 = O.functional(x, 2)
-        xg = np.concatenate([sc2.solver.u_sol.x.array, sc2.solver.p_sol.x.array])
-        rel = lambda a, b: abs(a - b) / abs(b)
-        out["parity"] = {
-            "step": nst, "drag_rel": rel(gd, od), "lift_rel": rel(gl, ol), "l2_rel": rel(gl2, ol2),
-            "solution_rel": float(np.linalg.norm(xg - x) / np.linalg.norm(x)),
-            "gpu": {"drag": gd, "lift": gl, "velocity_l2": gl2}, "oracle": {"drag": od, "lift": ol, "velocity_l2": ol2},
-            "tolerances": "PETSc defaults on both sides (snes_rtol 1e-8, ksp_rtol 1e-5): differences are solver noise; "
-                          "tests/test_gpu_parity_at_size.py repeats the comparison with both sides converged to 1e-12",
-        }
+        out["parity_default_tolerances"] = dict(compare(sc2, x), step=nst)
         del sc2
+        tight = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
+        sc3 = DFG1Benchmark(args.solver, dt, 1.0, m=args.m, quiet=True, device=local_rank, verbose=0, options=tight)
+        xt = np.zeros(3 * nv)
+        O.set_un(np.zeros(2 * nv))
+        topts = orc.default_opts(pc_kind=2, **tight)
+        hist = np.zeros(2 * nv)
+        for k in range(2):
+            sc3.solver.solveStep()
+            sc3.solver.advance()
+            if bdf2:
+                O.set_scheme(1.0, *((1.0, -1.0, 0.0) if k == 0 else (1.5, -2.0, 0.5)))
+                O.set_un2(hist)
+                hist = xt[: 2 * nv].copy()
+            xt, _ = O.solve_step(xt, topts)
+            O.set_un(xt[: 2 * nv])
+        out["parity"] = dict(compare(sc3, xt), step=2,
+                             tolerances="two steps from rest, both sides snes_rtol 1e-12 / ksp_rtol 1e-10 (oracle pc_kind=2)")
+        del sc3
 
     if rank == 0:
         print(json.dumps(out))

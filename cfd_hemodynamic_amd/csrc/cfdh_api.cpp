@@ -103,6 +103,7 @@ int cfdh_set_options(cfdh_ctx *c, const cfdh_options *o) {
     return cfdh_fail(c, CFDH_E_ARG, "option out of range");
   const bool pc_changed = o->amg_theta != c->opt.amg_theta || o->amg_max_coarse != c->opt.amg_max_coarse ||
                           o->amg_smooth_ratio != c->opt.amg_smooth_ratio || o->pc_type != c->opt.pc_type ||
+                          o->amg_smooth_degree != c->opt.amg_smooth_degree ||  // composite operators exist for degree 1 only
                           o->schur_full != c->opt.schur_full;  // the velocity hierarchy covers owned + ghost vertices only for schur_full == 2 (ras)
   c->opt = *o;
   if (pc_changed) c->pc_valid = false;
@@ -570,7 +571,7 @@ int cfdh_profile_enable(cfdh_ctx *c, int on) {
   return 0;
 }
 int cfdh_profile_get(cfdh_ctx *c, int kind, double *total_ms, int64_t *launches) {
-  if (!c || kind < 0 || kind >= 8) return CFDH_E_ARG;
+  if (!c || kind < 0 || kind >= 12) return CFDH_E_ARG;
   prof_flush(c);
   if (total_ms) *total_ms = c->prof[kind].total_ms;
   if (launches) *launches = c->prof[kind].launches;
@@ -606,6 +607,13 @@ int64_t cfdh_info(const cfdh_ctx *c, int what) {
     case 16: return c->n_krylov;
     case 17: return c->n_allgather;
     case 18: return c->nranks;
+    case 19: return c->opt.pc_type == 1 ? c->hL.nnz_S0 : c->hS.nnz_S0;
+    case 20: return c->hA.nnz_S0;
+    case 21: return c->opt.pc_type == 1 ? c->hL.nnz_G0 : c->hS.nnz_G0;
+    case 22: return c->hA.nnz_G0;
+    case 23: { const AmgHier &h = c->opt.pc_type == 1 ? c->hL : c->hS; return h.lev.size() > 1 ? h.lev[1]->n : 0; }
+    case 24: return c->hA.lev.size() > 1 ? c->hA.lev[1]->n : 0;
+    case 25: { const AmgHier &h = c->opt.pc_type == 1 ? c->hL : c->hS; return h.fused ? 1 : 0; }
     default: return -1;
   }
 }

@@ -65,13 +65,24 @@ struct CsrDev {
   // SELL values are kept in fp32: they feed preconditioner sweeps only (FGMRES is flexible and measures the
   // true fp64 residual), and the matrix stream is 60 % of a fine-level sweep's traffic
   dbuf<float> sval, svalw;  // svalw: values scaled by a column weight (Jacobi pre-sweep), optional
+  dbuf<float> valf;         // CSR-order fp32 copy of val (composite operators of the fine levels), optional
 };
+enum { CFDH_UP_CSR = 1, CFDH_UP_SELL = 2, CFDH_UP_CSRF = 4 };  // parts of a CsrDev to upload
 
 struct AmgLevel {
   int n = 0;
   CsrDev A, P, R;
   dbuf<double> dinv, wdinv, x, b, r, d0, d1;  // wdinv: Jacobi weight (1/theta, or 1 on diagonal-only rows) * dinv; work vectors hold ncol values per row
   double lmax = 0, lmin = 0;
+  // Composite operators of the fused V(1,1) Jacobi cycle (AmgHier::fused).  With W = diag(wdinv) the sweeps of a level
+  //   pre : xa = W b ; r = b - A xa ; b_c = R r              ==>  b_c = G b ,              G  = R (I - A W)
+  //   post: x1 = xa + P x_c ; x = x1 + W (b - A x1)          ==>  x = Sb b + Sc x_c ,      Sb = 2W - W A W , Sc = (I - W A) P
+  // are the SAME linear maps, applied with one kernel per level and direction instead of two.  On the level above
+  // a dense coarsest solve the correction is folded in as well: x = Sb b + D b_c , D = Sc A_c^-1 (dense, fp32).
+  CsrDev G, Sb, Sc;
+  dbuf<float> D;
+  int Dn = 0;        // columns of D (= size of the coarsest level); 0: not folded
+  bool fine = false; // SELL / fp32 formats are in use on this level (short regular rows)
 };
 
 // One smoothed-aggregation hierarchy.  ncol = 2 applies the same scalar operators to two
@@ -82,6 +93,8 @@ struct AmgHier {
   int coarse_n = 0, ncol = 1;
   long long fine_nnz = 0;
   bool valid = false;
+  bool fused = false;  // composite operators present on every level (built for damped-Jacobi smoothing)
+  long long nnz_G0 = 0, nnz_S0 = 0;  // entries of G and of Sb + Sc on the finest level (roofline accounting)
   // host copies of the finest level (operator, prolongator, Jacobi weights): kept on request so that a
   // partitioned run can cut its rows of the replicated pressure hierarchy out of them
   bool keep_host0 = false;
@@ -264,7 +277,7 @@ struct cfdh_ctx {
 
   // profiling
   bool prof_on = false;
-  ProfSlot prof[8];
+  ProfSlot prof[12];
   std::vector<hipEvent_t> ev_pool;
   struct EvRec { int kind; hipEvent_t a, b; };
   std::vector<EvRec> ev_pending;
@@ -295,7 +308,7 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv, int64_t nvo, int64_t nc, const int3
                     int64_t nfac, const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker);
 int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A, bool singular, int ncol);
 int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol, std::vector<double> *w_out = nullptr);
-int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<double> *colw = nullptr);
+int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<double> *colw = nullptr, int parts = CFDH_UP_CSR | CFDH_UP_SELL);
 
 // ---- kernels (cfdh_kernels.hip) ----------------------------------------------------
 void prof_begin(cfdh_ctx *c, int kind);

@@ -1219,6 +1219,161 @@ static int amg_cycle_jacobi(cfdh_ctx *c, AmgHier &H, size_t lev, const T *b, T *
   return 0;
 }
 
+// ---- fused V(1,1) Jacobi cycle: one kernel per level and direction on precomputed composite operators
+// (AmgLevel::G / Sb / Sc / D, built in cfdh_amg_setup).  Same linear map as amg_cycle_jacobi.
+template <int LPR>
+__device__ __forceinline__ double lpr_sum(double v) {
+  v = group8_sum(v);
+  if (LPR >= 16) v += dpp_shuffle<0x140>(v);  // row_mirror: sums of 16
+  if (LPR >= 32) v += __shfl_xor(v, 16);
+  if (LPR >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+template <int LPR> __device__ __forceinline__ double lsum(double v) { return lpr_sum<LPR>(v); }
+template <int LPR> __device__ __forceinline__ double2 lsum(double2 v) { return make_double2(lpr_sum<LPR>(v.x), lpr_sum<LPR>(v.y)); }
+
+// y = G x, LPR lanes per row (rows of the coarse level: tens to hundreds of entries)
+template <int LPR, typename VT, typename T>
+__global__ __launch_bounds__(TPB) void fused_down_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                         const VT *__restrict__ val, const T *__restrict__ x, T *__restrict__ y) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid / LPR, l = gid % LPR;
+  T a = vzero((const T *)nullptr);
+  if (row < n) {
+    const int ks = rowptr[row], ke = rowptr[row + 1];
+    for (int k = ks + l; k < ke; k += LPR) a = vfma((double)val[k], x[col[k]], a);
+  }
+  a = lsum<LPR>(a);
+  if (row < n && l == 0) y[row] = a;
+}
+// x = Sb b + Sc xc  (Sc may be absent: smoothing-only coarsest level), 8 lanes per row over CSR
+template <typename T>
+__global__ __launch_bounds__(TPB) void fused_up_csr_kernel(int n, const int *__restrict__ rpB, const int *__restrict__ clB,
+                                                           const double *__restrict__ vlB, const T *__restrict__ b,
+                                                           const int *__restrict__ rpC, const int *__restrict__ clC,
+                                                           const double *__restrict__ vlC, const T *__restrict__ xc,
+                                                           T *__restrict__ x) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  T a = vzero((const T *)nullptr);
+  if (row < n) {
+    for (int k = rpB[row] + l, ke = rpB[row + 1]; k < ke; k += 8) a = vfma(vlB[k], b[clB[k]], a);
+    if (rpC)
+      for (int k = rpC[row] + l, ke = rpC[row + 1]; k < ke; k += 8) a = vfma(vlC[k], xc[clC[k]], a);
+  }
+  a = g8(a);
+  if (row < n && l == 0) x[row] = a;
+}
+// the same on SELL-64 (fp32 values), one lane per row
+template <typename T>
+__global__ __launch_bounds__(TPB) void fused_up_sell_kernel(int n, const int *__restrict__ spB, const int *__restrict__ scB,
+                                                            const float *__restrict__ svB, const T *__restrict__ b,
+                                                            const int *__restrict__ spC, const int *__restrict__ scC,
+                                                            const float *__restrict__ svC, const T *__restrict__ xc,
+                                                            T *__restrict__ x) {
+  const int row = blockIdx.x * TPB + threadIdx.x;
+  if (row >= n) return;
+  const int sl = row >> 6, lane = row & 63;
+  T a = vzero((const T *)nullptr);
+  {
+    const int p0 = spB[sl], w = (spB[sl + 1] - p0) >> 6;
+#pragma unroll 4
+    for (int k = 0; k < w; k++) { const int p = p0 + k * 64 + lane; a = vfma((double)svB[p], b[scB[p]], a); }
+  }
+  if (spC) {
+    const int p0 = spC[sl], w = (spC[sl + 1] - p0) >> 6;
+#pragma unroll 4
+    for (int k = 0; k < w; k++) { const int p = p0 + k * 64 + lane; a = vfma((double)svC[p], xc[scC[p]], a); }
+  }
+  x[row] = a;
+}
+// x = Sb b + D bc with the dense folded coarse correction D [n][nc] (fp32), one wave per row
+template <typename T>
+__global__ __launch_bounds__(TPB) void fused_up_dense_kernel(int n, const int *__restrict__ rpB, const int *__restrict__ clB,
+                                                             const double *__restrict__ vlB, const T *__restrict__ b,
+                                                             const float *__restrict__ D, int nc, const T *__restrict__ bc,
+                                                             T *__restrict__ x) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 6, l = gid & 63;
+  T a = vzero((const T *)nullptr);
+  if (row < n) {
+    for (int k = rpB[row] + l, ke = rpB[row + 1]; k < ke; k += 64) a = vfma(vlB[k], b[clB[k]], a);
+    const float *Dr = D + (size_t)row * nc;
+#pragma unroll 4
+    for (int j = l; j < nc; j += 64) a = vfma((double)Dr[j], bc[j], a);
+  }
+  a = wsum(a);
+  if (row < n && l == 0) x[row] = a;
+}
+
+template <typename VT, typename T>
+static void launch_down(cfdh_ctx *c, const CsrDev &G, const VT *val, const T *x, T *y) {
+  const long long avg = G.n > 0 ? (G.nnz + G.n - 1) / G.n : 1;
+  const int lpr = avg > 48 ? 64 : (avg > 24 ? 32 : (avg > 12 ? 16 : 8));
+  dim3 block(TPB), grid((unsigned)(((long long)G.n * lpr + TPB - 1) / TPB));
+  if (lpr == 64) hipLaunchKernelGGL((fused_down_kernel<64, VT, T>), grid, block, 0, c->stream, G.n, G.rowptr.p, G.col.p, val, x, y);
+  else if (lpr == 32) hipLaunchKernelGGL((fused_down_kernel<32, VT, T>), grid, block, 0, c->stream, G.n, G.rowptr.p, G.col.p, val, x, y);
+  else if (lpr == 16) hipLaunchKernelGGL((fused_down_kernel<16, VT, T>), grid, block, 0, c->stream, G.n, G.rowptr.p, G.col.p, val, x, y);
+  else hipLaunchKernelGGL((fused_down_kernel<8, VT, T>), grid, block, 0, c->stream, G.n, G.rowptr.p, G.col.p, val, x, y);
+}
+
+template <typename T>
+static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof) {
+  const int nl = (int)H.lev.size();
+  // down: right-hand sides of all coarse levels
+  for (int l = 0; l + 1 < nl; l++) {
+    AmgLevel *L = H.lev[l], *N = H.lev[l + 1];
+    const T *src = l == 0 ? b : (const T *)L->b.p;
+    if (prof && l == 0) prof_begin(c, prof + 4);
+    if (L->fine) launch_down<float, T>(c, L->G, L->G.valf.p, src, (T *)N->b.p);
+    else launch_down<double, T>(c, L->G, L->G.val.p, src, (T *)N->b.p);
+    if (prof && l == 0) prof_end(c, prof + 4);
+  }
+  // coarsest level (or the level above it when the dense solve is folded into its up-sweep)
+  int l = nl - 1;
+  {
+    AmgLevel *L = H.lev[l];
+    const T *bl = l == 0 ? b : (const T *)L->b.p;
+    T *xl = l == 0 ? x : (T *)L->x.p;
+    if (nl >= 2 && H.lev[nl - 2]->Dn > 0) {
+      AmgLevel *U = H.lev[nl - 2];
+      const T *bu = nl - 2 == 0 ? b : (const T *)U->b.p;
+      T *xu = nl - 2 == 0 ? x : (T *)U->x.p;
+      hipLaunchKernelGGL((fused_up_dense_kernel<T>), dim3((unsigned)((64ll * U->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, U->n,
+                         U->Sb.rowptr.p, U->Sb.col.p, U->Sb.val.p, bu, U->D.p, U->Dn, bl, xu);
+      l = nl - 3;
+    } else {
+      if (H.coarse_n > 0)
+        hipLaunchKernelGGL((dense_mv_kernel<T>), dim3(H.coarse_n), dim3(64), 0, c->stream, H.coarse_n, H.coarse_inv.p, bl, xl);
+      else if (L->fine)
+        hipLaunchKernelGGL((fused_up_sell_kernel<T>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
+                           L->Sb.sptr.p, L->Sb.scol.p, L->Sb.sval.p, bl, (const int *)nullptr, (const int *)nullptr,
+                           (const float *)nullptr, (const T *)nullptr, xl);
+      else
+        hipLaunchKernelGGL((fused_up_csr_kernel<T>), dim3((unsigned)((8ll * L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
+                           L->Sb.rowptr.p, L->Sb.col.p, L->Sb.val.p, bl, (const int *)nullptr, (const int *)nullptr,
+                           (const double *)nullptr, (const T *)nullptr, xl);
+      l = nl - 2;
+    }
+  }
+  // up
+  for (; l >= 0; l--) {
+    AmgLevel *L = H.lev[l], *N = H.lev[l + 1];
+    const T *bl = l == 0 ? b : (const T *)L->b.p;
+    T *xl = l == 0 ? x : (T *)L->x.p;
+    if (prof && l == 0) prof_begin(c, prof);
+    if (L->fine)
+      hipLaunchKernelGGL((fused_up_sell_kernel<T>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
+                         L->Sb.sptr.p, L->Sb.scol.p, L->Sb.sval.p, bl, L->Sc.sptr.p, L->Sc.scol.p, L->Sc.sval.p, (const T *)N->x.p, xl);
+    else
+      hipLaunchKernelGGL((fused_up_csr_kernel<T>), dim3((unsigned)((8ll * L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
+                         L->Sb.rowptr.p, L->Sb.col.p, L->Sb.val.p, bl, L->Sc.rowptr.p, L->Sc.col.p, L->Sc.val.p, (const T *)N->x.p, xl);
+    if (prof && l == 0) prof_end(c, prof);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 // V-cycle with Chebyshev smoothing of degree >= 2 (single right-hand side)
 static int amg_cycle_cheb(cfdh_ctx *c, AmgHier &H, size_t lev, const double *b, double *x, bool prof) {
   AmgLevel *L = H.lev[lev];
@@ -1293,6 +1448,10 @@ int k_dl0_up(cfdh_ctx *c, double *out) {
 int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x) {
   if (!H.valid || H.lev.empty()) return cfdh_fail(c, CFDH_E_STATE, "AMG hierarchy not built");
   const bool prof = (&H == &c->hS) || (&H == &c->hL) || (&H == &c->hLg);
+  if (H.fused && c->opt.amg_smooth_degree == 1 && H.lev.size() >= 2) {
+    if (H.ncol == 2) return amg_cycle_fused<double2>(c, H, (const double2 *)b, (double2 *)x, 5);
+    return amg_cycle_fused<double>(c, H, b, x, prof ? 4 : 0);
+  }
   if (H.ncol == 2) return amg_cycle_jacobi<double2>(c, H, 0, (const double2 *)b, (double2 *)x, 5);
   if (c->opt.amg_smooth_degree == 1) return amg_cycle_jacobi<double>(c, H, 0, b, x, prof ? 4 : 0);
   return amg_cycle_cheb(c, H, 0, b, x, prof);

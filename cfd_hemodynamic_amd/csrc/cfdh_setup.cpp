@@ -484,11 +484,20 @@ static void transpose_host(const CsrHost &A, CsrHost &T) {
 }
 
 // colw (optional): per-column weights for the scaled copy svalw[k] = val[k] * colw[col[k]]
-static int upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<double> *colw = nullptr) {
+static int upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<double> *colw = nullptr,
+                      int parts = CFDH_UP_CSR | CFDH_UP_SELL) {
   D.n = H.n; D.m = H.m; D.nnz = H.nnz();
-  HIPCHK(c, D.rowptr.upload(H.rowptr, c->stream));
-  HIPCHK(c, D.col.upload(H.col, c->stream));
-  HIPCHK(c, D.val.upload(H.val, c->stream));
+  if (parts & (CFDH_UP_CSR | CFDH_UP_CSRF)) {
+    HIPCHK(c, D.rowptr.upload(H.rowptr, c->stream));
+    HIPCHK(c, D.col.upload(H.col, c->stream));
+  }
+  if (parts & CFDH_UP_CSR) HIPCHK(c, D.val.upload(H.val, c->stream));
+  if (parts & CFDH_UP_CSRF) {
+    std::vector<float> vf(H.val.begin(), H.val.end());
+    HIPCHK(c, D.valf.upload(vf, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (!(parts & CFDH_UP_SELL)) { HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
   // SELL-64
   const int ns = (H.n + 63) / 64;
   std::vector<int> sptr(ns + 1, 0);
@@ -544,7 +553,30 @@ static bool dense_inverse(std::vector<double> &a, int n) {
 }
 
 // device copy of one operator with its Jacobi diagonal, spectral bound and work vectors
-int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<double> *colw) { return upload_csr(c, H, D, colw); }
+int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<double> *colw, int parts) { return upload_csr(c, H, D, colw, parts); }
+
+// C = alpha * A + B restricted to the union pattern (both with sorted columns); scale_col / scale_row (optional)
+// multiply the entries of A by s_col[j] / s_row[i] first.
+static void csr_axpby_scaled(const CsrHost &A, double alpha, const double *s_row, const double *s_col, const CsrHost &B, CsrHost &C) {
+  C.n = A.n; C.m = A.m;
+  C.rowptr.assign(A.n + 1, 0);
+  C.col.clear(); C.val.clear();
+  C.col.reserve(A.col.size() + B.col.size() / 4); C.val.reserve(A.col.size() + B.col.size() / 4);
+  for (int i = 0; i < A.n; i++) {
+    int ka = A.rowptr[i], kb = B.rowptr[i];
+    const int ea = A.rowptr[i + 1], eb = B.rowptr[i + 1];
+    const double sr = s_row ? s_row[i] : 1.0;
+    while (ka < ea || kb < eb) {
+      const int ja = ka < ea ? A.col[ka] : 0x7fffffff, jb = kb < eb ? B.col[kb] : 0x7fffffff;
+      const int j = ja < jb ? ja : jb;
+      double v = 0.0;
+      if (ja == j) { v += alpha * sr * A.val[ka] * (s_col ? s_col[j] : 1.0); ka++; }
+      if (jb == j) { v += B.val[kb]; kb++; }
+      C.col.push_back(j); C.val.push_back(v);
+    }
+    C.rowptr[i + 1] = (int)C.col.size();
+  }
+}
 
 int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol, std::vector<double> *w_out) {
   L.n = A.n;
@@ -581,12 +613,21 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
   const cfdh_options &o = c->opt;
   CsrHost A = A0;
   const int maxlev = 16;
+  // composite operators of the fused cycle: only for the damped-Jacobi V(1,1) cycle (the default smoother)
+  const char *nf = getenv("CFDH_NO_FUSED_AMG");
+  const bool want_fused = o.amg_smooth_degree == 1 && !(nf && nf[0] == '1');
+  H.fused = false; H.nnz_G0 = H.nnz_S0 = 0;
+  std::vector<double> prevW, curW;
+  CsrHost lastSc;  // Sc of the level above the current one (for the folded dense correction)
   for (;;) {
     AmgLevel *L = new AmgLevel();
     H.lev.push_back(L);
     const bool keep0 = H.keep_host0 && H.lev.size() == 1;
-    CHK(cfdh_level_setup(c, *L, A, o.amg_smooth_ratio, ncol, keep0 ? &H.h_wdinv0 : nullptr));
-    if (keep0) H.h_A0 = A;
+    std::vector<double> w;  // Jacobi weights of this level
+    CHK(cfdh_level_setup(c, *L, A, o.amg_smooth_ratio, ncol, &w));
+    if (keep0) { H.h_wdinv0 = w; H.h_A0 = A; }
+    L->fine = A.nnz() <= 12ll * A.n && A.n >= 16384;
+    prevW.swap(curW); curW = w;
     const double lm = L->lmax / 1.1;
     if (A.n <= o.amg_max_coarse || (int)H.lev.size() >= maxlev) break;
     std::vector<int> agg;
@@ -632,10 +673,29 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
     CsrHost R, AP, Ac;
     transpose_host(P, R);
     spgemm_host(A, P, AP);
-    spgemm_host(R, AP, Ac);
     CHK(upload_csr(c, P, L->P));
     if (H.keep_host0 && H.lev.size() == 1) H.h_P0 = P;
     CHK(upload_csr(c, R, L->R));
+    if (want_fused) {
+      // G = R - (R A) W ; Sb = 2W - W A W ; Sc = P - W (A P) ; A_c = (R A) P
+      CsrHost RA, G, Sb, Sc, Dg;
+      spgemm_host(R, A, RA);
+      csr_axpby_scaled(RA, -1.0, nullptr, curW.data(), R, G);
+      Dg.n = Dg.m = A.n; Dg.rowptr.resize(A.n + 1); Dg.col.resize(A.n); Dg.val.resize(A.n);
+      for (int i = 0; i < A.n; i++) { Dg.rowptr[i] = i; Dg.col[i] = i; Dg.val[i] = 2.0 * curW[i]; }
+      Dg.rowptr[A.n] = A.n;
+      csr_axpby_scaled(A, -1.0, curW.data(), curW.data(), Dg, Sb);
+      csr_axpby_scaled(AP, -1.0, curW.data(), nullptr, P, Sc);
+      spgemm_host(RA, P, Ac);
+      const int fmt = L->fine ? CFDH_UP_CSRF : CFDH_UP_CSR;
+      CHK(upload_csr(c, G, L->G, nullptr, fmt));
+      CHK(upload_csr(c, Sb, L->Sb, nullptr, L->fine ? CFDH_UP_SELL : CFDH_UP_CSR));
+      CHK(upload_csr(c, Sc, L->Sc, nullptr, L->fine ? CFDH_UP_SELL : CFDH_UP_CSR));
+      if (H.lev.size() == 1) { H.nnz_G0 = G.nnz(); H.nnz_S0 = (long long)Sb.nnz() + Sc.nnz(); }
+      lastSc.n = Sc.n; lastSc.m = Sc.m; lastSc.rowptr.swap(Sc.rowptr); lastSc.col.swap(Sc.col); lastSc.val.swap(Sc.val);
+    } else {
+      spgemm_host(R, AP, Ac);
+    }
     A.n = Ac.n; A.m = Ac.m;
     A.rowptr.swap(Ac.rowptr); A.col.swap(Ac.col); A.val.swap(Ac.val);
   }
@@ -646,12 +706,23 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
   // O(n^3) on the host for n in the ten thousands).
   H.coarse_n = 0;
   if (A.n > 2500) {
+    if (want_fused) {
+      // two damped-Jacobi sweeps from a zero guess: x = (2W - W A W) b
+      AmgLevel *L = H.lev.back();
+      CsrHost Sb, Dg;
+      Dg.n = Dg.m = A.n; Dg.rowptr.resize(A.n + 1); Dg.col.resize(A.n); Dg.val.resize(A.n);
+      for (int i = 0; i < A.n; i++) { Dg.rowptr[i] = i; Dg.col[i] = i; Dg.val[i] = 2.0 * curW[i]; }
+      Dg.rowptr[A.n] = A.n;
+      csr_axpby_scaled(A, -1.0, curW.data(), curW.data(), Dg, Sb);
+      CHK(upload_csr(c, Sb, L->Sb, nullptr, L->fine ? CFDH_UP_SELL : CFDH_UP_CSR));
+      H.fused = H.lev.size() >= 1;
+    }
     H.valid = true;
     H.fine_nnz = A0.nnz();
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->opt.verbose) {
-      fprintf(stderr, "[cfdh] AMG hierarchy (ncol %d, smoothed coarsest level):", ncol);
-      for (AmgLevel *l : H.lev) fprintf(stderr, " (%d, nnz %d)", l->n, l->A.nnz);
+      fprintf(stderr, "[cfdh] AMG hierarchy (ncol %d, smoothed coarsest level%s):", ncol, H.fused ? ", fused" : "");
+      for (AmgLevel *l : H.lev) fprintf(stderr, " (%d, nnz %d; G %d Sb %d Sc %d)", l->n, l->A.nnz, l->G.nnz, l->Sb.nnz, l->Sc.nnz);
       fprintf(stderr, "\n");
     }
     return 0;
@@ -671,13 +742,36 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
     if (!dense_inverse(D, n)) return cfdh_fail(c, CFDH_E_STATE, "singular coarsest AMG operator (n=%d)", n);
     HIPCHK(c, H.coarse_inv.upload(D, c->stream));
     H.coarse_n = n;
+    if (want_fused && H.lev.size() >= 2) {
+      H.fused = true;
+      // fold the dense coarsest solve into the up-sweep of the level above: x = Sb b + (Sc A_c^-1) b_c
+      AmgLevel *U = H.lev[H.lev.size() - 2];
+      const long long ent = (long long)lastSc.n * n;
+      U->Dn = 0;
+      if (lastSc.m == n && ent <= 8000000ll && !U->fine) {
+        std::vector<float> Df((size_t)ent);
+#pragma omp parallel for schedule(static) num_threads(cfdh_host_threads())
+        for (int i = 0; i < lastSc.n; i++) {
+          std::vector<double> acc(n, 0.0);
+          for (int k = lastSc.rowptr[i]; k < lastSc.rowptr[i + 1]; k++) {
+            const double s = lastSc.val[k];
+            const double *row = &D[(size_t)lastSc.col[k] * n];
+            for (int j = 0; j < n; j++) acc[j] += s * row[j];
+          }
+          for (int j = 0; j < n; j++) Df[(size_t)i * n + j] = (float)acc[j];
+        }
+        HIPCHK(c, U->D.upload(Df, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        U->Dn = n;
+      }
+    }
   }
   H.fine_nnz = A0.nnz();
   H.valid = true;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->opt.verbose) {
-    fprintf(stderr, "[cfdh] AMG hierarchy (ncol %d):", ncol);
-    for (AmgLevel *l : H.lev) fprintf(stderr, " (%d, nnz %d)", l->n, l->A.nnz);
+    fprintf(stderr, "[cfdh] AMG hierarchy (ncol %d%s):", ncol, H.fused ? ", fused" : "");
+    for (AmgLevel *l : H.lev) fprintf(stderr, " (%d, nnz %d; G %d Sb %d Sc %d D %d)", l->n, l->A.nnz, l->G.nnz, l->Sb.nnz, l->Sc.nnz, l->Dn);
     fprintf(stderr, "\n");
   }
   return 0;

@@ -240,8 +240,9 @@ int cfdh_comm_set_callbacks(cfdh_ctx *ctx, cfdh_allreduce_fn ar, cfdh_exchange_f
 
 /* HIP-event timing of the hot kernels on the library's stream.
  * kind 0: fused residual+Jacobian assembly, 1: monolithic SpMV, 2: tau moments,
- * 3: A00 SpMV (Chebyshev sweep, pc_type 0), 4: level-0 sweep of the pressure hierarchy,
- * 5: level-0 sweep of the velocity hierarchy (two right-hand sides),
+ * 3: A00 SpMV (Chebyshev sweep, pc_type 0), 4: level-0 up-sweep of the pressure hierarchy (x = Sb b + Sc x_c; a
+ * Jacobi sweep of the unfused cycle), 5: the same for the velocity hierarchy (two right-hand sides),
+ * 8 / 9: level-0 down-sweep (b_c = G b) of the pressure / velocity hierarchy,
  * 7: EMPTY event pairs recorded when profiling is switched on (the per-launch overhead of the method). */
 int cfdh_profile_enable(cfdh_ctx *ctx, int on);
 int cfdh_profile_get(cfdh_ctx *ctx, int kind, double *total_ms, int64_t *launches);
@@ -252,7 +253,9 @@ int cfdh_profile_reset(cfdh_ctx *ctx);
  * 11: size of the replicated coarse level below the distributed finest pressure level (0: fully replicated cycle),
  * 12: overlapping (restricted additive Schwarz) velocity cycle in use;
  * counters since cfdh_create / cfdh_profile_reset: 13 all-reduce calls, 14 halo exchanges, 15 host synchronisations
- * (stream/event waits for scalars), 16 FGMRES iterations, 17 all-gathers; 18: communicator size */
+ * (stream/event waits for scalars), 16 FGMRES iterations, 17 all-gathers; 18: communicator size;
+ * fused AMG cycle: 19 / 20 entries of Sb + Sc on level 0 (pressure / velocity hierarchy), 21 / 22 entries of G on
+ * level 0, 23 / 24 size of level 1, 25: fused cycle in use */
 int64_t cfdh_info(const cfdh_ctx *ctx, int what);
 
 #ifdef __cplusplus

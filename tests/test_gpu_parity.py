@@ -404,3 +404,32 @@ def test_stalled_coarsening_is_closed_by_smoothing_not_a_dense_inverse():
     assert time.time() - t0 < 30.0
     assert ctx.info(6) == 1  # a one-level "hierarchy"
     ctx.close()
+
+
+def test_fused_amg_cycle_is_the_same_preconditioner(monkeypatch):
+    """The fused V-cycle (one kernel per level and direction on the composite operators G = R(I - A W),
+    Sb = 2W - W A W, Sc = (I - W A)P, dense coarse solve folded into the level above) is the same linear map as the
+    sweep-by-sweep Jacobi V(1,1) cycle: identical FGMRES iteration counts step by step, same step solutions."""
+    case = dfg_case(64)   # four-level hierarchies, fine level in SELL format
+    nv = case.nv
+    runs = []
+    for nofuse in ("1", "0"):
+        monkeypatch.setenv("CFDH_NO_FUSED_AMG", nofuse)
+        ctx = make_ctx(case)
+        o = ctx.default_options()
+        o.snes_rtol, o.ksp_rtol, o.snes_stol = 1e-11, 1e-9, 0.0
+        ctx.set_options(o)
+        z2, z1 = np.zeros(2 * nv), np.zeros(nv)
+        ctx.set_state(u_prev=z2, p_prev=z1, u=z2, p=z1)
+        its = []
+        for _ in range(3):
+            st = ctx.solve_step()
+            its.append((st.newton_its, st.krylov_its))
+            ctx.advance()
+        runs.append((its, np.concatenate(ctx.get_solution()), ctx.info(25), ctx.info(6)))
+        ctx.close()
+    (its0, x0, f0, lev0), (its1, x1, f1, lev1) = runs
+    assert f0 == 0 and f1 == 1 and lev0 == lev1 >= 3
+    assert [n for n, _ in its0] == [n for n, _ in its1]
+    assert all(abs(a - b) <= 1 for (_, a), (_, b) in zip(its0, its1)), (its0, its1)
+    assert np.linalg.norm(x0 - x1) <= 1e-9 * np.linalg.norm(x0)
