@@ -19,6 +19,9 @@
 #include "quad_tri.h"
 
 #define TPB 256
+// streamed-once operands (matrix values / columns of the AMG sweeps): non-temporal loads keep them from evicting the
+// gathered vector entries out of the 32 KB L1
+#define NTLOAD(p) __builtin_nontemporal_load(p)
 
 __constant__ double d_qw[CFDH_NQ];
 __constant__ double d_ql[CFDH_NQ][3];
@@ -70,6 +73,12 @@ __device__ __forceinline__ double group8_sum(double v) {
   v += dpp_shuffle<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_shuffle<0x4E>(v);   // quad_perm [2,3,0,1]
   v += dpp_shuffle<0x141>(v);  // row_half_mirror
+  return v;
+}
+// sum over aligned groups of 4 lanes
+__device__ __forceinline__ double quad_sum(double v) {
+  v += dpp_shuffle<0xB1>(v);  // quad_perm [1,0,3,2]
+  v += dpp_shuffle<0x4E>(v);  // quad_perm [2,3,0,1]
   return v;
 }
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -1036,7 +1045,7 @@ __global__ __launch_bounds__(TPB) void sell_cheb2_scale_kernel(int n, const int 
 #pragma unroll 4
   for (int k = 0; k < w; k++) {
     const int p = p0 + k * 64 + lane;
-    a = fma((double)svalw[p], b[scol[p]], a);
+    a = fma((double)NTLOAD(svalw + p), b[NTLOAD(scol + p)], a);
   }
   const double bi = b[row];
   const double dd = wdinv[row] * bi;
@@ -1232,6 +1241,11 @@ __device__ __forceinline__ double lpr_sum(double v) {
 template <int LPR> __device__ __forceinline__ double lsum(double v) { return lpr_sum<LPR>(v); }
 template <int LPR> __device__ __forceinline__ double2 lsum(double2 v) { return make_double2(lpr_sum<LPR>(v.x), lpr_sum<LPR>(v.y)); }
 
+__device__ __forceinline__ double epi_apply(double acc, int row, double alpha, double beta, const double *zH, const double *r, const unsigned char *pbc) {
+  return (pbc[row] & 1) ? r[row] : alpha * acc + beta * zH[row];
+}
+__device__ __forceinline__ double2 epi_apply(double2 acc, int, double, double, const double *, const double *, const unsigned char *) { return acc; }
+
 // y = G x, LPR lanes per row (rows of the coarse level: tens to hundreds of entries)
 template <int LPR, typename VT, typename T>
 __global__ __launch_bounds__(TPB) void fused_down_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
@@ -1252,7 +1266,8 @@ __global__ __launch_bounds__(TPB) void fused_up_csr_kernel(int n, const int *__r
                                                            const double *__restrict__ vlB, const T *__restrict__ b,
                                                            const int *__restrict__ rpC, const int *__restrict__ clC,
                                                            const double *__restrict__ vlC, const T *__restrict__ xc,
-                                                           T *__restrict__ x) {
+                                                           T *__restrict__ x, double ea, double eb, const double *__restrict__ ezH,
+                                                           const double *__restrict__ er, const unsigned char *__restrict__ epbc) {
   const int gid = blockIdx.x * TPB + threadIdx.x;
   const int row = gid >> 3, l = gid & 7;
   T a = vzero((const T *)nullptr);
@@ -1262,7 +1277,7 @@ __global__ __launch_bounds__(TPB) void fused_up_csr_kernel(int n, const int *__r
       for (int k = rpC[row] + l, ke = rpC[row + 1]; k < ke; k += 8) a = vfma(vlC[k], xc[clC[k]], a);
   }
   a = g8(a);
-  if (row < n && l == 0) x[row] = a;
+  if (row < n && l == 0) x[row] = epbc ? epi_apply(a, row, ea, eb, ezH, er, epbc) : a;
 }
 // the same on SELL-64 (fp32 values), one lane per row
 template <typename T>
@@ -1270,7 +1285,8 @@ __global__ __launch_bounds__(TPB) void fused_up_sell_kernel(int n, const int *__
                                                             const float *__restrict__ svB, const T *__restrict__ b,
                                                             const int *__restrict__ spC, const int *__restrict__ scC,
                                                             const float *__restrict__ svC, const T *__restrict__ xc,
-                                                            T *__restrict__ x) {
+                                                            T *__restrict__ x, double ea, double eb, const double *__restrict__ ezH,
+                                                            const double *__restrict__ er, const unsigned char *__restrict__ epbc) {
   const int row = blockIdx.x * TPB + threadIdx.x;
   if (row >= n) return;
   const int sl = row >> 6, lane = row & 63;
@@ -1278,14 +1294,14 @@ __global__ __launch_bounds__(TPB) void fused_up_sell_kernel(int n, const int *__
   {
     const int p0 = spB[sl], w = (spB[sl + 1] - p0) >> 6;
 #pragma unroll 4
-    for (int k = 0; k < w; k++) { const int p = p0 + k * 64 + lane; a = vfma((double)svB[p], b[scB[p]], a); }
+    for (int k = 0; k < w; k++) { const int p = p0 + k * 64 + lane; a = vfma((double)NTLOAD(svB + p), b[NTLOAD(scB + p)], a); }
   }
   if (spC) {
     const int p0 = spC[sl], w = (spC[sl + 1] - p0) >> 6;
 #pragma unroll 4
-    for (int k = 0; k < w; k++) { const int p = p0 + k * 64 + lane; a = vfma((double)svC[p], xc[scC[p]], a); }
+    for (int k = 0; k < w; k++) { const int p = p0 + k * 64 + lane; a = vfma((double)NTLOAD(svC + p), xc[NTLOAD(scC + p)], a); }
   }
-  x[row] = a;
+  x[row] = epbc ? epi_apply(a, row, ea, eb, ezH, er, epbc) : a;
 }
 // x = Sb b + D bc with the dense folded coarse correction D [n][nc] (fp32), one wave per row
 template <typename T>
@@ -1320,7 +1336,9 @@ static void launch_down(cfdh_ctx *c, const CsrDev &G, const VT *val, const T *x,
 template <typename T>
 static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof) {
   const int nl = (int)H.lev.size();
-  // down: right-hand sides of all coarse levels
+  // down: right-hand sides of all coarse levels.  (Merging the coarse levels' down-sweeps into one launch through the
+  // products G_2 G_1, ... was measured and dropped: the products fill in -- 1.1 M entries for a 713-row level -- and the one
+  // launch costs more than the two it replaces.)
   for (int l = 0; l + 1 < nl; l++) {
     AmgLevel *L = H.lev[l], *N = H.lev[l + 1];
     const T *src = l == 0 ? b : (const T *)L->b.p;
@@ -1348,11 +1366,13 @@ static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof) 
       else if (L->fine)
         hipLaunchKernelGGL((fused_up_sell_kernel<T>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
                            L->Sb.sptr.p, L->Sb.scol.p, L->Sb.sval.p, bl, (const int *)nullptr, (const int *)nullptr,
-                           (const float *)nullptr, (const T *)nullptr, xl);
+                           (const float *)nullptr, (const T *)nullptr, xl, 0.0, 0.0, (const double *)nullptr, (const double *)nullptr,
+                           (const unsigned char *)nullptr);
       else
         hipLaunchKernelGGL((fused_up_csr_kernel<T>), dim3((unsigned)((8ll * L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
                            L->Sb.rowptr.p, L->Sb.col.p, L->Sb.val.p, bl, (const int *)nullptr, (const int *)nullptr,
-                           (const double *)nullptr, (const T *)nullptr, xl);
+                           (const double *)nullptr, (const T *)nullptr, xl, 0.0, 0.0, (const double *)nullptr, (const double *)nullptr,
+                           (const unsigned char *)nullptr);
       l = nl - 2;
     }
   }
@@ -1361,13 +1381,21 @@ static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof) 
     AmgLevel *L = H.lev[l], *N = H.lev[l + 1];
     const T *bl = l == 0 ? b : (const T *)L->b.p;
     T *xl = l == 0 ? x : (T *)L->x.p;
+    // Cahouet-Chabard combination in the epilogue of the last kernel of the (single right-hand side) pressure cycle
+    const bool epi = l == 0 && c->epi.on && sizeof(T) == sizeof(double);
+    const double ea = epi ? c->epi.alpha : 0.0, eb = epi ? c->epi.beta : 0.0;
+    const double *ezH = epi ? c->epi.zH : nullptr, *er = epi ? c->epi.r : nullptr;
+    const unsigned char *epbc = epi ? c->epi.pbc : nullptr;
+    if (epi) { xl = (T *)c->epi.out; c->epi.done = true; }
     if (prof && l == 0) prof_begin(c, prof);
     if (L->fine)
       hipLaunchKernelGGL((fused_up_sell_kernel<T>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
-                         L->Sb.sptr.p, L->Sb.scol.p, L->Sb.sval.p, bl, L->Sc.sptr.p, L->Sc.scol.p, L->Sc.sval.p, (const T *)N->x.p, xl);
+                         L->Sb.sptr.p, L->Sb.scol.p, L->Sb.sval.p, bl, L->Sc.sptr.p, L->Sc.scol.p, L->Sc.sval.p, (const T *)N->x.p, xl,
+                         ea, eb, ezH, er, epbc);
     else
       hipLaunchKernelGGL((fused_up_csr_kernel<T>), dim3((unsigned)((8ll * L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
-                         L->Sb.rowptr.p, L->Sb.col.p, L->Sb.val.p, bl, L->Sc.rowptr.p, L->Sc.col.p, L->Sc.val.p, (const T *)N->x.p, xl);
+                         L->Sb.rowptr.p, L->Sb.col.p, L->Sb.val.p, bl, L->Sc.rowptr.p, L->Sc.col.p, L->Sc.val.p, (const T *)N->x.p, xl,
+                         ea, eb, ezH, er, epbc);
     if (prof && l == 0) prof_end(c, prof);
   }
   HIPCHK(c, hipGetLastError());
@@ -1737,6 +1765,8 @@ __global__ __launch_bounds__(TPB) void multidot_kernel(int n, const double *__re
     __syncthreads();
   }
 }
+// (A "last block does the final reduction" variant was measured and dropped: the device-scope release fence every
+// block needs before taking its ticket writes the XCD's L2 back -- 133 us per launch against 17 + 4 us for two kernels.)
 // h_dev[0..nvec) = V^T w (and h_dev[nvec] = w.w when with_ww), reduced over all ranks
 int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror) {
   const int nb = MD_NB, nout = nvec + (with_ww ? 1 : 0);
@@ -1779,6 +1809,33 @@ __global__ __launch_bounds__(TPB) void multiaxpy_kernel(int n, const double *__r
 }
 int v_multiaxpy(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, double *w) {
   hipLaunchKernelGGL(multiaxpy_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, h_dev, w, -1.0);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+__global__ __launch_bounds__(TPB) void gs_update_normalize_kernel(int n, const double *__restrict__ V, size_t ld, int nvec,
+                                                                 const double *__restrict__ h, const double *__restrict__ w,
+                                                                 double *__restrict__ vn, double *__restrict__ s_out) {
+  const double ww = h[nvec];
+  double hh2 = 0.0;
+  for (int v = 0; v < nvec; v++) hh2 += h[v] * h[v];
+  const double nrm2 = ww - hh2;
+  const double s = (nrm2 > 0.0 && nrm2 <= ww) ? sqrt(nrm2) : sqrt(ww);  // cancellation: any positive scale, the caller re-orthogonalises
+  const double inv = s > 0.0 ? 1.0 / s : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *s_out = s;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+    double a0 = w[i], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int v = 0;
+    for (; v + 4 <= nvec; v += 4) {
+      const double x0 = V[(size_t)v * ld + i], x1 = V[(size_t)(v + 1) * ld + i], x2 = V[(size_t)(v + 2) * ld + i],
+                   x3 = V[(size_t)(v + 3) * ld + i];
+      a0 -= h[v] * x0; a1 -= h[v + 1] * x1; a2 -= h[v + 2] * x2; a3 -= h[v + 3] * x3;
+    }
+    for (; v < nvec; v++) a0 -= h[v] * V[(size_t)v * ld + i];
+    vn[i] = ((a0 + a1) + (a2 + a3)) * inv;
+  }
+}
+int v_gs_update_normalize(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, const double *w, double *vn, double *s_dev) {
+  hipLaunchKernelGGL(gs_update_normalize_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, h_dev, w, vn, s_dev);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -391,9 +391,16 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
           CHK(k_amg_vcycle(c, c->hLg, c->gp_rhs.p, c->gp_sol.p));  // the same global V-cycle on every rank
           CHK(k_gather_global(c, nvo, c->gp_l2g.p, c->gp_sol.p, c->pu2.p));
         } else {
-          CHK(k_amg_vcycle(c, c->hL, c->pu1.p, c->pu2.p));
+          // rank-local cycle: the combination below runs in the epilogue of its last kernel when the fused cycle is used
+          c->epi.on = true; c->epi.done = false;
+          c->epi.alpha = c->cc_alpha; c->epi.beta = c->cc_beta; c->epi.zH = c->pp1.p; c->epi.r = upper ? rp : c->pp0.p;
+          c->epi.pbc = c->ccPbc.p; c->epi.out = zp;
+          const int rc = k_amg_vcycle(c, c->hL, c->pu1.p, c->pu2.p);
+          c->epi.on = false;
+          CHK(rc);
         }
-        CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, upper ? rp : c->pp0.p, c->ccPbc.p, zp));
+        if (c->epi.done) c->epi.done = false;
+        else CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, upper ? rp : c->pp0.p, c->ccPbc.p, zp));
         if (multi && c->opt.schur_full) CHK(v_copy(c, nvo, zp, c->pcw.p + nu));  // z_p into the halo scratch vector
         return 0;
       case 3:
@@ -568,7 +575,10 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       // h (all-reduced in a partitioned run) sits in the host-mapped scratch: wait for THAT only, the update of w
       // below overlaps with the host's Hessenberg bookkeeping and the next launches
       HIPCHK(c, hipEventRecord(c->ev_h, c->stream));
-      CHK(v_multiaxpy(c, n, V, (int)ld, j + 1, hd, w));
+      // v_{j+1} = (w - V h) / s with s = sqrt(w.w - |h|^2) formed on the device from the reduced coefficients: update and
+      // normalisation in one pass (the host forms the same norm for the Hessenberg matrix from its copy of h)
+      double *s_dev = hd + 2 * (m + 2) + 1;
+      CHK(v_gs_update_normalize(c, n, V, (int)ld, j + 1, hd, w, vn, s_dev));
       c->n_host_sync++;
       HIPCHK(c, hipEventSynchronize(c->ev_h));
       double ww = c->h_pinned[j + 1], hh2 = 0.0;
@@ -581,17 +591,19 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       bool refine = !(nrm2 > eta2 * ww);
       double hnorm;
       if (refine) {
-        CHK(v_multidot(c, n, V, (int)ld, j + 1, w, hd + (m + 2), false));
-        CHK(v_multiaxpy(c, n, V, (int)ld, j + 1, hd + (m + 2), w));
-        CHK(v_norm_to_dev(c, n, w, hd + 2 * (m + 2)));
-        HIPCHK(c, hipMemcpyAsync(c->h_pinned, hd + (m + 2), sizeof(double) * (m + 3), hipMemcpyDeviceToHost, c->stream));
+        // second Gram-Schmidt pass on the (already scaled) vector: vn = w'/s  ->  h2 = V^T vn, vn -= V h2, vn /= |vn|;
+        // in terms of w: h += s h2, |w''| = s |vn|
+        CHK(v_multidot(c, n, V, (int)ld, j + 1, vn, hd + (m + 2), false));
+        CHK(v_multiaxpy(c, n, V, (int)ld, j + 1, hd + (m + 2), vn));
+        CHK(v_norm_to_dev(c, n, vn, hd + 2 * (m + 2)));
+        HIPCHK(c, hipMemcpyAsync(c->h_pinned, hd + (m + 2), sizeof(double) * (m + 4), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int i = 0; i <= j; i++) hh[i] += c->h_pinned[i];
-        hnorm = c->h_pinned[m + 2];
-        CHK(v_scale_inv_dev(c, n, w, hd + 2 * (m + 2), vn));
+        const double s = c->h_pinned[m + 3];
+        for (int i = 0; i <= j; i++) hh[i] += s * c->h_pinned[i];
+        hnorm = s * c->h_pinned[m + 2];
+        CHK(v_scale_inv_dev(c, n, vn, hd + 2 * (m + 2), vn));
       } else {
         hnorm = std::sqrt(nrm2);
-        CHK(v_scale_to(c, n, 1.0 / hnorm, w, vn));
       }
       double *Hj = &H[(size_t)j * (m + 1)];
       for (int i = 0; i <= j; i++) Hj[i] = hh[i];
