@@ -43,7 +43,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp)
 SYMBOLS = [
     "cfdh_create", "cfdh_set_facet_markers", "cfdh_destroy", "cfdh_last_error", "cfdh_abi_version", "cfdh_set_params", "cfdh_default_options",
     "cfdh_set_options", "cfdh_clear_dirichlet", "cfdh_add_dirichlet", "cfdh_set_state", "cfdh_get_solution",
-    "cfdh_get_previous", "cfdh_get_residual", "cfdh_advance", "cfdh_set_time_scheme", "cfdh_set_previous2", "cfdh_get_previous2",
+    "cfdh_get_previous", "cfdh_get_residual", "cfdh_advance", "cfdh_advance_field", "cfdh_set_time_scheme", "cfdh_set_previous2", "cfdh_get_previous2",
     "cfdh_shift_history", "cfdh_set_boundary_terms", "cfdh_assemble", "cfdh_get_csr", "cfdh_spmv", "cfdh_solve_step",
     "cfdh_functional", "cfdh_wall_shear_stress", "cfdh_set_global_pressure_space", "cfdh_set_halo", "cfdh_comm_unique_id", "cfdh_comm_init", "cfdh_comm_set_callbacks",
     "cfdh_profile_enable", "cfdh_profile_get", "cfdh_profile_reset", "cfdh_info",
@@ -97,6 +97,7 @@ def lib():
     L.cfdh_get_residual.argtypes = [vp, dp, dp]
     L.cfdh_get_previous.argtypes = [vp, dp, dp]
     L.cfdh_advance.argtypes = [vp]
+    L.cfdh_advance_field.argtypes = [vp, C.c_int]
     L.cfdh_assemble.argtypes = [vp, C.c_int]
     L.cfdh_get_csr.argtypes = [vp, lp, ip, ip, dp]
     L.cfdh_spmv.argtypes = [vp, dp, dp]
@@ -223,6 +224,9 @@ class Context:
 
     def advance(self):
         self._chk(self.L.cfdh_advance(self.h))
+
+    def advance_field(self, field):
+        self._chk(self.L.cfdh_advance_field(self.h, int(field)))
 
     def set_time_scheme(self, theta, a0, a1, a2):
         self._chk(self.L.cfdh_set_time_scheme(self.h, float(theta), float(a0), float(a1), float(a2)))

@@ -248,6 +248,20 @@ int cfdh_advance(cfdh_ctx *c) {
   return 0;
 }
 
+int cfdh_advance_field(cfdh_ctx *c, int field) {
+  ENTER(c);
+  const size_t nu = 2 * (size_t)c->nvo;
+  if (field == 0) {
+    CHK(v_copy(c, (int)nu, c->x.p, c->xprev.p));  // ghost entries follow with the halo exchange before the next assembly
+    c->mom_valid = false;
+  } else if (field == 1) {
+    CHK(v_copy(c, c->nvo, c->x.p + nu, c->xprev.p + nu));
+  } else {
+    return cfdh_fail(c, CFDH_E_ARG, "cfdh_advance_field: field must be 0 (velocity) or 1 (pressure)");
+  }
+  return 0;
+}
+
 int cfdh_set_time_scheme(cfdh_ctx *c, double theta, double a0, double a1, double a2) {
   ENTER(c);
   if (!(theta > 0) || theta > 1 || !(a0 > 0)) return cfdh_fail(c, CFDH_E_ARG, "time scheme needs 0 < theta <= 1 and a0 > 0");

@@ -156,17 +156,13 @@ struct cfdh_ctx {
 
   // incidences (row vertex, cell), grouped in workgroup blocks of whole rows
   int ninc = 0, nblk = 0;
-  dbuf<int> inc_cell;        // cell*4 + local index of the row vertex
-  dbuf<int> inc_row;         // row (internal owned vertex)
   dbuf<unsigned> inc_slot;   // per lane: slot0 | slot1<<8 | slot2<<16 | a<<24 | emit_v2<<26 | has_prev<<27
   dbuf<unsigned> inc_rank;   // per lane: position in row | row length<<8 | (lane offset of the fan predecessor + 64)<<16
   dbuf<int> blk_row;         // [nblk+1]
-  dbuf<int> blk_inc;         // [nblk+1] first incidence of the block
   dbuf<int> blk_vptr, blk_vlist;  // per-block list of the vertices its cells touch
   dbuf<int> blk_cptr, blk_clist;  // per-block list of distinct cells
   dbuf<unsigned> inc_loc;    // per lane: lcell | lv0<<8 | lv1<<16 | lv2<<24 (block-local, rotated); ~0u = idle lane
   dbuf<int> wave_maxlen;     // per wavefront: longest row (bound of the segmented reduction)
-  dbuf<int> blk_maxrank;     // [nblk]
 
   // Dirichlet data (host master copies in internal numbering)
   std::vector<unsigned char> h_bcflag;  // bit0 ux, bit1 uy, bit2 p

@@ -1,13 +1,19 @@
 // Hand-written gfx950 (CDNA4, wave64) kernels of the stabilized_schur hot path.
 //
 //  * k_moments    : tau / tau_LSIC moments per cell (stabilized_schur.py:100-118)
-//  * asm_kernel   : fused element residual + Jacobian, one lane per
-//                   (row vertex, cell) incidence, accumulation in LDS in fixed
-//                   rounds (bitwise reproducible, no global atomics), coalesced
-//                   write-out of whole CSR row segments (stabilized_schur.py:67-123,
-//                   144-175,185-189)
+//  * asm_kernel   : fused element residual + Jacobian, one lane per (row vertex, cell)
+//                   incidence; patch data staged in LDS; the cells of a vertex form a
+//                   counter-clockwise fan, so off-diagonal blocks are completed by one
+//                   lane shuffle and the diagonal block / residual by a segmented
+//                   wavefront reduction -- no LDS accumulation, no atomics, fixed order
+//                   (bitwise reproducible); plain stores of complete 3x3 blocks
+//                   (stabilized_schur.py:67-123,144-175,185-189)
 //  * spmv kernels : 8 lanes per vertex row over the block CSR, DPP reductions
-//  * Chebyshev / AMG / vector kernels for the Krylov solver
+//  * AMG          : fused V(1,1) Jacobi cycle on composite operators (one kernel per level
+//                   and direction), SELL-64 / fp32 on the fine levels, dense coarse solve
+//                   folded into the level above; sweep-by-sweep cycle for the other smoothers
+//                   and the distributed finest level of a partitioned run
+//  * vector kernels of FGMRES (fused multi-dot, Gram-Schmidt update + normalisation)
 //
 // Everything is HBM-bound fp64 stream/gather work; MFMA is not used (nothing
 // here is a dense contraction).  Algebra: SURVEY.md Appendix A / DESIGN.md.
@@ -181,7 +187,7 @@ int k_moments(cfdh_ctx *c) {
 // ---------------------------------------------------------------- fused assembly
 struct AsmArgs {
   const double *coords, *mom, *x, *un, *un2, *bcval, *bcmult;
-  const int *vptr, *vdiag, *inc_cell, *blk_row, *blk_inc, *blk_maxrank, *blk_vptr, *blk_vlist, *blk_cptr, *blk_clist, *wave_maxlen;
+  const int *vptr, *blk_row, *blk_vptr, *blk_vlist, *blk_cptr, *blk_clist, *wave_maxlen;
   const unsigned *inc_slot, *inc_rank, *inc_loc;
   const unsigned char *cflag, *bcflag;
   double *A00, *A01, *A10, *A11, *F;
@@ -574,9 +580,9 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
 int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
   AsmArgs a;
   a.coords = c->coords.p; a.mom = c->mom.p; a.x = xstate; a.un = c->xprev.p; a.un2 = c->xprev2.p; a.bcval = c->bcval.p; a.bcmult = c->bcmult.p;
-  a.vptr = c->vptr.p; a.vdiag = c->vdiag.p; a.inc_cell = c->inc_cell.p;
+  a.vptr = c->vptr.p;
   a.blk_vptr = c->blk_vptr.p; a.blk_vlist = c->blk_vlist.p; a.blk_cptr = c->blk_cptr.p; a.blk_clist = c->blk_clist.p; a.inc_loc = c->inc_loc.p; a.wave_maxlen = c->wave_maxlen.p;
-  a.blk_row = c->blk_row.p; a.blk_inc = c->blk_inc.p; a.blk_maxrank = c->blk_maxrank.p;
+  a.blk_row = c->blk_row.p;
   a.inc_slot = c->inc_slot.p; a.inc_rank = c->inc_rank.p; a.cflag = c->cflag.p; a.bcflag = c->bcflag.p;
   a.A00 = c->A00.p; a.A01 = c->A01.p; a.A10 = c->A10.p; a.A11 = c->A11.p; a.F = c->F.p;
   a.nvo = c->nvo; a.dt = c->dt; a.rho = c->rho; a.mu = c->mu; a.muf = c->muf; a.fx = c->f[0]; a.fy = c->f[1];

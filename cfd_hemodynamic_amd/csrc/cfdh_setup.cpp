@@ -235,7 +235,7 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
   }
   // ---- pack whole rows into wavefronts (64 lanes) and 4 wavefronts into a workgroup; every
   // workgroup carries compact lists of the vertices and cells it touches (staged in LDS)
-  std::vector<int> blk_row(1, 0), blk_maxrank, blk_inc(1, 0), blk_vptr(1, 0), blk_cptr(1, 0), blk_vlist, blk_clist;
+  std::vector<int> blk_row(1, 0), blk_vptr(1, 0), blk_cptr(1, 0), blk_vlist, blk_clist;
   std::vector<unsigned> lane_loc, lane_meta, lane_seg;   // per lane of every workgroup (0xFFFFFFFF = idle lane)
   std::vector<int> wave_maxlen;
   {
@@ -288,14 +288,13 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
       lane_meta.insert(lane_meta.end(), bmeta.begin(), bmeta.end());
       lane_seg.insert(lane_seg.end(), bseg.begin(), bseg.end());
       for (int w = 0; w < CFDH_MAX_INC / 64; w++) wave_maxlen.push_back(wmaxes[w]);
-      blk_row.push_back(r1); blk_maxrank.push_back(wmax); blk_inc.push_back(vcptr[r1]);
+      blk_row.push_back(r1);
       blk_vptr.push_back((int)blk_vlist.size()); blk_cptr.push_back((int)blk_clist.size());
       r0 = r1; bid++;
     }
   }
-  std::vector<int> inc_cell(1, 0), inc_row(1, 0);
   std::vector<unsigned> inc_slot(lane_meta), inc_rank(lane_seg), inc_loc(lane_loc);
-  c->nblk = (int)blk_maxrank.size();
+  c->nblk = (int)blk_row.size() - 1;
 
   // ---- uploads
   hipStream_t s = c->stream;
@@ -312,13 +311,9 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, cons
   HIPCHK(c, c->A01.alloc(2 * (size_t)c->nnzv));
   HIPCHK(c, c->A10.alloc(2 * (size_t)c->nnzv));
   HIPCHK(c, c->A11.alloc((size_t)c->nnzv));
-  HIPCHK(c, c->inc_cell.upload(inc_cell, s));
-  HIPCHK(c, c->inc_row.upload(inc_row, s));
   HIPCHK(c, c->inc_slot.upload(inc_slot, s));
   HIPCHK(c, c->inc_rank.upload(inc_rank, s));
   HIPCHK(c, c->blk_row.upload(blk_row, s));
-  HIPCHK(c, c->blk_maxrank.upload(blk_maxrank, s));
-  HIPCHK(c, c->blk_inc.upload(blk_inc, s));
   HIPCHK(c, c->blk_vptr.upload(blk_vptr, s)); HIPCHK(c, c->blk_cptr.upload(blk_cptr, s));
   HIPCHK(c, c->blk_vlist.upload(blk_vlist, s)); HIPCHK(c, c->blk_clist.upload(blk_clist, s));
   HIPCHK(c, c->inc_loc.upload(inc_loc, s));

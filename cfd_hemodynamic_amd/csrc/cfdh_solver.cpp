@@ -1,12 +1,16 @@
 // Host driver of the per-step solve (stabilized_schur.py:313-334): Newton with a
 // backtracking line search (SNES newtonls/bt), right-preconditioned FGMRES
-// (KSPFGMRES, restart/caps of :272-273) and a GPU block-Schur preconditioner
-//     z_u = C(A00) r_u ;  z_p = V(Sp)(r_p - A10 z_u) ;  z_u = C(A00)(r_u - A01 z_p)
-// with C = Jacobi-Chebyshev polynomial and V = one smoothed-aggregation V-cycle
-// on the (lagged) SELFP matrix Sp = A11 - A10 diag(A00)^-1 A01 -- the same
-// factorisation the reference configures (PCFIELDSPLIT Schur FULL / SELFP,
-// :231-235) with GPU-friendly sub-solvers instead of GMRES+ILU(0)/ILU(0).
-// All vectors stay in HBM; the host sees a few scalars per iteration.
+// (KSPFGMRES, restart/caps of :272-273) and a GPU block-Schur preconditioner in
+// the factorisation the reference configures (PCFIELDSPLIT Schur, :231-235) with
+// GPU-friendly sub-solvers instead of GMRES+ILU(0)/ILU(0):
+//   pc_type 1 (default): velocity block = one AMG V-cycle of the scalar proxy of A00
+//     (both components at once); Schur complement of Cahouet-Chabard type,
+//     S^-1 ~ (a' L^-1 + b' M_l^-1) H^-1 -- Chebyshev(2) on the mass-like H, one AMG
+//     V-cycle on the P1 Laplacian L; block upper-triangular (default) / FULL / lower;
+//   pc_type 0: the reference's SELFP matrix Sp = A11 - A10 diag(A00)^-1 A01 with an
+//     AMG V-cycle, Jacobi-Chebyshev on A00.
+// Hierarchies are built on the host and lagged.  All vectors stay in HBM; the host
+// sees a few scalars per iteration.
 #include <algorithm>
 #include <chrono>
 #include <cmath>

@@ -57,23 +57,97 @@ def functionspace(mesh, element):
     return FunctionSpace(mesh, bs)
 
 
+def _is_whole(key):
+    return isinstance(key, slice) and key == slice(None, None, None) or key is Ellipsis
+
+
+class _LazyArray(np.lib.mixins.NDArrayOperatorsMixin):
+    """What `Function.x.array` hands out for a field that lives in HBM: an array-like that touches the host copy
+    only when its data are really needed (then it downloads / marks the host copy dirty exactly like a plain
+    access did before).  The one idiom it keeps on the device is the reference's state copy
+
+        u_prev.x.array[:] = u_sol.x.array[:]          (/root/reference/src/scenario.py:306-307)
+
+    a whole-array assignment from a sibling field, which becomes a device-to-device copy (cfdh_advance_field)
+    instead of a 24 MB round trip over PCIe per field and step.  Everything else (indexing, ufuncs, numpy functions,
+    ndarray methods) sees the synchronised host array."""
+
+    __slots__ = ("_vec",)
+
+    def __init__(self, vec):
+        object.__setattr__(self, "_vec", vec)
+
+    def _real(self):
+        return self._vec._materialise()
+
+    # --- cheap metadata: no synchronisation
+    shape = property(lambda self: self._vec._array.shape)
+    dtype = property(lambda self: self._vec._array.dtype)
+    size = property(lambda self: self._vec._array.size)
+    ndim = property(lambda self: 1)
+
+    def __len__(self):
+        return len(self._vec._array)
+
+    # --- data access
+    def __array__(self, dtype=None, copy=None):
+        a = self._real()
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        conv = lambda v: v._real() if isinstance(v, _LazyArray) else v
+        if "out" in kwargs:
+            kwargs["out"] = tuple(conv(o) for o in kwargs["out"])
+        return getattr(ufunc, method)(*(conv(v) for v in inputs), **kwargs)
+
+    def __getitem__(self, key):
+        if _is_whole(key):
+            return _LazyArray(self._vec)  # `a[:]` of a whole field: still lazy
+        return self._real()[key]
+
+    def __setitem__(self, key, value):
+        if _is_whole(key) and isinstance(value, _LazyArray) and self._vec._assign_on_device(value._vec):
+            return
+        self._real()[key] = value._real() if isinstance(value, _LazyArray) else value
+
+    def __iter__(self):
+        return iter(self._real())
+
+    def __getattr__(self, name):  # ndarray methods / attributes: reshape, copy, max, ...
+        return getattr(self._real(), name)
+
+    def __repr__(self):
+        return "lazy(%r)" % (self._real(),)
+
+
 class _Vector:
-    """`Function.x`: owns the host array; `array` access can be observed by a
-    device-resident solver (lazy download before a host read, host-dirty mark
-    after the view was handed out)."""
+    """`Function.x`: owns the host array.  A device-resident solver installs hooks: `_pre_access` (download before
+    a host read), `_post_access` (host-dirty mark once the host array was handed out) and `_assign_hook`
+    (whole-field assignment from another field, done on the device when possible)."""
 
     def __init__(self, n):
         self._array = np.zeros(n, dtype=np.float64)
         self._pre_access = None  # callable() -> None, run before handing out the view
         self._post_access = None
+        self._assign_hook = None  # callable(src_vector) -> bool (True: handled on the device)
 
-    @property
-    def array(self):
+    def _materialise(self):
         if self._pre_access is not None:
             self._pre_access()
         if self._post_access is not None:
             self._post_access()
         return self._array
+
+    def _assign_on_device(self, src):
+        return bool(self._assign_hook(src)) if self._assign_hook is not None else False
+
+    @property
+    def array(self):
+        if self._pre_access is None and self._post_access is None and self._assign_hook is None:
+            return self._array
+        return _LazyArray(self)
 
     def scatter_forward(self):
         return None

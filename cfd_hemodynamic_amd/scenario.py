@@ -212,7 +212,7 @@ class Scenario(ABC):
         solver.assemble_wss()
         if output_folder:
             # reading `x.array` gathers the owned slices in a partitioned run: every rank takes part, rank 0 writes
-            fields = dict(velocity=solver.u_sol.x.array, pressure=solver.p_sol.x.array, wss=solver.shear_stress.x.array)
+            fields = {k: np.asarray(f.x.array) for k, f in (('velocity', solver.u_sol), ('pressure', solver.p_sol), ('wss', solver.shear_stress))}
             if mesh.comm.rank == 0:
                 with open(os.path.join(output_folder, "norms.txt"), "w") as f:
                     f.write(f"L2 norm of velocity: {norm_v}\n")

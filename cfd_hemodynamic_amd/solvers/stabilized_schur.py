@@ -70,6 +70,7 @@ class Solver(SolverBase):
         self._dev_newer = {"sol": False, "res": False, "wss": False}
         self._prev_host_dirty = True
         self._prev_dev_newer = False
+        self.transfers = {"downloads": 0, "uploads": 0}  # whole-field host <-> device copies since construction
         self._u_sol.x._pre_access = self._sync_solution
         self._p_sol.x._pre_access = self._sync_solution
         self.u_residual.x._pre_access = self._sync_residual
@@ -78,6 +79,9 @@ class Solver(SolverBase):
         self._p_prev.x._pre_access = self._sync_previous
         self._u_prev.x._post_access = self._mark_prev_dirty
         self._p_prev.x._post_access = self._mark_prev_dirty
+        # `u_prev.x.array[:] = u_sol.x.array[:]` (scenario.py:306-307) stays on the device
+        self._u_prev.x._assign_hook = lambda src: self._assign_previous(0, src)
+        self._p_prev.x._assign_hook = lambda src: self._assign_previous(1, src)
 
     # -- global <-> local (identity on one GPU) ------------------------------------
     def _loc_u(self, a):
@@ -99,6 +103,7 @@ class Solver(SolverBase):
     def _sync_solution(self):
         if self._dev_newer["sol"]:
             self._dev_newer["sol"] = False
+            self.transfers["downloads"] += 1
             lu, lp = self.ctx.get_solution()
             self._store(self._u_sol.x._array, self._p_sol.x._array, lu, lp)
 
@@ -127,11 +132,26 @@ class Solver(SolverBase):
     def _sync_previous(self):
         if self._prev_dev_newer:
             self._prev_dev_newer = False
+            self.transfers["downloads"] += 1
             lu, lp = self.ctx.get_previous()
             self._store(self._u_prev.x._array, self._p_prev.x._array, lu, lp)
 
     def _mark_prev_dirty(self):
         self._prev_host_dirty = True
+
+    def _assign_previous(self, field, src):
+        """Whole-field assignment `u_prev <- u_sol` / `p_prev <- p_sol` as a device-to-device copy.  Possible when the
+        source is this solver's solution field and the device holds its current values; anything else goes through
+        the host as before (returns False)."""
+        if src is not (self._u_sol.x if field == 0 else self._p_sol.x) or not self._dev_newer["sol"]:
+            return False
+        if self._prev_host_dirty and not self._prev_dev_newer:
+            # host writes to u_prev / p_prev not uploaded yet: bring the device up to date before overwriting one field
+            self.ctx.set_state(u_prev=self._loc_u(self._u_prev.x._array), p_prev=self._loc_p(self._p_prev.x._array))
+        self._prev_host_dirty = False
+        self.ctx.advance_field(field)
+        self._prev_dev_newer = True  # the host copies of u_prev / p_prev are stale now
+        return True
 
     # -- reference API ---------------------------------------------------------
     def setup(self, bcu: list[BoundaryCondition], bcp: list[BoundaryCondition], facet_tags=None, tags=None) -> None:
@@ -201,6 +221,7 @@ class Solver(SolverBase):
             bc.update()  # stabilized_schur.py:170
         self._upload_bcs()
         if self._prev_host_dirty and not self._prev_dev_newer:
+            self.transfers["uploads"] += 1
             self.ctx.set_state(u_prev=self._loc_u(self._u_prev.x._array), p_prev=self._loc_p(self._p_prev.x._array))
         self._prev_host_dirty = False
         st = self.ctx.solve_step()  # raises RuntimeError("Did not converge, reason: r.") like :332-334

@@ -148,6 +148,9 @@ int cfdh_get_previous(cfdh_ctx *ctx, double *u_prev, double *p_prev);
 int cfdh_get_residual(cfdh_ctx *ctx, double *ru, double *rp);
 /* device-side u_prev <- u_sol, p_prev <- p_sol (scenario.py:306-307) */
 int cfdh_advance(cfdh_ctx *ctx);
+/* one line of that copy: field 0: u_prev <- u_sol (scenario.py:306), field 1: p_prev <- p_sol (:307); lets a binding
+ * map the reference's literal `u_prev.x.array[:] = u_sol.x.array[:]` onto the device without a host round trip */
+int cfdh_advance_field(cfdh_ctx *ctx, int field);
 
 /* ---- time scheme (the `stabilized_schur_bdf2` variant) ------------------------ */
 

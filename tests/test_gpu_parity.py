@@ -205,6 +205,45 @@ def test_solver_class_and_scenario_drop_in():
     assert a.solver.shear_stress.x.array.any()
 
 
+def test_literal_state_copy_of_the_reference_loop_stays_on_the_device():
+    """`u_prev.x.array[:] = u_sol.x.array[:]` (scenario.py:306-307) through the lazy array proxy: no whole-field
+    transfer in either direction, bitwise the same fields as the `advance()` loop; ordinary host access still sees
+    current data, and a host write to u_prev is still picked up by the next step."""
+    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+    a = DFG1Benchmark("stabilized_schur", 0.01, 1.0, m=12, quiet=True)
+    b = DFG1Benchmark("stabilized_schur", 0.01, 1.0, m=12, quiet=True)
+    t0 = dict(b.solver.transfers)
+    for _ in range(3):
+        a.solver.solveStep()
+        a.solver.advance()
+        b.solver.solveStep()
+        b.solver.u_prev.x.array[:] = b.solver.u_sol.x.array[:]
+        b.solver.p_prev.x.array[:] = b.solver.p_sol.x.array[:]
+    assert b.solver.transfers == t0
+    assert np.array_equal(np.asarray(a.solver.u_sol.x.array), np.asarray(b.solver.u_sol.x.array))
+    assert np.array_equal(a.solver.u_prev.x.array.copy(), b.solver.u_prev.x.array.copy())  # downloads on demand
+    assert b.solver.transfers["downloads"] == t0["downloads"] + 2
+    assert np.array_equal(a.solver.p_prev.x.array[:], b.solver.p_sol.x.array[:])
+    # numpy semantics of the proxy
+    u = b.solver.u_sol.x.array
+    assert u.shape == (2 * b.mesh.num_vertices,) and len(u) == u.size and u.dtype == np.float64
+    assert np.linalg.norm(u, ord=np.inf) == np.abs(u).max() == u.reshape(-1, 2).__abs__().max()
+    assert float((u - u)[0]) == 0.0 and (2.0 * u)[3] == 2.0 * u[3]
+    # a host write goes through the host path and reaches the device at the next step
+    b.solver.u_prev.x.array[:] = 0.0
+    b.solver.p_prev.x.array[:] = np.zeros(b.mesh.num_vertices)
+    n_up = b.solver.transfers["uploads"]
+    b.solver.solveStep()
+    assert b.solver.transfers["uploads"] == n_up + 1
+    up, _ = b.solver.ctx.get_previous()
+    assert not up.any()
+    # assignment from a foreign array-like is not mistaken for the device idiom
+    other = DFG1Benchmark("stabilized_schur", 0.01, 1.0, m=12, quiet=True)
+    other.solver.solveStep()
+    b.solver.u_prev.x.array[:] = other.solver.u_sol.x.array[:]
+    assert np.array_equal(np.asarray(b.solver.u_prev.x.array), np.asarray(other.solver.u_sol.x.array))
+
+
 def test_time_dependent_dirichlet_values():
     """bc.update() re-reads the source every step (stabilized_schur.py:170): a pulsatile inlet
     `v(t) = v0 (1 + 0.5 sin 2 pi t)` through the Function the BoundaryCondition wraps."""
