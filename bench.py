@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
-"""Headline benchmark: time steps per second of the stabilized_schur step on the
-DFG 2D-1 mesh refined to ~1M P1/P1 DOFs (BASELINE.json configs[2]).
+"""Headline benchmark: time steps per second of the stabilized_schur step.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config c3|c2|c4|c5]
 
-N=1 runs in-process; for N>1 the driver launches one rank per GPU with
-torch.distributed.run.  A "step" is one full time step (moments, Newton with
-fused residual/Jacobian assembly, FGMRES + Schur/AMG preconditioner, u_prev
-update) with every field resident in HBM.  Rank 0 prints ONE JSON line carrying
-`roofline` (dominant kernel, HIP-event timed inside the timed region) and, at
-N=1, `cpu_baseline` (the CPU oracle running the same algorithm on the same
-mesh for a bounded number of steps on the host cores).
+Default workload = BASELINE.json configs[2], the one its metric is quoted on: DFG 2D-1 refined to ~1M P1/P1 DOF.
+Other configs (same harness, for the per-config lines in DESIGN.md): c2 lid-driven cavity nx=288 (250 k DOF),
+c4 stenosis "moderate" at the reference geometry (~2 M DOF), c5 stenosis with vascular tree, pulsatile inlet,
+dt = 0.001 (~8 M DOF).
+
+N=1 runs in-process; for N>1 the driver launches one rank per GPU with torch.distributed.run.  A "step" is one full
+time step (moments, Newton with fused residual/Jacobian assembly, FGMRES + Schur/AMG preconditioner, wall shear
+stress, u_prev update) with every field resident in HBM.  Rank 0 prints ONE JSON line carrying `roofline` (dominant
+instrumented kernel, HIP-event timed), and at N=1 `cpu_baseline` (the CPU oracle running the same algorithm on the
+same mesh for a bounded number of steps on the host cores) and `parity` (GPU vs oracle functionals with both sides
+converged tightly).
 """
 from __future__ import annotations
 
@@ -19,6 +22,7 @@ import json
 import os
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -40,32 +44,76 @@ def host_cores():
 
 def kernel_bytes(ctx):
     """Algorithmic HBM bytes per launch of the instrumented kernels (DESIGN.md section 'Kernels')."""
-    nvo, nnzv, nc, ninc, spnnz = (ctx.info(k) for k in (0, 3, 2, 5, 4))
-    return {
+    nvo, nnzv, nc, spnnz = (ctx.info(k) for k in (0, 3, 2, 4))
+    kb = {
         # fused residual+Jacobian: SURVEY.md 8d figure, 624 B per vertex
         0: ("asm_residual_jacobian", 624.0 * nvo),
         # block SpMV: values 72 B + column 4 B per graph entry; rowptr 4, x 24, y 24 per row
         1: ("spmv_full_block3x3", 76.0 * nnzv + 52.0 * nvo),
-        # tau moments: cells 12 + coords/u_prev gathers 2*16*3 (per cell, L2-resident per vertex: 32 B) + 64 B record out
+        # tau moments: cells 12 + coords/u_prev gathers (L2-resident per vertex: 32 B) + 64 B record out
         2: ("tau_moments", 12.0 * nc + 32.0 * nvo + 64.0 * nc),
-        # Chebyshev step on A00: values 32 B + column 4 B per entry; rowptr 4 + 7 vectors x 16 B per row
+        # Chebyshev step on A00 (pc_type 0): values 32 B + column 4 B per entry; rowptr 4 + 7 vectors x 16 B per row
         3: ("cheb_step_A00", 36.0 * nnzv + 116.0 * nvo),
+    }
+    if ctx.info(25):
         # fused AMG cycle, level 0 (SELL-64 / CSR, fp32 values: 4 B value + 4 B column per entry):
         # up-sweep x = Sb b + Sc x_c: entries of Sb and Sc, b and x per row, the coarse vector once
-        4: ("amg_up0_pressure", 8.0 * ctx.info(19) + 16.0 * nvo + 8.0 * ctx.info(23)),
-        5: ("amg_up0_velocity_2rhs", 8.0 * ctx.info(20) + 32.0 * nvo + 16.0 * ctx.info(24)),
+        kb[4] = ("amg_up0_pressure", 8.0 * ctx.info(19) + 16.0 * nvo + 8.0 * ctx.info(23))
+        kb[5] = ("amg_up0_velocity_2rhs", 8.0 * ctx.info(20) + 32.0 * nvo + 16.0 * ctx.info(24))
         # down-sweep b_c = G b: entries of G, row pointer and result per coarse row, the fine vector once
-        8: ("amg_down0_pressure", 8.0 * ctx.info(21) + 12.0 * ctx.info(23) + 8.0 * nvo),
-        9: ("amg_down0_velocity_2rhs", 8.0 * ctx.info(22) + 20.0 * ctx.info(24) + 16.0 * nvo),
-    } if ctx.info(25) else {
-        0: ("asm_residual_jacobian", 624.0 * nvo),
-        1: ("spmv_full_block3x3", 76.0 * nnzv + 52.0 * nvo),
-        2: ("tau_moments", 12.0 * nc + 32.0 * nvo + 64.0 * nc),
-        3: ("cheb_step_A00", 36.0 * nnzv + 116.0 * nvo),
-        # unfused cycle: level-0 Jacobi sweep (SELL-64, fp32 values): 8 B per entry; weights 8 + 4 vectors x 8 B per row
-        4: ("amg_sweep_pressure", 8.0 * spnnz + 40.0 * nvo),
-        5: ("amg_sweep_velocity_2rhs", 8.0 * ctx.info(8) + 56.0 * nvo),
-    }
+        kb[8] = ("amg_down0_pressure", 8.0 * ctx.info(21) + 12.0 * ctx.info(23) + 8.0 * nvo)
+        kb[9] = ("amg_down0_velocity_2rhs", 8.0 * ctx.info(22) + 20.0 * ctx.info(24) + 16.0 * nvo)
+    else:
+        # sweep-by-sweep cycle: level-0 Jacobi sweep (SELL-64, fp32 values): 8 B per entry; weights + 4 vectors per row
+        kb[4] = ("amg_sweep_pressure", 8.0 * spnnz + 40.0 * nvo)
+        kb[5] = ("amg_sweep_velocity_2rhs", 8.0 * ctx.info(8) + 56.0 * nvo)
+    return kb
+
+
+TIGHT = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
+
+
+def make_scenario(args, solver_name, **kw):
+    """The scenario of the chosen BASELINE config on `solver_name` (a product plugin or the oracle-backed double)."""
+    cfg = args.config
+    if cfg == "c3":
+        from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+        return DFG1Benchmark(solver_name, args.dt, 1.0, m=args.m, quiet=True, **kw)
+    if cfg == "c2":
+        from cfd_hemodynamic_amd.scenarios.lid_driven2D import LidDriven2DSimulation
+        return LidDriven2DSimulation(solver_name, args.dt, 10.0, nx=args.nx, mu=0.01, quiet=True, **kw)
+    if cfg == "c4":
+        from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
+        return StenosisSimulation(solver_name, args.dt, 1.0, grade="moderate", ny=args.ny, v_max=args.v_max, quiet=True, **kw)
+    from cfd_hemodynamic_amd.scenarios.stenosis_with_tree import StenosisWithTreeSimulation
+    return StenosisWithTreeSimulation(solver_name, args.dt, 1.0, grade="moderate", res=args.res, pulse_amplitude=0.5,
+                                      ramp_time=args.ramp, inlet_max_velocity=args.v_max, quiet=True, **kw)
+
+
+def workload_text(args, sc):
+    nv = sc.mesh.num_vertices
+    head = {"c3": "dfg_1 (DFG 2D-1, Re=20) block-structured mesh m=%d" % args.m,
+            "c2": "lid_driven2D (Re=100) unit square nx=%d" % args.nx,
+            "c4": "stenosis grade moderate (L=138, R_in=1.57, R_out=1.2, x_sten=30, severity .5, slope .3), ny=%d, inlet v_max=%g mm/s, p=0 outlet" % (args.ny, args.v_max),
+            "c5": "stenosis_with_tree grade moderate (L=0.03, H=0.003, severity .5, slope .5; 3-generation Murray tree, 8 outlets p=0), "
+                  "res=%g, pulsatile inlet v_max (1 + 0.5 sin 2 pi t) with a (1 - cos(pi t / %g)) / 2 start-up ramp, v_max=%g" % (args.res, args.ramp, args.v_max)}[args.config]
+    return "%s: %d vertices, %d P1/P1 DOF, dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)" % (
+        head, nv, 3 * nv, args.dt)
+
+
+def step_hook(sc, k, dt):
+    """Time-dependent boundary data of the step about to be solved (only config 5 has any)."""
+    if hasattr(sc, "set_inlet_time"):
+        sc.set_inlet_time((k + 1) * dt)
+
+
+def functionals(args, sc):
+    """Config-specific scalar results (global values) from a scenario whose solver offers `functional`."""
+    s = sc.solver
+    out = {"velocity_l2": s.functional(2), "pressure_l2": s.functional(3)}
+    if args.config == "c3":
+        out["drag"], out["lift"] = 500 * s.functional(0, sc.obstacle_marker), 500 * s.functional(1, sc.obstacle_marker)
+    return out
 
 
 def main():
@@ -73,16 +121,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--m", type=int, default=200, help="DFG mesh parameter (m=200: 336,474 vertices, 1,009,422 DOF)")
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--m", type=int, default=200, help="c3: DFG mesh parameter (m=200: 336,273 vertices, 1,008,819 DOF)")
+    ap.add_argument("--nx", type=int, default=288, help="c2: cells per side")
+    ap.add_argument("--ny", type=int, default=115, help="c4: cells across the inlet (115: 678,136 vertices, 2.03 M DOF)")
+    ap.add_argument("--res", type=float, default=7.3e-6, help="c5: cell size (7.3e-6: 2.73 M vertices, 8.18 M DOF)")
+    ap.add_argument("--v-max", type=float, default=None, help="inlet peak velocity (c4 default 100 mm/s, c5 default 0.05 m/s: Re = 45)")
+    ap.add_argument("--ramp", type=float, default=0.03, help="c5: start-up ramp of the inlet (s); 0 = impulsive start")
+    ap.add_argument("--dt", type=float, default=None, help="time step (default 0.01; c5: 0.001)")
     ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--parity-steps", type=int, default=None,
+                    help="tightly converged steps compared with the oracle (default 2; c5: 0 = skipped, a tight oracle step at 8 M DOF "
+                         "takes minutes -- tests/test_gpu_configs.py does that comparison on a coarse mesh of the same domain)")
     ap.add_argument("--prof-steps", type=int, default=2, help="extra steps with HIP-event kernel timing (after the timed region)")
-    ap.add_argument("--host-loop-steps", type=int, default=10, help="extra steps with the reference's host-copy loop (PCIe-inclusive rate)")
+    ap.add_argument("--host-loop-steps", type=int, default=10, help="extra steps with the reference's literal state-copy loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "host"])
     ap.add_argument("--verbose", type=int, default=0)
     ap.add_argument("--solver", default="stabilized_schur", choices=["stabilized_schur", "stabilized_schur_bdf2"],
                     help="solver plugin (default: the headline one)")
     args = ap.parse_args()
+    if args.dt is None:
+        args.dt = 0.001 if args.config == "c5" else 0.01
+    if args.v_max is None:
+        args.v_max = 0.05 if args.config == "c5" else 100.0
+    if args.parity_steps is None:
+        args.parity_steps = 0 if args.config == "c5" else 2
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,18 +173,15 @@ def main():
     torch.cuda.set_device(local_rank)
 
     from cfd_hemodynamic_amd.parallel import PartComm
-    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
 
-    dt = 0.01
+    dt = args.dt
     comm = PartComm(rank, world, args.comm) if world > 1 else None
     t0 = time.perf_counter()
-    sc = DFG1Benchmark(args.solver, dt, 1.0, m=args.m, quiet=True, device=local_rank, comm=comm,
-                       verbose=args.verbose)
+    sc = make_scenario(args, args.solver, device=local_rank, comm=comm, verbose=args.verbose)
     solver = sc.solver
     ctx = solver.ctx
     t_setup = time.perf_counter() - t0
     nv = sc.mesh.num_vertices
-    ndof = 3 * nv
 
     def sync_all():
         torch.cuda.synchronize()
@@ -129,17 +190,23 @@ def main():
 
     its_newton, its_krylov = [], []
     solver.initStressForm()
+    kstep = 0
     for _ in range(args.warmup):
+        step_hook(sc, kstep, dt)
         solver.solveStep()
         solver.assemble_wss()
         solver.advance()
+        kstep += 1
     sync_all()
+    ctx.profile_reset()  # zero the communication / synchronisation counters
     t0 = time.perf_counter()
     ms_asm = ms_solve = ms_pc = 0.0
     for _ in range(args.steps):
+        step_hook(sc, kstep, dt)  # time-dependent Dirichlet data (config 5), part of the step
         solver.solveStep()     # Newton + FGMRES step (stabilized_schur.py:313-334)
         solver.assemble_wss()  # per-step wall shear stress (scenario.py:262), on the device
         solver.advance()       # u_prev <- u_sol, p_prev <- p_sol (scenario.py:306-307), on the device
+        kstep += 1
         st = solver.last_stats
         its_newton.append(st.newton_its)
         its_krylov.append(st.krylov_its)
@@ -148,71 +215,74 @@ def main():
         ms_pc += st.ms_pc_setup
     sync_all()
     elapsed = time.perf_counter() - t0
+    counters = {k: ctx.info(i) for k, i in (("allreduce", 13), ("halo", 14), ("host_sync", 15), ("krylov", 16), ("allgather", 17))}
+    comm_size = ctx.info(18)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
-    # the reference's literal loop: u_prev.x.array[:] = u_sol.x.array[:] through the host every step
-    # (scenario.py:306-307) -> PCIe-inclusive rate, reported beside `value`, never as `value`
-    pcie_rate = None
+    # the reference's literal loop: u_prev.x.array[:] = u_sol.x.array[:] (scenario.py:306-307), reported beside `value`
+    literal_rate = None
     if world == 1 and args.host_loop_steps > 0:
         sync_all()
         t0h = time.perf_counter()
         for _ in range(args.host_loop_steps):
+            step_hook(sc, kstep, dt)
             solver.solveStep()
+            solver.assemble_wss()
             solver.u_prev.x.array[:] = solver.u_sol.x.array[:]
             solver.p_prev.x.array[:] = solver.p_sol.x.array[:]
+            kstep += 1
         sync_all()
-        pcie_rate = args.host_loop_steps / (time.perf_counter() - t0h)
+        literal_rate = args.host_loop_steps / (time.perf_counter() - t0h)
 
-    # parity metrics of the run (global values)
-    drag, lift = sc.drag_lift()
-    l2u = solver.functional(2)
+    results = functionals(args, sc)
 
-    # Kernel durations: HIP events on the library's stream around every launch of the hot
-    # kernels, over `prof_steps` further steps of the same run (the preconditioner's hipGraph
-    # replay is switched off while events are recorded; the kernels and their data are the same)
-    ctx.profile_reset()
-    ctx.profile_enable(True)
-    for _ in range(args.prof_steps):
-        solver.solveStep()
-        solver.advance()
-    ctx.profile_enable(False)
-    sync_all()
+    # Kernel durations: HIP events on the library's stream around every launch of the hot kernels, over `prof_steps`
+    # further steps of the same run (the preconditioner's hipGraph replay is switched off while events are recorded;
+    # the kernels and their data are the same)
+    kern, roof = [], None
+    if args.prof_steps > 0:
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(args.prof_steps):
+            step_hook(sc, kstep, dt)
+            solver.solveStep()
+            solver.advance()
+            kstep += 1
+        ctx.profile_enable(False)
+        sync_all()
+        # An empty event pair on the stream already reads ~4.5 us (kind 7, recorded when profiling is switched on); a
+        # pair around a kernel overlaps part of that with the launch, so the excess over rocprofv3's kernel-trace
+        # duration is ~3 us per launch.  `avg_us` is the RAW event time (the achieved rates are lower bounds).
+        oms, on = ctx.profile_get(7)
+        ovh_us = 1e3 * oms / on if on else 0.0
+        for kind, (name, nbytes) in kernel_bytes(ctx).items():
+            ms, n = ctx.profile_get(kind)
+            if n:
+                raw = 1e3 * ms / n
+                kern.append({"kernel": name, "launches": n, "avg_us": raw, "total_ms": ms, "algorithmic_MB": nbytes / 1e6,
+                             "GBps": nbytes / (raw * 1e-6) / 1e9, "avg_us_minus_empty_event_pair": max(raw - ovh_us, 0.0)})
+        kern.sort(key=lambda k: -k["total_ms"])
+        if kern:
+            d = kern[0]
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc) and args.config == "c3" and args.m == 200:
+                try:
+                    traffic = json.load(open(pmc)).get("per_launch_bytes", {}).get(d["kernel"])
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": d["kernel"], "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "avg_us": d["avg_us"],
+                    "algorithmic_bytes": d["algorithmic_MB"] * 1e6, "empty_event_pair_us": ovh_us}
 
-    # roofline of the dominant instrumented kernel
-    kb = kernel_bytes(ctx)
-    kern = []
-    # An empty event pair on the stream already reads ~4.5 us (the library records 256 of them when profiling is
-    # switched on, kind 7); a pair around a kernel overlaps part of that with the launch, so the excess over
-    # rocprofv3's kernel-trace duration is ~3 us per launch.  `avg_us` is the RAW event time (conservative: the
-    # achieved rates below are lower bounds); the calibration is reported next to it.
-    oms, on = ctx.profile_get(7)
-    ovh_us = 1e3 * oms / on if on else 0.0
-    for kind, (name, nbytes) in kb.items():
-        ms, n = ctx.profile_get(kind)
-        if n:
-            raw = 1e3 * ms / n
-            kern.append({"kernel": name, "launches": n, "avg_us": raw, "total_ms": ms, "algorithmic_MB": nbytes / 1e6,
-                         "GBps": nbytes / (raw * 1e-6) / 1e9, "avg_us_minus_empty_event_pair": max(raw - ovh_us, 0.0)})
-    kern.sort(key=lambda k: -k["total_ms"])
-    roof = None
-    if kern:
-        d = kern[0]
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("per_launch_bytes", {}).get(d["kernel"])
-            except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "kernel": d["kernel"], "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "avg_us": d["avg_us"],
-                "algorithmic_bytes": d["algorithmic_MB"] * 1e6, "empty_event_pair_us": ovh_us}
-
+    label = {"c3": "dfg_1 ~1M DOF", "c2": "lid_driven2D ~250k DOF", "c4": "stenosis moderate ~2M DOF",
+             "c5": "stenosis_with_tree ~8M DOF pulsatile"}[args.config]
+    kits = max(sum(its_krylov), 1)
     out = {
-        "metric": "time-steps/sec, dfg_1 ~1M DOF (%s)" % args.solver,
+        "metric": "time-steps/sec, %s (%s)" % (label, args.solver),
         "value": args.steps / elapsed,
         "unit": "time-steps/s",
         "n_gpus": world,
@@ -224,54 +294,49 @@ def main():
         "vs_baseline": None,
         "dtype": "f64 (AMG matrix values of the preconditioner in fp32)",
         "data": "synthetic",
-        "config": {"workload": "dfg_1 (DFG 2D-1, Re=20) block-structured mesh m=%d: %d vertices, %d P1/P1 DOF, "
-                               "dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)"
-                               % (args.m, nv, ndof, dt),
-                   "parallelism": "element partition x%d (RCB), halo + dot all-reduce on %s" % (
+        "config": {"workload": workload_text(args, sc),
+                   "parallelism": "element partition x%d (RCB), halo + dot all-reduce on %s; communicator size %d" % (
                        world, (comm.backend if comm is not None else args.comm) + (
-                           " [fallback: %s]" % comm.fallback_reason if getattr(comm, "fallback_reason", None) else ""))},
+                           " [fallback: %s]" % comm.fallback_reason if getattr(comm, "fallback_reason", None) else ""), comm_size)},
         "ms_assemble_per_step": ms_asm / args.steps,
         "ms_solve_per_step": ms_solve / args.steps,
         "ms_pc_setup_per_step": ms_pc / args.steps,
         "newton_its_per_step": float(np.mean(its_newton)),
         "krylov_its_per_step": float(np.mean(its_krylov)),
+        "per_krylov_iteration": {"allreduce": counters["allreduce"] / kits, "halo_exchange": counters["halo"] / kits,
+                                 "allgather": counters["allgather"] / kits, "host_sync": counters["host_sync"] / kits},
         "setup_s": t_setup,
         # the reference's literal loop `u_prev.x.array[:] = u_sol.x.array[:]` (scenario.py:306-307); since the lazy
         # array proxy maps that idiom to a device copy no field crosses PCIe any more (key kept for comparability)
-        "pcie_inclusive_steps_per_s": pcie_rate,
-        "literal_reference_loop_steps_per_s": pcie_rate,
-        "drag_coefficient": drag,
-        "lift_coefficient": lift,
-        "velocity_l2": l2u,
+        "pcie_inclusive_steps_per_s": literal_rate,
+        "literal_reference_loop_steps_per_s": literal_rate,
+        "results": results,
         "roofline": roof,
         "kernels": kern,
     }
+    if args.config == "c3":
+        out["drag_coefficient"], out["lift_coefficient"], out["velocity_l2"] = results["drag"], results["lift"], results["velocity_l2"]
 
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        from util import dfg_case, make_oracle
-        from oracle import orc
+        # CPU baseline and parity: the same Scenario class on the oracle-backed test double of the solver plugin
+        # (tests/oracle_solver.py over oracle/cfdh_oracle.c) -- checker and reported baseline only, never the product.
+        import oracle_solver
+        mod = types.ModuleType("cfd_hemodynamic_amd.solvers._oracle_double")
+        mod.Solver = oracle_solver.Solver
+        sys.modules["cfd_hemodynamic_amd.solvers._oracle_double"] = mod
         cores = min(host_cores(), 16)
         os.environ["CFDH_ORACLE_THREADS"] = str(cores)
-        case = dfg_case(args.m, dt)
-        O = make_oracle(case)
-        O.set_threads(cores)
-        x = np.zeros(3 * nv)
-        O.set_un(np.zeros(2 * nv))
         bdf2 = args.solver == "stabilized_schur_bdf2"
-        un_hist = np.zeros(2 * nv)
         # same Newton / FGMRES / Cahouet-Chabard + AMG algorithm and tolerances; FULL Schur factorisation, which is
         # the faster variant on the CPU (4.0 vs 2.7 steps/s with the upper-triangular factor the GPU path prefers)
-        opts = orc.default_opts(pc_kind=2, schur_upper=0)
+        osc = make_scenario(args, "_oracle_double", pc_kind=2, options=dict(schur_upper=0), bdf2=bdf2)
+        osc.solver.O.set_threads(cores)
         t0 = time.perf_counter()
         nst = 0
         for _ in range(args.warmup + args.cpu_steps):
-            ts = time.perf_counter()
-            if bdf2:
-                O.set_scheme(1.0, *((1.0, -1.0, 0.0) if nst == 0 else (1.5, -2.0, 0.5)))
-                O.set_un2(un_hist)
-                un_hist = x[: 2 * nv].copy()  # u_prev of this step = u_prev2 of the next
-            x, so = O.solve_step(x, opts)
-            O.set_un(x[: 2 * nv])
+            step_hook(osc, nst, dt)
+            osc.solver.solveStep()
+            osc.solver.advance()
             nst += 1
             if nst == args.warmup:
                 t0 = time.perf_counter()
@@ -282,53 +347,47 @@ def main():
         out["cpu_baseline"] = {
             "value": ncpu / tcpu, "unit": "time-steps/s", "cores": cores, "kind": "port",
             "sample": "steps %d..%d of the same mesh/dt from t=0 with the C oracle (oracle/cfdh_oracle.c, pc_kind=2: "
-                      "same Newton + FGMRES + Cahouet-Chabard/AMG preconditioner and tolerances, FULL Schur factorisation = the faster variant on the CPU, OpenMP)" % (args.warmup + 1, nst),
+                      "same Newton + FGMRES + Cahouet-Chabard/AMG preconditioner and tolerances, FULL Schur factorisation = "
+                      "the faster variant on the CPU, OpenMP)" % (args.warmup + 1, nst),
             "ms_per_step": 1e3 * tcpu / max(ncpu, 1),
         }
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        # Parity at the bench size (checker use of the oracle only; drag/lift: dfg_1.py:183-211, L2 norm: scenario.py:315-324).
-        # (1) the states both sides reached at PETSc-default tolerances: oracle after step `nst` of the timed leg above
-        #     against the HIP path replayed from rest for the same number of steps -- differences = solver noise;
-        # (2) two steps from rest with BOTH sides converged tightly (snes_rtol 1e-12, ksp_rtol 1e-10): this is the
-        #     `parity` entry, north_star's "drag/lift within 1e-6 relative" is read against it.
-        obst = case.markers["ft"].find(5)
-        rel = lambda a, b: abs(a - b) / abs(b)
 
-        def compare(sc_g, x_o):
-            gd, gl = sc_g.drag_lift()
-            gl2 = sc_g.solver.functional(2)
-            od, ol = 500 * O.functional(x_o, 0, obst), 500 * O.functional(x_o, 1, obst)
-            ol2 = O.functional(x_o, 2)
-            xg = np.concatenate([sc_g.solver.u_sol.x.array, sc_g.solver.p_sol.x.array])
-            return {"drag_rel": rel(gd, od), "lift_rel": rel(gl, ol), "l2_rel": rel(gl2, ol2),
-                    "solution_rel": float(np.linalg.norm(xg - x_o) / np.linalg.norm(x_o)),
-                    "gpu": {"drag": gd, "lift": gl, "velocity_l2": gl2},
-                    "oracle": {"drag": od, "lift": ol, "velocity_l2": ol2}}
+        # Parity at the bench size (drag/lift: dfg_1.py:183-211, L2 norms: scenario.py:315-324).
+        rel = lambda a, b: abs(a - b) / abs(b) if b != 0 else abs(a - b)
 
-        sc2 = DFG1Benchmark(args.solver, dt, 1.0, m=args.m, quiet=True, device=local_rank, verbose=0)
-        for _ in range(nst):
+        def compare(sc_g, sc_o):
+            fg, fo = functionals(args, sc_g), functionals(args, sc_o)
+            xg = np.concatenate([np.asarray(sc_g.solver.u_sol.x.array), np.asarray(sc_g.solver.p_sol.x.array)])
+            xo = sc_o.solver.x_n
+            d = {"%s_rel" % k: rel(fg[k], fo[k]) for k in fo}
+            d["l2_rel"] = d["velocity_l2_rel"]
+            d["solution_rel"] = float(np.linalg.norm(xg - xo) / np.linalg.norm(xo))
+            d["gpu"], d["oracle"] = fg, fo
+            return d
+
+        # (1) the states both sides reached at PETSc-default tolerances after `nst` steps: differences = solver noise
+        sc2 = make_scenario(args, args.solver, device=local_rank)
+        for k in range(nst):
+            step_hook(sc2, k, dt)
             sc2.solver.solveStep()
             sc2.solver.advance()
-        out["parity_default_tolerances"] = dict(compare(sc2, x), step=nst)
-        del sc2
-        tight = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
-        sc3 = DFG1Benchmark(args.solver, dt, 1.0, m=args.m, quiet=True, device=local_rank, verbose=0, options=tight)
-        xt = np.zeros(3 * nv)
-        O.set_un(np.zeros(2 * nv))
-        topts = orc.default_opts(pc_kind=2, **tight)
-        hist = np.zeros(2 * nv)
-        for k in range(2):
-            sc3.solver.solveStep()
-            sc3.solver.advance()
-            if bdf2:
-                O.set_scheme(1.0, *((1.0, -1.0, 0.0) if k == 0 else (1.5, -2.0, 0.5)))
-                O.set_un2(hist)
-                hist = xt[: 2 * nv].copy()
-            xt, _ = O.solve_step(xt, topts)
-            O.set_un(xt[: 2 * nv])
-        out["parity"] = dict(compare(sc3, xt), step=2,
-                             tolerances="two steps from rest, both sides snes_rtol 1e-12 / ksp_rtol 1e-10 (oracle pc_kind=2)")
-        del sc3
+        out["parity_default_tolerances"] = dict(compare(sc2, osc), step=nst)
+        del sc2, osc
+        # (2) steps from rest with BOTH sides converged tightly: this is the `parity` entry, north_star's
+        #     "drag/lift within 1e-6 relative" is read against it
+        if args.parity_steps > 0:
+            sc3 = make_scenario(args, args.solver, device=local_rank, options=dict(TIGHT))
+            osc3 = make_scenario(args, "_oracle_double", pc_kind=2, options=dict(TIGHT), bdf2=bdf2)
+            osc3.solver.O.set_threads(cores)
+            for k in range(args.parity_steps):
+                for s_ in (sc3, osc3):
+                    step_hook(s_, k, dt)
+                    s_.solver.solveStep()
+                    s_.solver.advance()
+            out["parity"] = dict(compare(sc3, osc3), step=args.parity_steps,
+                                 tolerances="steps from rest, both sides snes_rtol 1e-12 / ksp_rtol 1e-10 (oracle pc_kind=2)")
+            del sc3, osc3
 
     if rank == 0:
         print(json.dumps(out))

@@ -591,7 +591,11 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       // PETSc's default never refines.  Here: tolerances down to ~1e-7 refine only when two digits
       // cancel; tighter solves (parity runs at 1e-10) use the DGKS criterion (|w'| < |w|/sqrt(2)),
       // because classical Gram-Schmidt then loses the orthogonality the deep convergence needs
-      const double eta2 = (o.ksp_rtol < 1e-7) ? 0.5 : 1e-2;
+      // ... and so does a long Krylov cycle: beyond ~two dozen vectors the unrefined basis drifts far enough from
+      // orthogonality that the least-squares solution picks up huge spurious components (Newton corrections ten times
+      // the size of the iterate on the tree domain, config 5) although the residual norm looks converged
+      static const int refine_from = getenv("CFDH_GS_REFINE_FROM") ? atoi(getenv("CFDH_GS_REFINE_FROM")) : 24;
+      const double eta2 = (o.ksp_rtol < 1e-7 || j >= refine_from) ? 0.5 : 1e-2;
       bool refine = !(nrm2 > eta2 * ww);
       double hnorm;
       if (refine) {
@@ -734,6 +738,7 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
     if (!ok) { reason = CFDH_DIVERGED_LINE_SEARCH; break; }
     double dn, xn;
     CHK(v_norm2_pair(c, n, d, xt, &dn, &xn));
+    if (o.verbose) fprintf(stderr, "[cfdh]     step length %.3e, |dx| = %.3e, |x| = %.3e, %d FGMRES iterations\n", lam, dn, xn, kits);
     std::swap(c->x.p, c->xt.p);
     x = c->x.p; xt = c->xt.p;
     st->newton_its = it + 1;

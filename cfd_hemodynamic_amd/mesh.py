@@ -364,27 +364,34 @@ def create_dfg_channel(m, comm=None):
     return mesh, ft
 
 
-def create_stenosis_channel(ny, L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, severity=0.5,
-                            half_len=None, comm=None):
-    """2-D stenosed channel 0<=x<=L, walls y = R_in +- R(x): a symmetric
-    cosine-shaped narrowing of relative depth `severity` centred at x_sten and
-    a linear taper from R_in to R_out over the whole length (a y-profile
-    reduction of the Bezier walls of /root/reference/src/scenarios/stenosis.py:27-69;
-    the exact CAD outline is out of scope).
-
-    Structured ny cells across, uniform aspect ~1 in x, shorter-diagonal split.
-    Markers as in the reference (stenosis.py:22-25): inlet=2 (x=0), outlet=3 (x=L), wall=4.
+def create_stenosis_channel(ny, L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, severity=0.5, slope=0.3, tension=0.5,
+                            comm=None):
+    """2-D stenosed channel of /root/reference/src/scenarios/stenosis.py:262-374: 0 <= x <= L, walls
+    y = R_in +- R(x) with R the linear taper R_in -> R_out and, around x_sten, the narrowing to
+    (1 - severity) R_taper(x_sten) drawn by two cubic Beziers per wall (junctions at x_sten -+ h_sten/slope, handle
+    length tension * dist_x along the taper slope).  Defaults = the reference's defaults with grade "moderate"
+    (stenosis.py:27-31,60-69).  The outline is the reference's; the triangulation is structured (gmsh is not
+    available): ny cells across, columns spaced by the local cell height 2 R(x) / ny (aspect ratio ~1 everywhere,
+    also in the throat), shorter-diagonal split.  Markers (stenosis.py:22-25): inlet=2 (x=0), outlet=3 (x=L), wall=4.
     """
+    from .geom.shapes import StenosedChannel
     ny = int(ny)
-    if half_len is None:
-        half_len = 2.0 * R_in / 0.3 * severity  # slope parameter ~0.3 of the reference
-    hx = 2.0 * R_in / ny
-    nx = int(round(L / hx))
-    xs = np.linspace(0.0, L, nx + 1)
-    Rx = R_in + (R_out - R_in) * xs / L
-    bump = np.where(np.abs(xs - x_sten) < half_len,
-                    0.5 * severity * (1.0 + np.cos(np.pi * (xs - x_sten) / half_len)), 0.0)
-    Rx = Rx * (1.0 - bump)
+    ch = StenosedChannel(L, R_in, R_out, x_sten, severity, slope, tension, yc=R_in, clamp_frac=None)
+    # columns: x_{i+1} = x_i + 2 R(x_i) / ny, then rescaled so that the last one lands on L
+    xs = [0.0]
+    while xs[-1] < L:
+        xs.append(xs[-1] + 2.0 * float(ch.radius(np.array([min(xs[-1], L)]))[0]) / ny)
+    xs = np.array(xs)
+    # keep the stenosis position exact under the rescaling: piecewise-linear map fixing 0, x_sten and L
+    k = int(np.argmin(np.abs(xs - x_sten)))
+    if 0 < k < len(xs) - 1:
+        left = xs[: k + 1] * (x_sten / xs[k])
+        right = x_sten + (xs[k:] - xs[k]) * ((L - x_sten) / (xs[-1] - xs[k]))
+        xs = np.concatenate([left, right[1:]])
+    else:
+        xs = xs * (L / xs[-1])
+    nx = len(xs) - 1
+    Rx = ch.radius(xs)
     eta = np.linspace(-1.0, 1.0, ny + 1)
     X = np.repeat(xs[:, None], ny + 1, axis=1)
     Y = R_in + Rx[:, None] * eta[None, :]
@@ -396,7 +403,58 @@ def create_stenosis_channel(ny, L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, seve
     mesh = Mesh(cells, x, comm=comm, name="stenosis")
     mid = mesh.facet_midpoints()
     marker = np.full(mesh.num_facets, 4, dtype=np.int32)
-    marker[np.abs(mid[:, 0]) < 1e-9] = 2
-    marker[np.abs(mid[:, 0] - L) < 1e-9] = 3
+    marker[np.abs(mid[:, 0]) < 1e-9 * L] = 2
+    marker[np.abs(mid[:, 0] - L) < 1e-9 * L] = 3
     ft = MeshTags(mesh, 1, np.arange(mesh.num_facets, dtype=np.int32), marker)
+    mesh.channel = ch
+    return mesh, ft
+
+
+def create_stenosis_tree(res, L=0.03, H=0.003, x_sten=0.01, severity=0.75, slope=0.3, tension=0.5, n_generations=3,
+                         gamma=3.0, bifurcation_angle=35.0, length_ratio=8.0, asymmetry=0.5, coupling_slope=0.1,
+                         comm=None):
+    """Domain of /root/reference/src/scenarios/stenosis_with_tree.py:146-420: the stenosed channel [0,L] x [0,H]
+    (Bezier walls, :256-310), a coupling trapezoid narrowing from H to 2 r_root over (H/2 - r_root) / coupling_slope
+    (:312-341), and one channel of constant half-width per tree branch around a cubic-Bezier centreline that leaves
+    its start node along the parent's direction (:343-420; 12 samples, handle 0.4), all fused.  r_root = 0.9 x the
+    throat half-width (:236-238).  The tree itself comes from the pure-Python Murray-law generator
+    (geom/vascular_tree.py = /root/reference/src/geom/tree/tree_2d.py) in place of the external VascuSynth binary
+    the reference scenario shells out to (:166-195), which does not exist here.  Meshed by the implicit-domain
+    mesher (geom/implicit_mesh.py) with cell size `res`.  Markers (:37-41): inlet=2 (x=0), outlet=3 (the end caps of
+    the terminal branches), wall=4.  Returns (mesh, facet_tags); the tree is kept as `mesh.tree`."""
+    from .geom.implicit_mesh import keep_largest_component, mesh_implicit_domain
+    from .geom.shapes import Polygon, StenosedChannel, Union, branch_polygon
+    from .geom.vascular_tree import VascularTree
+    ch = StenosedChannel(L, H / 2.0, H / 2.0, x_sten, severity, slope, tension, yc=H / 2.0, clamp_frac=0.05)
+    r_root = 0.9 * (H / 2.0) * (1.0 - severity)
+    cl = (H / 2.0 - r_root) / coupling_slope
+    trap = Polygon([(L, 0.0), (L + cl, H / 2.0 - r_root), (L + cl, H / 2.0 + r_root), (L, H)])
+    tree = VascularTree(r_root, n_generations, gamma, bifurcation_angle, length_ratio, asymmetry).generate((L + cl, H / 2.0), 0.0)
+    din = tree.incoming_direction()
+    din[0] = (1.0, 0.0)  # the root leaves the coupling along +x (:355)
+    parts, caps = [ch, trap], []
+    term = set(tree.terminals)
+    for (a, b), r in zip(tree.edges, tree.radius):
+        poly, cap = branch_polygon(tree.nodes[a], tree.nodes[b], din[a], r)
+        parts.append(Polygon(poly))
+        if int(b) in term:
+            caps.append((np.asarray(cap[0]), np.asarray(cap[1])))
+    dom = Union(parts, pad=2.0 * res)
+    x0, y0, x1, y1 = dom.bbox
+    bbox = (x0 - 0.5 * res, y0 - 0.37 * res, x1 + res, y1 + res)  # off-grid offsets: no boundary line exactly on a grid line
+    x, cells = mesh_implicit_domain(dom.phi, bbox, res, fill=dom.fill)
+    x, cells = keep_largest_component(x, cells)
+    mesh = Mesh(cells, x, comm=comm, name="stenosis_with_tree")
+    mid = mesh.facet_midpoints()
+    marker = np.full(mesh.num_facets, 4, dtype=np.int32)
+    marker[mid[:, 0] < 0.25 * res] = 2
+    for p0, p1 in caps:
+        e = p1 - p0
+        ln = np.linalg.norm(e)
+        w = mid - p0
+        s = (w @ e) / (ln * ln)
+        dist = np.abs(w[:, 0] * e[1] - w[:, 1] * e[0]) / ln
+        marker[(dist < 0.3 * res) & (s > -0.05) & (s < 1.05)] = 3
+    ft = MeshTags(mesh, 1, np.arange(mesh.num_facets, dtype=np.int32), marker)
+    mesh.tree, mesh.coupling_length, mesh.r_root, mesh.outlet_caps = tree, cl, r_root, caps
     return mesh, ft

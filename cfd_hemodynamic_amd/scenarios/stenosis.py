@@ -30,15 +30,31 @@ class StenosisSimulation(Scenario):
     outlet_marker = 3
     wall_marker = 4
 
-    def __init__(self, solver_name, dt, T, f: tuple[float, float] = (0, 0), *, rho=1.06e-3, mu=3.5e-3, ny=32,
-                 L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, severity=0.5, v_max=None, outlet_pressure=0.0,
-                 **solver_kwargs):
+    # stenosis.py:27-31
+    stenosis_grades = {
+        "mild": {"severity": 0.25, "slope": 0.3},
+        "moderate": {"severity": 0.50, "slope": 0.3},
+        "severe": {"severity": 0.75, "slope": 0.3},
+    }
+
+    def __init__(self, solver_name, dt, T, f: tuple[float, float] = (0, 0), grade="severe", *, rho=1.06e-3, mu=3.5e-3,
+                 ny=None, res=0.15, L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, x_position_stenosis=None, severity=None,
+                 slope=None, tension=0.5, v_max=None, outlet_pressure=0.0, **solver_kwargs):
+        """Geometry defaults of stenosis.py:60-69 (L 138, R_in 1.57, R_out 1.2, stenosis at x = 30, res 0.15); `grade`
+        selects severity / slope unless they are given (:71-74).  `ny` (cells across the inlet) replaces `res` as the
+        resolution parameter of the structured mesh: ny = round(2 R_in / res) when not given."""
         self._mesh = None
         self._ft = None
         self._bcu = None
         self._bcp = None
-        self.ny, self.L, self.R_in, self.R_out = int(ny), L, R_in, R_out
-        self.x_sten, self.severity, self.v_max = x_sten, severity, v_max
+        g = self.stenosis_grades.get(grade, self.stenosis_grades["severe"])
+        self.severity = g["severity"] if severity is None else severity
+        self.slope = g["slope"] if slope is None else slope
+        self.tension = tension
+        self.ny = int(ny) if ny is not None else max(4, int(round(2.0 * R_in / res)))
+        self.L, self.R_in, self.R_out = L, R_in, R_out
+        self.x_sten = x_sten if x_position_stenosis is None else x_position_stenosis
+        self.v_max = v_max
         self.outlet_pressure = outlet_pressure
         self.quiet = bool(solver_kwargs.get("quiet", False))
         if v_max is not None:
@@ -49,7 +65,7 @@ class StenosisSimulation(Scenario):
     @property
     def mesh(self):
         if not self._mesh:
-            self._mesh, self._ft = create_stenosis_channel(self.ny, self.L, self.R_in, self.R_out, self.x_sten, self.severity)
+            self._mesh, self._ft = create_stenosis_channel(self.ny, self.L, self.R_in, self.R_out, self.x_sten, self.severity, self.slope, self.tension)
         return self._mesh
 
     def inlet_profile(self, x):
@@ -107,4 +123,20 @@ class StenosisSimulation(Scenario):
                     f.write(txt + "\n")
 
     def initial_velocity(self, x):
-        return np.zeros((2, x.shape[1]))
+        """Zero without `v_max`; with it the flow-rate-conserving parabola of stenosis.py:219-259: at every x the
+        profile `v_loc (1 - (r / R_loc)^2)` with v_loc R_loc = v_max R_in, R_loc from the linear taper and a cosine
+        approximation of the narrowing (the reference's own approximation of its Bezier wall)."""
+        if self.v_max is None:
+            return np.zeros((2, x.shape[1]))
+        R_taper = self.R_in + (self.R_out - self.R_in) * (x[0] / self.L)
+        r_mid = self.R_in + (self.R_out - self.R_in) * (self.x_sten / self.L)
+        h_sten = self.severity * r_mid
+        dist_x = h_sten / self.slope if self.slope > 0 else self.L / 4
+        dist_x = max(dist_x, self.L * 0.05)
+        dist_x = min(dist_x, min(self.x_sten, self.L - self.x_sten) * 0.95)
+        dx = np.abs(x[0] - self.x_sten)
+        bump = np.where(dx < dist_x, h_sten * 0.5 * (1.0 + np.cos(np.pi * dx / dist_x)), 0.0)
+        R_loc = np.maximum(R_taper - bump, 1e-6)
+        v = np.zeros((2, x.shape[1]))
+        v[0] = np.maximum(float(self.v_max) * self.R_in / R_loc * (1.0 - ((x[1] - self.R_in) / R_loc) ** 2), 0.0)
+        return v

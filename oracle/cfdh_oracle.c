@@ -1541,3 +1541,33 @@ double orc_functional(orc_ctx *c, const double *xv, int kind, int nfac, const in
   }
   return kind == 0 ? FD : FL;
 }
+
+/* Wall shear stress, the per-step assemble_wss() of /root/reference/src/solverBase.py:163-195:
+ *   Lt = (1/FacetArea) inner(w, Tt) ds,  T = -sigma(u,p) n,  sigma = 2 mu eps(u) - p I (solverBase.py:176-182),
+ *   Tt = T - (T.n) n  (the pressure part is purely normal and drops out).
+ * P1 test functions on a straight facet e: (1/|e|) oint lambda_a ds = 1/2, so every exterior facet adds Tt/2 to
+ * both of its vertices.  out[2*nv], zero away from the boundary. */
+void orc_wss(orc_ctx *c, const double *xv, double mu, double *out) {
+  memset(out, 0, sizeof(double) * 2 * c->nv);
+  for (int k = 0; k < c->nf; k++) {
+    const int e = c->fcell[k], fl = c->flocal[k];
+    double xe[3][2], g[3][2], area, h;
+    int vs[3];
+    for (int a = 0; a < 3; a++) { vs[a] = c->cells[3 * e + a]; xe[a][0] = c->x[2 * vs[a]]; xe[a][1] = c->x[2 * vs[a] + 1]; }
+    geom(xe, g, &area, &h);
+    const double gl = hypot(g[fl][0], g[fl][1]);
+    const double n[2] = {-g[fl][0] / gl, -g[fl][1] / gl}; /* outward normal: grad(lambda_fl) points inwards */
+    double G[2][2] = {{0, 0}, {0, 0}};                    /* G_ij = d_i u_j */
+    for (int a = 0; a < 3; a++)
+      for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) G[i][j] += g[a][i] * xv[2 * vs[a] + j];
+    const double E01 = 0.5 * (G[0][1] + G[1][0]);
+    const double T[2] = {-2.0 * mu * (G[0][0] * n[0] + E01 * n[1]), -2.0 * mu * (E01 * n[0] + G[1][1] * n[1])};
+    const double Tn = T[0] * n[0] + T[1] * n[1];
+    for (int q = 1; q <= 2; q++) {
+      const int v = vs[(fl + q) % 3];
+      out[2 * v] += 0.5 * (T[0] - Tn * n[0]);
+      out[2 * v + 1] += 0.5 * (T[1] - Tn * n[1]);
+    }
+  }
+}

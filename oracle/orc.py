@@ -66,6 +66,7 @@ def lib():
         L.orc_spmv.argtypes = [C.c_void_p, dp, dp]
         L.orc_functional.argtypes = [C.c_void_p, dp, C.c_int, C.c_int, ip, C.c_double]
         L.orc_functional.restype = C.c_double
+        L.orc_wss.argtypes = [C.c_void_p, dp, C.c_double, dp]
         L.orc_element.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp, C.c_int, dp, dp]
         _LIB = L
     return _LIB
@@ -174,6 +175,17 @@ class Oracle:
         xv = np.ascontiguousarray(xv, dtype=np.float64)
         fa = np.ascontiguousarray(facets if facets is not None else [], dtype=np.int32)
         return lib().orc_functional(self.h, _dp(xv), int(kind), len(fa), _ip(fa), float(self.mu))
+
+
+def _wss(self, xv):
+    """Wall shear stress field [2*nv] of solverBase.py:163-195 for the monolithic state xv."""
+    xv = np.ascontiguousarray(xv, dtype=np.float64)
+    out = np.empty(2 * self.nv)
+    lib().orc_wss(self.h, _dp(xv), float(self.mu), _dp(out))
+    return out
+
+
+Oracle.wall_shear_stress = _wss
 
 
 def element(dt, rho, mu, muf, f, xe, ue, une, pe, fflag):

@@ -21,6 +21,9 @@ class Solver(SolverBase):
         self.nv = mesh.num_vertices
         self.last_stats = None
         self.calls = 0
+        # bdf2=True: the time discretisation of stabilized_schur_bdf2.py (BDF1 on the first step, BDF2 afterwards)
+        self.bdf2 = bool(kwargs.get("bdf2", False))
+        self._un2 = np.zeros(2 * self.nv)
 
     def setup(self, bcu, bcp, facet_tags=None, tags=None):
         self._bcs = [(0, bc.getBC(self.V)) for bc in bcu] + [(1, bc.getBC(self.Q)) for bc in bcp]
@@ -35,11 +38,20 @@ class Solver(SolverBase):
             else:
                 self.O.add_bc_p(bc.dofs, bc.g.x.array[bc.dofs])
         self.O.set_un(self.u_prev.x.array)
+        if self.bdf2:
+            self.O.set_scheme(1.0, *((1.0, -1.0, 0.0) if self.calls == 0 else (1.5, -2.0, 0.5)))
+            self.O.set_un2(self._un2)
+            self._un2 = np.array(self.u_prev.x.array, copy=True)  # u_prev2 of the next step
         self.x_n, st = self.O.solve_step(self.x_n, self.opts)
         self.u_sol.x.array[:] = self.x_n[: 2 * self.nv]
         self.p_sol.x.array[:] = self.x_n[2 * self.nv:]
         self.last_stats = st
         self.calls += 1
+
+    def advance(self):
+        """u_prev <- u_sol, p_prev <- p_sol (scenario.py:306-307)."""
+        self.u_prev.x.array[:] = self.u_sol.x.array
+        self.p_prev.x.array[:] = self.p_sol.x.array
 
     def functional(self, kind, marker=0):
         """Same contract as the product Solver.functional (cfdh_functional kinds 0-3)."""

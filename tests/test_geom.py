@@ -1,0 +1,131 @@
+"""Geometry of BASELINE configs 4 and 5 (CPU): the vascular-tree generator against fixtures generated FROM the
+reference's own pure-Python generator (tools/gen_tree_golden.py -> tests/golden/tree2d.npz), the Bezier-walled
+stenosis outline of stenosis.py:262-374, and the implicit-domain mesher."""
+import os
+
+import numpy as np
+import pytest
+
+from cfd_hemodynamic_amd.geom.implicit_mesh import keep_largest_component, mesh_implicit_domain, mesh_quality
+from cfd_hemodynamic_amd.geom.shapes import Polygon, StenosedChannel, branch_polygon
+from cfd_hemodynamic_amd.geom.vascular_tree import VascularTree
+from cfd_hemodynamic_amd.mesh import Mesh, create_stenosis_channel, create_stenosis_tree
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tree2d.npz")
+
+
+def test_vascular_tree_matches_reference_generator_bit_for_bit():
+    g = np.load(GOLD)
+    assert int(g["ncases"]) == 4
+    for k in range(int(g["ncases"])):
+        p = g["c%d_params" % k]
+        t = VascularTree(p[0], int(p[1]), p[2], p[3], p[4], p[5]).generate((p[6], p[7]), p[8])
+        assert np.array_equal(t.edges, g["c%d_edges" % k])          # depth-first pre-order numbering
+        assert np.array_equal(t.nodes, g["c%d_nodes" % k])          # same floating-point operations
+        assert np.array_equal(t.radius, g["c%d_radius" % k]) and np.array_equal(t.parent_radius, g["c%d_rparent" % k])
+        assert list(t.terminals) == list(g["c%d_terminals" % k])
+        assert len(t.terminals) == 2 ** int(p[1])
+        b = np.array(t.bifurcations).reshape(-1, 2)
+        assert np.array_equal(b, g["c%d_bif" % k])
+
+
+def test_murray_law_and_flow_split():
+    t = VascularTree(1.0, 2, gamma=2.7, asymmetry=0.35)
+    rl, rr = t.child_radii(1.0)
+    assert abs(rl ** 2.7 + rr ** 2.7 - 1.0) < 1e-14
+    assert abs((rl / rr) ** 3 - 0.35 / 0.65) < 1e-14
+    with pytest.raises(ValueError):
+        VascularTree(asymmetry=1.0)
+
+
+def test_stenosis_outline_is_the_references():
+    """stenosis.py:262-374 with the defaults of :60-69 and grade "moderate" (:27-31)."""
+    ch = StenosedChannel(138.0, 1.57, 1.2, 30.0, 0.5, 0.3, 0.5, yc=1.57, clamp_frac=None)
+    r_mid = 1.57 + (1.2 - 1.57) * 30.0 / 138.0
+    assert abs(ch.R_min - 0.5 * r_mid) < 1e-15 and abs(ch.dist_x - 0.5 * r_mid / 0.3) < 1e-14
+    x = np.array([0.0, ch.x1, 30.0, ch.x2, 138.0])
+    R = ch.radius(x)
+    taper = 1.57 + (1.2 - 1.57) * x / 138.0
+    assert np.allclose(R[[0, 1, 3, 4]], taper[[0, 1, 3, 4]], rtol=0, atol=1e-13) and abs(R[2] - ch.R_min) < 1e-13
+    # C1 at the junctions and the throat: slope equals the taper slope there (handles lie along it)
+    eps = 1e-6
+    for xx in (ch.x1, 30.0, ch.x2):
+        dl = (ch.radius(np.array([xx]))[0] - ch.radius(np.array([xx - eps]))[0]) / eps
+        dr = (ch.radius(np.array([xx + eps]))[0] - ch.radius(np.array([xx]))[0]) / eps
+        assert abs(dl - ch.s) < 2e-5 and abs(dr - ch.s) < 2e-5
+    # the Bezier really is the cubic with the reference's control points: midpoint of B1 at t = 1/2
+    P = ch.B1
+    mid = 0.125 * P[0] + 0.375 * P[1] + 0.375 * P[2] + 0.125 * P[3]
+    assert abs(ch.radius(np.array([mid[0]]))[0] - mid[1]) < 1e-12
+    mesh, ft = create_stenosis_channel(12)
+    wall = np.unique(mesh.facet_vertices[ft.find(4)])
+    assert np.allclose(np.abs(mesh.x[wall, 1] - 1.57), ch.radius(mesh.x[wall, 0]), rtol=0, atol=1e-12)
+    assert len(ft.find(2)) == len(ft.find(3)) == 12
+    assert np.isclose(mesh.x[:, 0], 30.0).any() and mesh.x[:, 0].max() == 138.0
+    ang, _ = mesh_quality(mesh.x, mesh.cells)
+    assert ang > 35.0  # columns follow the local height: no thin cells in the throat
+
+
+def _edge_counts(cells):
+    e = np.concatenate([cells[:, [1, 2]], cells[:, [2, 0]], cells[:, [0, 1]]])
+    e.sort(axis=1)
+    _, cnt = np.unique(e, axis=0, return_counts=True)
+    return cnt
+
+
+def test_implicit_mesher_on_a_disk():
+    phi = lambda q: np.hypot(q[:, 0] - 0.1, q[:, 1] + 0.05) - 1.0
+    errs = []
+    for h in (0.1, 0.05):
+        x, cells = mesh_implicit_domain(phi, (-1.0, -1.15, 1.2, 1.0), h)
+        m = Mesh(cells, x)
+        assert np.array_equal(m.cells, cells)              # already counter-clockwise
+        cnt = _edge_counts(cells)
+        assert set(np.unique(cnt)) <= {1, 2}                # conforming: every edge in one or two cells
+        bv = np.unique(m.facet_vertices)
+        assert np.abs(phi(x[bv])).max() < 1e-9              # boundary vertices ON the level set
+        assert (phi(x) < 1e-9).all()
+        fv = m.facet_vertices
+        per = np.linalg.norm(x[fv[:, 0]] - x[fv[:, 1]], axis=1).sum()
+        errs.append((abs(m.cell_areas().sum() - np.pi), abs(per - 2 * np.pi)))
+        ang, amin = mesh_quality(x, cells)
+        assert ang > 8.0 and amin > 0.02
+    assert errs[1][0] < 0.3 * errs[0][0] and errs[1][0] < 3e-3   # second order in h (inscribed polygon)
+    x2, c2 = keep_largest_component(x, cells)
+    assert len(c2) == len(cells)
+
+
+def test_polygon_signed_distance_and_branch_channel():
+    sq = Polygon([(0, 0), (2, 0), (2, 1), (0, 1)])
+    q = np.array([[1.0, 0.5], [3.0, 0.5], [1.0, -0.25], [-1.0, -1.0], [0.1, 0.9]])
+    assert np.allclose(sq.phi(q), [-0.5, 1.0, 0.25, np.sqrt(2.0), -0.1])
+    poly, cap = branch_polygon((0, 0), (4, 1), (1, 0), 0.3)
+    assert poly.shape == (26, 2)
+    # starts perpendicular to the incoming direction, ends perpendicular to the chord (stenosis_with_tree.py:379-403)
+    assert np.allclose(poly[0], (0, 0.3)) and np.allclose(poly[-1], (0, -0.3))
+    tout = np.array([4.0, 1.0]) / np.hypot(4, 1)
+    assert abs((cap[0] - cap[1]) @ tout) < 1e-12 and abs(np.linalg.norm(cap[0] - cap[1]) - 0.6) < 1e-12
+
+
+def test_stenosis_tree_domain():
+    """Union of channel, coupling trapezoid and the 15 branch channels of a 3-generation tree (config 5, coarse)."""
+    H, L = 0.003, 0.03
+    out = {}
+    for res in (2e-4, 1e-4):
+        mesh, ft = create_stenosis_tree(res, severity=0.5, slope=0.5)
+        assert set(np.unique(_edge_counts(mesh.cells))) <= {1, 2}
+        fv = mesh.facet_vertices
+        ln = np.linalg.norm(mesh.x[fv[:, 0]] - mesh.x[fv[:, 1]], axis=1)
+        out[res] = (mesh.cell_areas().sum(), ln[ft.values == 2].sum(), ln[ft.values == 3].sum())
+        assert len(mesh.tree.terminals) == 8 and len(mesh.outlet_caps) == 8
+        # every terminal cap carries outlet facets, and only facets on a cap do
+        mid = mesh.facet_midpoints()[ft.values == 3]
+        near = np.array([min(np.linalg.norm(m - 0.5 * (a + b)) for a, b in mesh.outlet_caps) for m in mid])
+        assert near.max() < mesh.r_root and len(mid) >= 8 * 2
+        assert mesh.x[:, 0].min() >= -1e-12 and mesh.x[:, 0].max() > L + mesh.coupling_length
+        ang, _ = mesh_quality(mesh.x, mesh.cells)
+        assert ang > 5.0
+    r_term = 0.9 * H / 2 * 0.5 * 0.5  # r_root halves over three symmetric Murray generations (2^(-1/3))^3
+    assert abs(out[1e-4][0] - out[2e-4][0]) < 2e-3 * out[1e-4][0]              # area converged to 0.2 %
+    assert abs(out[1e-4][1] - H) < 0.05 * H                                     # inlet = the channel height
+    assert abs(out[1e-4][2] - 8 * 2 * r_term) < 0.08 * 8 * 2 * r_term          # outlets = the eight caps

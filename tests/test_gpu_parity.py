@@ -369,18 +369,23 @@ def test_lid_cavity_config_c2():
     assert np.linalg.norm(sols[0][1] - sols[1][1]) <= 1e-6 * np.linalg.norm(sols[1][1])
 
 
-def test_wall_shear_stress_device_matches_host_restatement():
-    """cfdh_wall_shear_stress (the per-step assemble_wss of solverBase.py:163-195 on the device)
-    against the numpy restatement in SolverBase.assemble_wss, after a few scenario steps."""
+def test_wall_shear_stress_device_matches_oracle():
+    """cfdh_wall_shear_stress (the per-step assemble_wss of solverBase.py:163-195 on the device) against the C
+    oracle's restatement (orc_wss), after a few scenario steps; the host restatement kept in SolverBase agrees too."""
     from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
     from cfd_hemodynamic_amd.solverBase import SolverBase
     sc = DFG1Benchmark("stabilized_schur", 0.01, 0.035, m=10, quiet=True)
     sc.solve(None, device_resident=True)
-    dev = sc.solver.shear_stress.x.array.copy()
+    dev = np.array(sc.solver.shear_stress.x.array, copy=True)
+    case = dfg_case(10)
+    O = make_oracle(case)
+    x = np.concatenate([np.asarray(sc.solver.u_sol.x.array), np.asarray(sc.solver.p_sol.x.array)])
+    ref = O.wall_shear_stress(x)
+    assert np.abs(ref).max() > 1e-4
+    assert np.abs(dev - ref).max() <= 1e-13 * np.abs(ref).max()
     SolverBase.assemble_wss(sc.solver)
-    host = sc.solver.shear_stress.x.array.copy()
-    assert np.abs(host).max() > 1e-4
-    assert np.abs(dev - host).max() <= 1e-13 * np.abs(host).max()
+    host = np.array(sc.solver.shear_stress.x.array, copy=True)
+    assert np.abs(host - ref).max() <= 1e-13 * np.abs(ref).max()
     # zero away from the boundary
     interior = np.ones(sc.mesh.num_vertices, bool)
     interior[np.unique(sc.mesh.facet_vertices)] = False
