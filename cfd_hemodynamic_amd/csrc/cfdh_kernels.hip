@@ -899,6 +899,31 @@ __device__ __forceinline__ double2 g8(double2 v) { return make_double2(group8_su
 __device__ __forceinline__ double wsum(double v) { return wave_sum(v); }
 __device__ __forceinline__ double2 wsum(double2 v) { return make_double2(wave_sum(v.x), wave_sum(v.y)); }
 
+// One row of a SELL-64 matrix times x, latency-oriented: at ~1 M DOF a sweep is one wave of work per SIMD lane group and
+// 85 % of a wave's life is spent waiting on memory (SQ_WAIT_ANY / SQ_WAVE_CYCLES, profiles/r02_pmc_sq_tcc.json), in a
+// chain  columns -> gathers -> next columns ...  With all column/value loads of the row issued first, then all gathers,
+// the chain is three round trips whatever the row length.  The slice width is wave-uniform: the guards are scalar branches.
+template <int MAXW, typename T>
+__device__ __forceinline__ T sell_row_dot(const int *__restrict__ sp, const int *__restrict__ sc, const float *__restrict__ sv,
+                                          const T *__restrict__ x, int sl, int lane, T a) {
+  sl = __builtin_amdgcn_readfirstlane(sl);  // wave-uniform: slice pointers and width live in scalar registers
+  const int p0 = sp[sl], w = (sp[sl + 1] - p0) >> 6;
+  int cidx[MAXW];
+  float cval[MAXW];
+#pragma unroll
+  for (int k = 0; k < MAXW; k++)
+    if (k < w) { const int p = p0 + k * 64 + lane; cidx[k] = NTLOAD(sc + p); cval[k] = NTLOAD(sv + p); }
+  T g[MAXW];
+#pragma unroll
+  for (int k = 0; k < MAXW; k++)
+    if (k < w) g[k] = x[cidx[k]];
+#pragma unroll
+  for (int k = 0; k < MAXW; k++)
+    if (k < w) a = vfma((double)cval[k], g[k], a);
+  for (int k = MAXW; k < w; k++) { const int p = p0 + k * 64 + lane; a = vfma((double)sv[p], x[sc[p]], a); }
+  return a;
+}
+
 // MODE 0: y = A x; 1: y = b - A x; 2: y += A x; 3: y = b + A x
 template <int MODE, typename T>
 __global__ __launch_bounds__(TPB) void csr_spmv_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
@@ -1047,12 +1072,8 @@ __global__ __launch_bounds__(TPB) void sell_cheb2_scale_kernel(int n, const int 
   if (row >= n) return;
   const int sl = row >> 6, lane = row & 63;
   const int p0 = sptr[sl], w = (sptr[sl + 1] - p0) >> 6;
-  double a = 0.0;
-#pragma unroll 4
-  for (int k = 0; k < w; k++) {
-    const int p = p0 + k * 64 + lane;
-    a = fma((double)NTLOAD(svalw + p), b[NTLOAD(scol + p)], a);
-  }
+  (void)p0; (void)w;
+  const double a = sell_row_dot<10, double>(sptr, scol, svalw, b, sl, lane, 0.0);
   const double bi = b[row];
   const double dd = wdinv[row] * bi;
   const double xv = dd + (c1 * dd + c2 * dinv[row] * (bi - a));
@@ -1251,6 +1272,8 @@ __device__ __forceinline__ double epi_apply(double acc, int row, double alpha, d
   return (pbc[row] & 1) ? r[row] : alpha * acc + beta * zH[row];
 }
 __device__ __forceinline__ double2 epi_apply(double2 acc, int, double, double, const double *, const double *, const unsigned char *) { return acc; }
+__device__ __forceinline__ double epi_value(double acc, unsigned flag, double alpha, double beta, double zh, double r) { return (flag & 1u) ? r : alpha * acc + beta * zh; }
+__device__ __forceinline__ double2 epi_value(double2 acc, unsigned, double, double, double, double) { return acc; }
 
 // y = G x, LPR lanes per row (rows of the coarse level: tens to hundreds of entries)
 template <int LPR, typename VT, typename T>
@@ -1261,7 +1284,17 @@ __global__ __launch_bounds__(TPB) void fused_down_kernel(int n, const int *__res
   T a = vzero((const T *)nullptr);
   if (row < n) {
     const int ks = rowptr[row], ke = rowptr[row + 1];
-    for (int k = ks + l; k < ke; k += LPR) a = vfma((double)val[k], x[col[k]], a);
+    // up to four entries per lane with all loads in flight together, then the gathers (see sell_row_dot)
+    int cidx[4];
+    VT cval[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int k = ks + l + q * LPR; if (k < ke) { cidx[q] = col[k]; cval[q] = val[k]; } }
+    T g[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int k = ks + l + q * LPR; if (k < ke) g[q] = x[cidx[q]]; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int k = ks + l + q * LPR; if (k < ke) a = vfma((double)cval[q], g[q], a); }
+    for (int k = ks + l + 4 * LPR; k < ke; k += LPR) a = vfma((double)val[k], x[col[k]], a);
   }
   a = lsum<LPR>(a);
   if (row < n && l == 0) y[row] = a;
@@ -1295,19 +1328,36 @@ __global__ __launch_bounds__(TPB) void fused_up_sell_kernel(int n, const int *__
                                                             const double *__restrict__ er, const unsigned char *__restrict__ epbc) {
   const int row = blockIdx.x * TPB + threadIdx.x;
   if (row >= n) return;
-  const int sl = row >> 6, lane = row & 63;
+  const int sl = __builtin_amdgcn_readfirstlane(row >> 6), lane = row & 63;
   T a = vzero((const T *)nullptr);
-  {
-    const int p0 = spB[sl], w = (spB[sl + 1] - p0) >> 6;
-#pragma unroll 4
-    for (int k = 0; k < w; k++) { const int p = p0 + k * 64 + lane; a = vfma((double)NTLOAD(svB + p), b[NTLOAD(scB + p)], a); }
-  }
-  if (spC) {
-    const int p0 = spC[sl], w = (spC[sl + 1] - p0) >> 6;
-#pragma unroll 4
-    for (int k = 0; k < w; k++) { const int p = p0 + k * 64 + lane; a = vfma((double)NTLOAD(svC + p), xc[NTLOAD(scC + p)], a); }
-  }
-  x[row] = epbc ? epi_apply(a, row, ea, eb, ezH, er, epbc) : a;
+  // operands of the epilogue: requested now, so that they arrive together with the matrix data
+  double e_zh = 0.0, e_r = 0.0;
+  unsigned e_f = 0;
+  if (epbc) { e_f = epbc[row]; e_zh = ezH[row]; e_r = er[row]; }
+  // both matrices together: slice pointers, then ALL column/value loads of the row, then ALL gathers (three
+  // dependent round trips; the straightforward loops make about ten)
+  constexpr int MW = sizeof(T) > 8 ? 8 : 10;
+  const int pB = spB[sl], wB = (spB[sl + 1] - pB) >> 6;
+  int pC = 0, wC = 0;
+  if (spC) { pC = spC[sl]; wC = (spC[sl + 1] - pC) >> 6; }
+  int cB[MW], cC[MW];
+  float vB[MW], vC[MW];
+#pragma unroll
+  for (int k = 0; k < MW; k++) if (k < wB) { const int p = pB + k * 64 + lane; cB[k] = NTLOAD(scB + p); vB[k] = NTLOAD(svB + p); }
+#pragma unroll
+  for (int k = 0; k < MW; k++) if (k < wC) { const int p = pC + k * 64 + lane; cC[k] = NTLOAD(scC + p); vC[k] = NTLOAD(svC + p); }
+  T gB[MW], gC[MW];
+#pragma unroll
+  for (int k = 0; k < MW; k++) if (k < wB) gB[k] = b[cB[k]];
+#pragma unroll
+  for (int k = 0; k < MW; k++) if (k < wC) gC[k] = xc[cC[k]];
+#pragma unroll
+  for (int k = 0; k < MW; k++) if (k < wB) a = vfma((double)vB[k], gB[k], a);
+#pragma unroll
+  for (int k = 0; k < MW; k++) if (k < wC) a = vfma((double)vC[k], gC[k], a);
+  for (int k = MW; k < wB; k++) { const int p = pB + k * 64 + lane; a = vfma((double)svB[p], b[scB[p]], a); }
+  for (int k = MW; k < wC; k++) { const int p = pC + k * 64 + lane; a = vfma((double)svC[p], xc[scC[p]], a); }
+  x[row] = epbc ? epi_value(a, e_f, ea, eb, e_zh, e_r) : a;
 }
 // x = Sb b + D bc with the dense folded coarse correction D [n][nc] (fp32), one wave per row
 template <typename T>
@@ -1331,7 +1381,7 @@ __global__ __launch_bounds__(TPB) void fused_up_dense_kernel(int n, const int *_
 template <typename VT, typename T>
 static void launch_down(cfdh_ctx *c, const CsrDev &G, const VT *val, const T *x, T *y) {
   const long long avg = G.n > 0 ? (G.nnz + G.n - 1) / G.n : 1;
-  const int lpr = avg > 48 ? 64 : (avg > 24 ? 32 : (avg > 12 ? 16 : 8));
+  const int lpr = avg > 96 ? 64 : (avg > 48 ? 32 : (avg > 20 ? 16 : 8));  // 2-4 entries per lane, loaded together
   dim3 block(TPB), grid((unsigned)(((long long)G.n * lpr + TPB - 1) / TPB));
   if (lpr == 64) hipLaunchKernelGGL((fused_down_kernel<64, VT, T>), grid, block, 0, c->stream, G.n, G.rowptr.p, G.col.p, val, x, y);
   else if (lpr == 32) hipLaunchKernelGGL((fused_down_kernel<32, VT, T>), grid, block, 0, c->stream, G.n, G.rowptr.p, G.col.p, val, x, y);

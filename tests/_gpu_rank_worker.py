@@ -39,8 +39,8 @@ def main():
         sc = StenosisSimulation("stabilized_schur_backflow", 0.01, 0.035, ny=12, L=30.0, x_sten=10.0, v_max=60.0, quiet=True,
                                 beta_backflow=0.2, device=0, comm=comm, options=tight)
     else:
-        sc = DFG1Benchmark(os.environ.get("CFDH_TEST_SOLVER", "stabilized_schur"), 0.01, 0.05, m=16, quiet=True, device=0,
-                           comm=comm, options=tight)
+        sc = DFG1Benchmark(os.environ.get("CFDH_TEST_SOLVER", "stabilized_schur"), 0.01, float(os.environ.get("CFDH_TEST_T", "0.05")),
+                           m=int(os.environ.get("CFDH_TEST_M", "16")), quiet=True, device=0, comm=comm, options=tight)
     outdir = os.environ.get("CFDH_TEST_OUTDIR") or None
     ctx = sc.solver.ctx
     ctx.profile_reset()  # zero the communication counters after setup

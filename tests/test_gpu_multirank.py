@@ -207,3 +207,36 @@ def test_partitioned_run_with_output_folder_writes_each_file_once(tmp_path):
     # communication per FGMRES iteration of this configuration (host-staged backend, 2 ranks)
     ar, halo, sync, its = (int(v) for v in r["counters"][:4])
     assert its > 0 and ar / its < 8 and halo / its < 8
+
+
+@pytest.mark.parametrize("world", [4, 6])
+def test_rccl_path_at_quarter_million_dof_with_4_and_6_ranks(tmp_path, world):
+    """DFG mesh m=100 (84 k vertices, 252 k DOF) through the RCCL code path (shared-memory stand-in) with 4 and 6 ranks
+    -- six is the most processes the test box lets share its GPU; the 8-rank run is the driver's.  Solution equal to
+    one rank's to 1e-9, FGMRES iterations within 1.3x, distributed finest pressure level and overlapping velocity
+    cycle in use, and the communication of one Krylov iteration counted."""
+    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+    fake = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "fake_rccl"), "-s"])
+    tight = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
+    ref = DFG1Benchmark("stabilized_schur", 0.01, 0.025, m=100, quiet=True, options=tight)
+    assert 3 * ref.mesh.num_vertices > 250000
+    ref.solve(None)
+    ref_krylov = sum(st.krylov_its for _, st in ref.step_stats)
+    u0, p0 = np.asarray(ref.solver.u_sol.x.array).copy(), np.asarray(ref.solver.p_sol.x.array).copy()
+    r = _run(world, str(tmp_path / ("big%d.npz" % world)), timeout=600, CFDH_TEST_BACKEND="rccl", CFDH_RCCL_LIB=fake,
+             CFDH_TEST_M="100", CFDH_TEST_T="0.025")
+    assert str(r["backend"]) == "rccl" and int(r["rccl_attached"]) == 1
+    assert int(r["steps"]) == ref.num_steps == 3
+    assert np.linalg.norm(r["u"] - u0) <= 1e-9 * np.linalg.norm(u0)
+    assert np.linalg.norm(r["p"] - p0) <= 1e-8 * np.linalg.norm(p0)
+    assert abs(float(r["drag"]) - ref.drag) <= 1e-8 * abs(ref.drag)
+    assert int(r["ras"]) == 1 and int(r["dist_coarse"]) > 0
+    assert int(r["krylov"]) <= 1.3 * ref_krylov, (int(r["krylov"]), ref_krylov)
+    ar, halo, sync, its, ag, size = (int(v) for v in r["counters"])
+    assert size == world and its == int(r["krylov"])
+    # per FGMRES iteration: 4 halo exchanges (iterate, pressure rhs, z_p, overlap residual) and 2 all-reduces (coarse
+    # pressure rhs, Gram-Schmidt coefficients) -- 4 here, because at ksp_rtol 1e-10 every iteration takes the second
+    # Gram-Schmidt pass (coefficients + norm); plus the per-solve and per-Newton-step reductions
+    assert 3.9 <= halo / its <= 4.6 and 3.9 <= ar / its <= 4.8 and sync / its <= 2.2, (halo / its, ar / its, sync / its)
