@@ -345,7 +345,7 @@ def main():
         ncpu = nst - args.warmup
         tcpu = time.perf_counter() - t0
         out["cpu_baseline"] = {
-            "value": ncpu / tcpu, "unit": "time-steps/s", "cores": cores, "kind": "port",
+            "value": ncpu / tcpu, "unit": "time-steps/s", "cores": cores, "kind": "port", "host_cores_available": host_cores(),
             "sample": "steps %d..%d of the same mesh/dt from t=0 with the C oracle (oracle/cfdh_oracle.c, pc_kind=2: "
                       "same Newton + FGMRES + Cahouet-Chabard/AMG preconditioner and tolerances, FULL Schur factorisation = "
                       "the faster variant on the CPU, OpenMP)" % (args.warmup + 1, nst),

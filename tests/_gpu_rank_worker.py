@@ -34,6 +34,10 @@ def main():
     if case == "lid":       # singular pressure (no pressure condition)
         from cfd_hemodynamic_amd.scenarios.lid_driven2D import LidDriven2DSimulation
         sc = LidDriven2DSimulation("stabilized_schur", 0.01, 0.035, nx=48, mu=0.01, quiet=True, device=0, comm=comm, options=tight)
+    elif case == "stenosis_c4":  # BASELINE config 4 at size: stenosis "moderate", reference geometry
+        from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
+        sc = StenosisSimulation("stabilized_schur", 0.01, float(os.environ.get("CFDH_TEST_T", "0.015")), grade="moderate",
+                                ny=int(os.environ.get("CFDH_TEST_NY", "115")), v_max=100.0, quiet=True, device=0, comm=comm, options=tight)
     elif case == "stenosis_backflow":  # do-nothing outlet, backflow facet term, no pressure Dirichlet set
         from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
         sc = StenosisSimulation("stabilized_schur_backflow", 0.01, 0.035, ny=12, L=30.0, x_sten=10.0, v_max=60.0, quiet=True,

@@ -142,3 +142,20 @@ def test_config5_full_size_properties():
     # the tree is symmetric about the artery axis (asymmetry 0.5): mirrored outlets carry the same flow
     assert np.allclose(q, q[::-1], rtol=5e-2)
     assert np.isfinite(sc.solver.functional(2)) and sc.solver.functional(3) > 0
+
+
+def test_config1_dfg_coarse_full_run_to_T1(oracle_double):
+    """BASELINE configs[0] as the reference runs it: `simulate --simulation dfg_1 --solver stabilized_schur --T 1.0
+    --dt 0.01` on the coarse mesh (m=18 ~ the gmsh sizes of dfg_1.py:146-155, 8.2 k DOF), PETSc-default tolerances,
+    the whole Scenario.solve loop with its early-stop bookkeeping -- on libcfdh.so and on the oracle-backed double."""
+    from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+    g = DFG1Benchmark("stabilized_schur", 0.01, 1.0, m=18, quiet=True)
+    g.solve(None)
+    o = DFG1Benchmark(oracle_double, 0.01, 1.0, m=18, quiet=True, pc_kind=1)
+    o.solve(None)
+    assert g.num_steps == o.num_steps == 100 and not g.stopped_early  # float-accumulated `while t < T` (scenario.py:243-250)
+    # default tolerances on both sides: agreement at the solver-noise level after 100 steps
+    assert abs(g.norm_v - o.norm_v) <= 1e-6 * o.norm_v and abs(g.norm_p - o.norm_p) <= 1e-5 * o.norm_p
+    od, ol = 500 * o.solver.functional(0, 5), 500 * o.solver.functional(1, 5)
+    assert abs(g.drag - od) <= 1e-5 * abs(od) and abs(g.lift - ol) <= 5e-3 * abs(ol) + 1e-6
+    assert 5.0 < g.drag < 6.5 and g.p_diff is not None and 0.09 < g.p_diff < 0.14

@@ -240,3 +240,27 @@ def test_rccl_path_at_quarter_million_dof_with_4_and_6_ranks(tmp_path, world):
     # pressure rhs, Gram-Schmidt coefficients) -- 4 here, because at ksp_rtol 1e-10 every iteration takes the second
     # Gram-Schmidt pass (coefficients + norm); plus the per-solve and per-Newton-step reductions
     assert 3.9 <= halo / its <= 4.6 and 3.9 <= ar / its <= 4.8 and sync / its <= 2.2, (halo / its, ar / its, sync / its)
+
+
+def test_config4_stenosis_partitioned_over_4_ranks_at_full_size(tmp_path):
+    """BASELINE configs[3]: stenosis "moderate" ~2 M DOF, element partition over 4 ranks with RCCL halo + dot all-reduce --
+    here 4 ranks on the one test GPU through the RCCL stand-in (same library code).  Two steps; solution equal to the
+    single-rank run, iteration count close to it."""
+    from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
+    fake = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "fake_rccl"), "-s"])
+    tight = dict(snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-9)
+    ref = StenosisSimulation("stabilized_schur", 0.01, 0.015, grade="moderate", ny=115, v_max=100.0, quiet=True, options=tight)
+    assert 3 * ref.mesh.num_vertices == 2034408
+    ref.solve(None)
+    ref_krylov = sum(st.krylov_its for _, st in ref.step_stats)
+    u0, p0 = np.asarray(ref.solver.u_sol.x.array).copy(), np.asarray(ref.solver.p_sol.x.array).copy()
+    del ref
+    r = _run(4, str(tmp_path / "c4.npz"), timeout=900, CFDH_TEST_BACKEND="rccl", CFDH_RCCL_LIB=fake, CFDH_TEST_CASE="stenosis_c4",
+             CFDH_TEST_SNES_RTOL="1e-11", CFDH_TEST_KSP_RTOL="1e-9")
+    assert int(r["steps"]) == 2 and str(r["backend"]) == "rccl"
+    assert np.linalg.norm(r["u"] - u0) <= 1e-8 * np.linalg.norm(u0)
+    assert np.linalg.norm(r["p"] - p0) <= 1e-7 * np.linalg.norm(p0)
+    assert int(r["ras"]) == 1 and int(r["dist_coarse"]) > 0
+    assert int(r["krylov"]) <= 1.5 * ref_krylov, (int(r["krylov"]), ref_krylov)
