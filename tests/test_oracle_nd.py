@@ -1,0 +1,139 @@
+"""The dimension-generic NumPy twin (oracle/np_twin_nd.py): for d = 2 it must reproduce oracle/np_twin.py to round-off,
+which pins the d = 3 instance (tetrahedra: 12 + 4 element dofs); for d = 3 the Jacobian is the derivative of the
+residual, patch solutions give zero residuals, and a small Poiseuille-type pipe run behaves."""
+import numpy as np
+
+from cfd_hemodynamic_amd.mesh import create_unit_square
+from cfd_hemodynamic_amd.mesh3d import Mesh3D, create_bifurcation, create_unit_cube
+from oracle import np_twin as T2
+from oracle import np_twin_nd as TN
+
+
+def test_d2_instance_equals_the_2d_twin():
+    m = create_unit_square(5)
+    rng = np.random.default_rng(0)
+    x = m.x + 0.02 * rng.standard_normal(m.x.shape) * (np.abs(m.x - 0.5).max(axis=1) < 0.49)[:, None]
+    nv = len(x)
+    u, un, p = rng.standard_normal((nv, 2)), rng.standard_normal((nv, 2)), rng.standard_normal(nv)
+    for th, a in ((0.5, (1.0, -1.0, 0.0)), (1.0, (1.5, -2.0, 0.5))):
+        p2 = T2.Params(0.013, 1.3, 0.07, (0.3, -0.2), theta=th, a0=a[0], a1=a[1], a2=a[2])
+        pn = TN.Params(0.013, 1.3, 0.07, (0.3, -0.2), theta=th, a0=a[0], a1=a[1], a2=a[2])
+        ff = np.zeros(len(m.cells), dtype=np.uint8)
+        np.bitwise_or.at(ff, m.facet_cells, (1 << m.facet_local).astype(np.uint8))
+        F2, J2 = T2.element_tensors(x, m.cells, u, un, p, p2, ff, un2=un[::-1].copy())
+        Fn, Jn = TN.element_tensors(x, m.cells.astype(np.int64), u, un, p, pn, ff, un2=un[::-1].copy())
+        assert np.abs(F2 - Fn).max() <= 1e-13 * np.abs(F2).max()
+        assert np.abs(J2 - Jn).max() <= 1e-13 * np.abs(J2).max()
+    # assembled problem with Dirichlet data
+    a2 = T2.Problem(x, m.cells, m.facet_cells, m.facet_local, p2)
+    an = TN.Problem(x, m.cells, m.facet_cells, m.facet_local, pn)
+    nodes = np.unique(m.facet_vertices[:7])
+    for pb in (a2, an):
+        pb.add_bc_u(nodes, np.tile([0.3, -0.1], (len(nodes), 1)))
+        pb.add_bc_p(nodes[:2], [0.5, 0.25])
+    xv = rng.standard_normal(3 * nv)
+    F2, J2 = a2.assemble(xv, un, un2=un[::-1].copy())
+    Fn, Jn = an.assemble(xv, un, un2=un[::-1].copy())
+    assert np.abs(F2 - Fn).max() <= 1e-13 * np.abs(F2).max() and abs(J2 - Jn).max() <= 1e-13 * abs(J2).max()
+
+
+def _cube_problem(n=2, seed=1, **kw):
+    m = create_unit_cube(n)
+    rng = np.random.default_rng(seed)
+    interior = (np.abs(m.x - 0.5).max(axis=1) < 0.49)
+    x = m.x + (0.1 / n) * rng.standard_normal(m.x.shape) * interior[:, None]
+    prm = TN.Params(kw.get("dt", 0.02), kw.get("rho", 1.2), kw.get("mu", 0.05), kw.get("f", (0.1, -0.3, 0.2)),
+                    theta=kw.get("theta", 0.5), a0=kw.get("a0", 1.0), a1=kw.get("a1", -1.0), a2=kw.get("a2", 0.0))
+    mm = Mesh3D(m.cells, x)
+    return mm, TN.Problem(mm.x, mm.cells, mm.facet_cells, mm.facet_local, prm), rng
+
+
+def test_reference_simplex_integrals_in_3d():
+    QL, QW = TN.quad_rule(3)
+    assert abs(QW.sum() - 1.0) < 1e-14 and QL.shape == (343, 4)
+    # int l0^a l1^b l2^c l3^d = 3! a! b! c! d! / (a+b+c+d+3)!  (weights normalised to the reference volume)
+    from math import factorial as f
+    for e in [(1, 0, 0, 0), (2, 0, 0, 0), (1, 1, 0, 0), (3, 2, 1, 0), (4, 4, 2, 2), (6, 3, 2, 1)]:
+        exact = 6.0 * np.prod([f(k) for k in e]) / f(sum(e) + 3)
+        assert abs((QW * np.prod(QL ** np.array(e), axis=1)).sum() - exact) <= 1e-14 * max(exact, 1e-3)
+    m = create_unit_cube(1)
+    g, vol, h = TN.geometry(m.x, m.cells.astype(np.int64))
+    assert np.allclose(vol, 1.0 / 6.0) and np.allclose(h, np.sqrt(3.0))
+    assert np.allclose(g.sum(axis=1), 0.0, atol=1e-14)
+
+
+def test_3d_jacobian_is_the_derivative_of_the_residual():
+    for kw in ({}, dict(theta=1.0, a0=1.5, a1=-2.0, a2=0.5)):
+        m, pb, rng = _cube_problem(2, **kw)
+        nv = pb.nv
+        xv = rng.standard_normal(4 * nv)
+        un = rng.standard_normal((nv, 3))
+        un2 = rng.standard_normal((nv, 3))
+        F, J = pb.assemble(xv, un, apply_bc=False, un2=un2)
+        assert J.shape == (4 * nv, 4 * nv)
+        v = rng.standard_normal(4 * nv)
+        eps = 1e-6
+        Fp, _ = pb.assemble(xv + eps * v, un, want_jac=False, apply_bc=False, un2=un2)
+        Fm, _ = pb.assemble(xv - eps * v, un, want_jac=False, apply_bc=False, un2=un2)
+        fd = (Fp - Fm) / (2 * eps)
+        assert np.linalg.norm(fd - J @ v) <= 1e-7 * np.linalg.norm(J @ v)
+
+
+def test_3d_patch_solutions():
+    m, pb, rng = _cube_problem(2, f=(0.0, 0.0, 0.0))
+    nv = pb.nv
+    interior = np.ones(nv, bool)
+    interior[np.unique(m.facet_vertices)] = False
+    # uniform flow, constant pressure, u = u_prev: every interior row of the residual vanishes
+    u = np.tile([0.3, -0.2, 0.5], (nv, 1))
+    xv = np.concatenate([u.ravel(), np.full(nv, 0.7)])
+    F, _ = pb.assemble(xv, u, want_jac=False, apply_bc=False)
+    Fu, Fp = F[: 3 * nv].reshape(-1, 3), F[3 * nv:]
+    assert np.abs(Fu[interior]).max() < 1e-13 and np.abs(Fp[interior]).max() < 1e-13
+    # hydrostatic balance: p = rho f . x with the fluid at rest
+    pb.prm.f = np.array([0.2, -0.4, 0.1])
+    xv = np.concatenate([np.zeros(3 * nv), pb.prm.rho * (m.x @ pb.prm.f)])
+    F, _ = pb.assemble(xv, np.zeros((nv, 3)), want_jac=False, apply_bc=False)
+    assert np.abs(F[: 3 * nv].reshape(-1, 3)[interior]).max() < 1e-13 and np.abs(F[3 * nv:][interior]).max() < 1e-13
+    # constant pressure is in the kernel of the Jacobian's pressure columns when every exterior facet carries the ds pair
+    _, J = pb.assemble(np.concatenate([0.1 * rng.standard_normal(3 * nv), np.zeros(nv)]), 0.1 * rng.standard_normal((nv, 3)), apply_bc=False)
+    e = np.zeros(4 * nv)
+    e[3 * nv:] = 1.0
+    assert np.abs(J @ e).max() < 1e-13
+
+
+def test_bifurcation_mesh_and_a_newton_step():
+    mesh, ft = create_bifurcation(0.0012)
+    assert mesh.num_vertices > 300 and set(np.unique(ft.values)) == {8, 9, 10, 11}
+    vol = mesh.cell_volumes().sum()
+    assert abs(vol - (np.pi * mesh.r_in ** 2 * 4 * mesh.r_in + 2 * np.pi * mesh.r_out ** 2 * 5 * mesh.r_in)) < 0.35 * vol  # staircase tubes
+    # inlet facets lie in y = 0 inside the inlet disc, outlets in y = y_end on either side
+    mid = mesh.facet_midpoints()
+    assert np.all(np.hypot(mid[ft.values == 8, 0], mid[ft.values == 8, 2]) < mesh.r_in + 0.0012)
+    assert np.all(mid[ft.values == 9, 0] > 0) and np.all(mid[ft.values == 10, 0] < 0)
+    # one time step of the scenario's boundary data (simple_bifurcation.py:77-133) with the direct solver
+    Re = 1055.0 * 0.01 * ((100 / 0.003918604) / 1e6) / 3.5e-3
+    prm = TN.Params(0.01, 1.0, 1.0 / Re, (0, 0, 0))
+    pb = TN.Problem(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, prm)
+    wall = np.unique(mesh.facet_vertices[ft.find(11)])
+    # rim vertices belong to the wall only here: a dof held by two DirichletBC objects gets the diagonal 2 (DOLFINx block
+    # assembly) and Newton then only HALVES its error per iteration when the two values differ
+    inl = np.setdiff1d(np.unique(mesh.facet_vertices[ft.find(8)]), wall)
+    r = np.hypot(mesh.x[inl, 0], mesh.x[inl, 2])
+    vin = np.zeros((len(inl), 3))
+    vin[:, 1] = 1.5 * (1 - (r / mesh.r_in) ** 2)
+    pb.add_bc_u(wall, np.zeros((len(wall), 3)))
+    pb.add_bc_u(inl, vin)
+    for tag in (9, 10):
+        o = np.unique(mesh.facet_vertices[ft.find(tag)])
+        pb.add_bc_p(o, np.zeros(len(o)))
+    nv = pb.nv
+    x, hist = pb.newton(np.zeros(4 * nv), np.zeros((nv, 3)))
+    assert hist[-1] <= 1e-12 * hist[0] and len(hist) <= 6
+    qin = -pb.flux(x, ft.find(8))
+    qout = pb.flux(x, ft.find(9)) + pb.flux(x, ft.find(10))
+    # first step after an impulsive start on a 3-cells-per-radius staircase mesh: the PSPG term leaks mass at first order in
+    # h (qout/qin = 0.39 / 0.65 / 0.84 at res 1.2e-3 / 8e-4 / 5e-4); the Kuhn tetrahedra are not mirror-symmetric
+    assert qin > 0 and 0.3 * qin < qout < qin
+    assert abs(pb.flux(x, ft.find(9)) - pb.flux(x, ft.find(10))) < 0.05 * qin
+    assert abs(pb.flux(x, ft.find(11))) < 1e-15
