@@ -147,7 +147,12 @@ class Context:
     def __init__(self, x, cells, facet_cells, facet_local, facet_marker, nv_owned=None, device=0):
         L = lib()
         self.L = L
-        self.x = np.ascontiguousarray(x, dtype=np.float64)[:, :2].copy()
+        x = np.asarray(x, dtype=np.float64)
+        cells = np.asarray(cells)
+        self.dim = cells.shape[1] - 1  # triangles -> 2, tetrahedra -> 3
+        if self.dim not in (2, 3) or x.shape[1] < self.dim:
+            raise ValueError("cells must be triangles [nc,3] or tetrahedra [nc,4] with matching coordinates")
+        self.x = np.ascontiguousarray(x[:, : self.dim]).copy()
         self.cells = np.ascontiguousarray(cells, dtype=np.int32)
         self.nv = len(self.x)
         self.nvo = self.nv if nv_owned is None else int(nv_owned)
@@ -155,7 +160,7 @@ class Context:
         fl = np.ascontiguousarray(facet_local, dtype=np.int32)
         fm = np.ascontiguousarray(facet_marker, dtype=np.int32)
         h = C.c_void_p()
-        rc = L.cfdh_create(C.byref(h), int(device), 2, self.nv, self.nvo, len(self.cells), _ip(self.cells), _dp(self.x),
+        rc = L.cfdh_create(C.byref(h), int(device), self.dim, self.nv, self.nvo, len(self.cells), _ip(self.cells), _dp(self.x),
                            len(fc), _ip(fc), _ip(fl), _ip(fm))
         if rc != 0:
             _raise(rc, "cfdh_create failed: " + L.cfdh_last_error(None).decode())
@@ -179,7 +184,8 @@ class Context:
 
     def set_params(self, dt, rho, mu, mu_facet=None, f=(0.0, 0.0)):
         ff = np.zeros(3)
-        ff[: len(f)] = np.asarray(f, dtype=np.float64)[:3]
+        f = np.atleast_1d(np.asarray(f, dtype=np.float64))[:3]
+        ff[: len(f)] = f
         self._chk(self.L.cfdh_set_params(self.h, dt, rho, mu, mu if mu_facet is None else mu_facet, _dp(ff)))
 
     def default_options(self):
@@ -200,25 +206,25 @@ class Context:
 
     def set_state(self, u_prev=None, p_prev=None, u=None, p=None):
         a = [None if v is None else np.ascontiguousarray(v, dtype=np.float64).reshape(-1) for v in (u_prev, p_prev, u, p)]
-        for v, n in zip(a, (2 * self.nv, self.nv, 2 * self.nv, self.nv)):
+        for v, n in zip(a, (self.dim * self.nv, self.nv, self.dim * self.nv, self.nv)):
             if v is not None and v.size != n:
                 raise ValueError("state array has wrong size")
         self._chk(self.L.cfdh_set_state(self.h, _dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(a[3])))
 
     def get_solution(self, u=None, p=None):
-        u = np.empty(2 * self.nv) if u is None else u
+        u = np.empty(self.dim * self.nv) if u is None else u
         p = np.empty(self.nv) if p is None else p
         self._chk(self.L.cfdh_get_solution(self.h, _dp(u), _dp(p)))
         return u, p
 
     def get_previous(self, u=None, p=None):
-        u = np.empty(2 * self.nv) if u is None else u
+        u = np.empty(self.dim * self.nv) if u is None else u
         p = np.empty(self.nv) if p is None else p
         self._chk(self.L.cfdh_get_previous(self.h, _dp(u), _dp(p)))
         return u, p
 
     def get_residual(self):
-        ru, rp = np.zeros(2 * self.nv), np.zeros(self.nv)
+        ru, rp = np.zeros(self.dim * self.nv), np.zeros(self.nv)
         self._chk(self.L.cfdh_get_residual(self.h, _dp(ru), _dp(rp)))
         return ru, rp
 
@@ -243,17 +249,17 @@ class Context:
         if not download:
             self._chk(self.L.cfdh_wall_shear_stress(self.h, None))
             return None
-        out = np.zeros(2 * self.nv)
+        out = np.zeros(self.dim * self.nv)
         self._chk(self.L.cfdh_wall_shear_stress(self.h, _dp(out)))
         return out
 
     def set_previous2(self, u_prev2):
         u_prev2 = np.ascontiguousarray(u_prev2, dtype=np.float64).reshape(-1)
-        assert u_prev2.size == 2 * self.nv
+        assert u_prev2.size == self.dim * self.nv
         self._chk(self.L.cfdh_set_previous2(self.h, _dp(u_prev2)))
 
     def get_previous2(self):
-        u = np.empty(2 * self.nv)
+        u = np.empty(self.dim * self.nv)
         self._chk(self.L.cfdh_get_previous2(self.h, _dp(u)))
         return u
 
@@ -267,15 +273,16 @@ class Context:
         import scipy.sparse as sp
         nnz = C.c_int64()
         self._chk(self.L.cfdh_get_csr(self.h, C.byref(nnz), None, None, None))
-        rowptr = np.empty(3 * self.nvo + 1, dtype=np.int32)
+        n1 = self.dim + 1
+        rowptr = np.empty(n1 * self.nvo + 1, dtype=np.int32)
         col = np.empty(nnz.value, dtype=np.int32)
         val = np.empty(nnz.value)
         self._chk(self.L.cfdh_get_csr(self.h, C.byref(nnz), _ip(rowptr), _ip(col), _dp(val)))
-        return sp.csr_matrix((val, col, rowptr), shape=(3 * self.nvo, 3 * self.nv))
+        return sp.csr_matrix((val, col, rowptr), shape=(n1 * self.nvo, n1 * self.nv))
 
     def spmv(self, xvec):
         xvec = np.ascontiguousarray(xvec, dtype=np.float64)
-        y = np.empty(3 * self.nvo)
+        y = np.empty((self.dim + 1) * self.nvo)
         self._chk(self.L.cfdh_spmv(self.h, _dp(xvec), _dp(y)))
         return y
 

@@ -38,7 +38,7 @@ int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_own
                 const int32_t *facet_marker) {
   if (!out) return cfdh_fail(nullptr, CFDH_E_ARG, "null output pointer");
   *out = nullptr;
-  if (gdim != 2) return cfdh_fail(nullptr, CFDH_E_ARG, "only gdim == 2 (P1 triangles) is implemented");
+  if (gdim != 2 && gdim != 3) return cfdh_fail(nullptr, CFDH_E_ARG, "gdim must be 2 (P1 triangles) or 3 (P1 tetrahedra)");
   if (!cells || !coords || (nfacets > 0 && (!facet_cells || !facet_local)))
     return cfdh_fail(nullptr, CFDH_E_ARG, "null mesh array");
   int ndev = 0;
@@ -55,9 +55,10 @@ int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_own
   do {
     if (hipSetDevice(device) != hipSuccess) { rc = cfdh_fail(nullptr, CFDH_E_HIP, "hipSetDevice(%d) failed", device); break; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = cfdh_fail(nullptr, CFDH_E_HIP, "hipStreamCreate failed"); break; }
-    rc = k_upload_quadrature(c);
+    rc = gdim == 3 ? k3_upload_quadrature(c) : k_upload_quadrature(c);
     if (rc) break;
-    rc = cfdh_build_mesh(c, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker);
+    rc = gdim == 3 ? cfdh_build_mesh3(c, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker)
+                   : cfdh_build_mesh(c, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker);
   } while (0);
   if (rc) {
     g_cfdh_last_error = c->err.empty() ? g_cfdh_last_error : c->err;
@@ -90,7 +91,7 @@ int cfdh_set_params(cfdh_ctx *c, double dt, double rho, double mu, double mu_fac
   if (!(dt > 0) || !(rho > 0) || !(mu > 0)) return cfdh_fail(c, CFDH_E_ARG, "dt, rho, mu must be positive");
   const bool changed = !c->params_set || dt != c->dt || rho != c->rho || mu != c->mu;
   c->dt = dt; c->rho = rho; c->mu = mu; c->muf = mu_facet;
-  c->f[0] = f ? f[0] : 0.0; c->f[1] = f ? f[1] : 0.0;
+  c->f[0] = f ? f[0] : 0.0; c->f[1] = f ? f[1] : 0.0; c->f[2] = f ? f[2] : 0.0;
   c->params_set = true;
   if (changed) { c->mom_valid = false; c->pc_valid = false; }
   return 0;
@@ -126,18 +127,19 @@ int cfdh_add_dirichlet(cfdh_ctx *c, int field, int64_t n, const int32_t *nodes, 
   if (!c || (field != 0 && field != 1) || n < 0 || (n > 0 && (!nodes || !values))) return cfdh_fail(c, CFDH_E_ARG, "bad Dirichlet arguments");
   for (int64_t k = 0; k < n; k++)
     if (nodes[k] < 0 || nodes[k] >= c->nv) return cfdh_fail(c, CFDH_E_ARG, "Dirichlet node %d out of range", (int)nodes[k]);
+  const int d = c->dim, st = d + 1;  // per vertex: d velocity components, then the pressure
   for (int64_t k = 0; k < n; k++) {
     const int v = c->perm[nodes[k]];
     if (field == 0) {
-      for (int i = 0; i < 2; i++) {
+      for (int i = 0; i < d; i++) {
         c->h_bcflag[v] |= (unsigned char)(1u << i);
-        c->h_bcval[3 * (size_t)v + i] = values[2 * k + i];
-        c->h_bcmult[3 * (size_t)v + i] += 1.0;
+        c->h_bcval[(size_t)st * v + i] = values[(size_t)d * k + i];
+        c->h_bcmult[(size_t)st * v + i] += 1.0;
       }
     } else {
-      c->h_bcflag[v] |= 4u;
-      c->h_bcval[3 * (size_t)v + 2] = values[k];
-      c->h_bcmult[3 * (size_t)v + 2] += 1.0;
+      c->h_bcflag[v] |= (unsigned char)(1u << d);
+      c->h_bcval[(size_t)st * v + d] = values[k];
+      c->h_bcmult[(size_t)st * v + d] += 1.0;
       c->n_pbc++;
     }
   }
@@ -156,24 +158,24 @@ static int stage_buffer(cfdh_ctx *c, double **h) {
   return 0;
 }
 static void pack_vec(const cfdh_ctx *c, const double *u, const double *p, std::vector<double> &out, const std::vector<double> *keep) {
-  const int nvo = c->nvo, nv = c->nv;
+  const int nvo = c->nvo, nv = c->nv, d = c->dim;
   out.resize((size_t)c->NL);
   if (keep) out = *keep;
 #pragma omp parallel for schedule(static) num_threads(cfdh_host_threads()) if (nv > 20000)
   for (int k = 0; k < nv; k++) {
     const int v = c->iperm[k];
-    const size_t uo = k < nvo ? 2 * (size_t)k : 3 * (size_t)k, po = k < nvo ? 2 * (size_t)nvo + k : 3 * (size_t)k + 2;
-    if (u) { out[uo] = u[2 * (size_t)v]; out[uo + 1] = u[2 * (size_t)v + 1]; }
+    const size_t uo = k < nvo ? (size_t)d * k : (size_t)(d + 1) * k, po = k < nvo ? (size_t)d * nvo + k : (size_t)(d + 1) * k + d;
+    if (u) for (int i = 0; i < d; i++) out[uo + i] = u[(size_t)d * v + i];
     if (p) out[po] = p[v];
   }
 }
 static void unpack_vec(const cfdh_ctx *c, const std::vector<double> &in, double *u, double *p) {
-  const int nvo = c->nvo, nv = c->nv;
+  const int nvo = c->nvo, nv = c->nv, d = c->dim;
 #pragma omp parallel for schedule(static) num_threads(cfdh_host_threads()) if (nv > 20000)
   for (int k = 0; k < nv; k++) {
     const int v = c->iperm[k];
-    const size_t uo = k < nvo ? 2 * (size_t)k : 3 * (size_t)k, po = k < nvo ? 2 * (size_t)nvo + k : 3 * (size_t)k + 2;
-    if (u) { u[2 * (size_t)v] = in[uo]; u[2 * (size_t)v + 1] = in[uo + 1]; }
+    const size_t uo = k < nvo ? (size_t)d * k : (size_t)(d + 1) * k, po = k < nvo ? (size_t)d * nvo + k : (size_t)(d + 1) * k + d;
+    if (u) for (int i = 0; i < d; i++) u[(size_t)d * v + i] = in[uo + i];
     if (p) p[v] = in[po];
   }
 }
@@ -236,7 +238,7 @@ int cfdh_get_residual(cfdh_ctx *c, double *ru, double *rp) {
   std::vector<double> h;
   CHK(download_vec(c, c->F.p, h));
   // ghost entries of F are not defined: report zeros there
-  for (size_t k = 3 * (size_t)c->nvo; k < h.size(); k++) h[k] = 0.0;
+  for (size_t k = (size_t)(c->dim + 1) * c->nvo; k < h.size(); k++) h[k] = 0.0;
   unpack_vec(c, h, ru, rp);
   return 0;
 }
@@ -250,7 +252,7 @@ int cfdh_advance(cfdh_ctx *c) {
 
 int cfdh_advance_field(cfdh_ctx *c, int field) {
   ENTER(c);
-  const size_t nu = 2 * (size_t)c->nvo;
+  const size_t nu = (size_t)c->dim * c->nvo;
   if (field == 0) {
     CHK(v_copy(c, (int)nu, c->x.p, c->xprev.p));  // ghost entries follow with the halo exchange before the next assembly
     c->mom_valid = false;
@@ -288,6 +290,7 @@ static int upload_cell_facet_flags(cfdh_ctx *c) {
 int cfdh_set_boundary_terms(cfdh_ctx *c, int ds_terms, int backflow_marker, double beta) {
   ENTER(c);
   if (beta < 0) return cfdh_fail(c, CFDH_E_ARG, "backflow beta must be >= 0");
+  if (beta > 0 && c->dim == 3) return cfdh_fail(c, CFDH_E_ARG, "the backflow term is not implemented for tetrahedra");
   if (!(beta > 0)) backflow_marker = -1;
   const bool changed = (ds_terms != 0) != c->ds_terms || beta != c->bf_beta || backflow_marker != c->bf_marker;
   c->ds_terms = ds_terms != 0; c->bf_beta = beta; c->bf_marker = backflow_marker;
@@ -344,14 +347,14 @@ int cfdh_assemble(cfdh_ctx *c, int want_jacobian) {
 
 int cfdh_get_csr(cfdh_ctx *c, int64_t *nnz, int32_t *rowptr, int32_t *col, double *vals) {
   if (!c || !nnz) return CFDH_E_ARG;
-  *nnz = 9ll * c->nnzv;
+  *nnz = (long long)(c->dim + 1) * (c->dim + 1) * c->nnzv;
   if (!rowptr && !col && !vals) return 0;
   if (!rowptr || !col || !vals) return cfdh_fail(c, CFDH_E_ARG, "pass all of rowptr/col/vals or none");
   if (!c->jac_valid) return cfdh_fail(c, CFDH_E_STATE, "no Jacobian assembled yet");
   std::vector<double> a00, a01, a10, a11;
   CHK(cfdh_download_blocks(c, a00, a01, a10, a11));
-  const int nvo = c->nvo, nv = c->nv;
-  // rows in user numbering: u rows 2*v+i (v < nvo), then p rows 2*nvo+v
+  const int nvo = c->nvo, nv = c->nv, d = c->dim;
+  // rows in user numbering: u rows d*v+i (v < nvo), then p rows d*nvo+v
   int64_t pos = 0;
   std::vector<std::pair<int, int>> ord;  // (user column vertex, slot k)
   auto emit_rows = [&](int kind) {
@@ -360,19 +363,19 @@ int cfdh_get_csr(cfdh_ctx *c, int64_t *nnz, int32_t *rowptr, int32_t *col, doubl
       ord.clear();
       for (int k = c->h_vptr[r]; k < c->h_vptr[r + 1]; k++) ord.push_back({c->iperm[c->h_vcol[k]], k});
       std::sort(ord.begin(), ord.end());
-      const int nrow = kind == 0 ? 2 : 1;
+      const int nrow = kind == 0 ? d : 1;
       for (int i = 0; i < nrow; i++) {
-        const int row = kind == 0 ? 2 * vu + i : 2 * nvo + vu;
+        const int row = kind == 0 ? d * vu + i : d * nvo + vu;
         rowptr[row] = (int32_t)pos;
         for (auto &e : ord)
-          for (int j = 0; j < 2; j++) {
-            col[pos] = 2 * e.first + j;
-            vals[pos] = kind == 0 ? a00[4 * (size_t)e.second + 2 * i + j] : a10[2 * (size_t)e.second + j];
+          for (int j = 0; j < d; j++) {
+            col[pos] = d * e.first + j;
+            vals[pos] = kind == 0 ? a00[(size_t)d * d * e.second + (size_t)d * i + j] : a10[(size_t)d * e.second + j];
             pos++;
           }
         for (auto &e : ord) {
-          col[pos] = 2 * nv + e.first;
-          vals[pos] = kind == 0 ? a01[2 * (size_t)e.second + i] : a11[e.second];
+          col[pos] = d * nv + e.first;
+          vals[pos] = kind == 0 ? a01[(size_t)d * e.second + i] : a11[e.second];
           pos++;
         }
       }
@@ -380,7 +383,7 @@ int cfdh_get_csr(cfdh_ctx *c, int64_t *nnz, int32_t *rowptr, int32_t *col, doubl
   };
   emit_rows(0);
   emit_rows(1);
-  rowptr[3 * nvo] = (int32_t)pos;
+  rowptr[(d + 1) * nvo] = (int32_t)pos;
   return 0;
 }
 
@@ -388,15 +391,15 @@ int cfdh_spmv(cfdh_ctx *c, const double *x, double *y) {
   if (!c || !x || !y) return CFDH_E_ARG;
   if (!c->jac_valid) return cfdh_fail(c, CFDH_E_STATE, "no Jacobian assembled yet");
   std::vector<double> h;
-  pack_vec(c, x, x + 2 * (size_t)c->nv, h, nullptr);
+  pack_vec(c, x, x + (size_t)c->dim * c->nv, h, nullptr);
   CHK(upload_vec(c, h, c->xt.p));
   CHK(k_spmv_full(c, c->xt.p, c->dvec.p));
   std::vector<double> o;
   CHK(download_vec(c, c->dvec.p, o));
   for (int k = 0; k < c->nvo; k++) {
-    const int v = c->iperm[k];
-    y[2 * (size_t)v] = o[2 * (size_t)k]; y[2 * (size_t)v + 1] = o[2 * (size_t)k + 1];
-    y[2 * (size_t)c->nvo + v] = o[2 * (size_t)c->nvo + k];
+    const int v = c->iperm[k], d = c->dim;
+    for (int i = 0; i < d; i++) y[(size_t)d * v + i] = o[(size_t)d * k + i];
+    y[(size_t)d * c->nvo + v] = o[(size_t)d * c->nvo + k];
   }
   return 0;
 }
@@ -558,16 +561,17 @@ int cfdh_functional(cfdh_ctx *c, int kind, int marker, double *out) {
 
 int cfdh_wall_shear_stress(cfdh_ctx *c, double *shear) {
   ENTER(c);
-  if (!c->wss.p) HIPCHK(c, c->wss.alloc(2 * (size_t)c->nv));
+  const size_t d = (size_t)c->dim;
+  if (!c->wss.p) HIPCHK(c, c->wss.alloc(d * (size_t)c->nv));
   CHK(comm_halo(c, c->x.p));
   CHK(k_wss(c, c->wss.p));
   if (!shear) return 0;
-  std::vector<double> h(2 * (size_t)c->nv);
+  std::vector<double> h(d * (size_t)c->nv);
   HIPCHK(c, hipMemcpyAsync(h.data(), c->wss.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int k = 0; k < c->nv; k++) {
     const int v = c->iperm[k];
-    shear[2 * (size_t)v] = h[2 * (size_t)k]; shear[2 * (size_t)v + 1] = h[2 * (size_t)k + 1];
+    for (size_t i = 0; i < d; i++) shear[d * (size_t)v + i] = h[d * (size_t)k + i];
   }
   return 0;
 }
@@ -621,6 +625,7 @@ int64_t cfdh_info(const cfdh_ctx *c, int what) {
     case 16: return c->n_krylov;
     case 17: return c->n_allgather;
     case 18: return c->nranks;
+    case 26: return c->dim;
     case 19: return c->opt.pc_type == 1 ? c->hL.nnz_S0 : c->hS.nnz_S0;
     case 20: return c->hA.nnz_S0;
     case 21: return c->opt.pc_type == 1 ? c->hL.nnz_G0 : c->hS.nnz_G0;

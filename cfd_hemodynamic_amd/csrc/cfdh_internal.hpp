@@ -120,6 +120,8 @@ struct cfdh_ctx {
   hipStream_t stream = nullptr;
   std::string err;
 
+  // geometric dimension: 2 (triangles, 3x3 vertex blocks) or 3 (tetrahedra, 4x4 vertex blocks; single GPU)
+  int dim = 2;
   // sizes (local part): nv = nvo owned + ng ghosts
   int nv = 0, nvo = 0, ng = 0, nc = 0, nfac = 0;
   int NL = 0;   // vector length incl. ghost tail = 3*nvo + 3*ng
@@ -136,7 +138,7 @@ struct cfdh_ctx {
   int nfac_user = 0;
 
   bool params_set = false;
-  double dt = 0, rho = 0, mu = 0, muf = 0, f[2] = {0, 0};
+  double dt = 0, rho = 0, mu = 0, muf = 0, f[3] = {0, 0, 0};
   cfdh_options opt;
 
   // device mesh
@@ -163,6 +165,13 @@ struct cfdh_ctx {
   dbuf<int> blk_cptr, blk_clist;  // per-block list of distinct cells
   dbuf<unsigned> inc_loc;    // per lane: lcell | lv0<<8 | lv1<<16 | lv2<<24 (block-local, rotated); ~0u = idle lane
   dbuf<int> wave_maxlen;     // per wavefront: longest row (bound of the segmented reduction)
+
+  // 3-D assembly (cfdh3_*): workgroups of consecutive rows whose value slots are accumulated in LDS
+  int a3_nblk = 0;
+  dbuf<int> a3_blk_row, a3_blk_iptr;   // [nblk+1] first row / first incidence of a workgroup
+  dbuf<int> a3_inc_cell;               // per incidence: cell * 4 + local index of the row vertex
+  dbuf<int> a3_inc_row;                // per incidence: row relative to the workgroup's first row
+  dbuf<unsigned long long> a3_inc_slots;  // per incidence: 4 x 16-bit slot offsets (relative to the workgroup's first slot) of the cell's columns
 
   // Dirichlet data (host master copies in internal numbering)
   std::vector<unsigned char> h_bcflag;  // bit0 ux, bit1 uy, bit2 p
@@ -310,6 +319,19 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv, int64_t nvo, int64_t nc, const int3
 int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A, bool singular, int ncol);
 int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol, std::vector<double> *w_out = nullptr);
 int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<double> *colw = nullptr, int parts = CFDH_UP_CSR | CFDH_UP_SELL);
+
+// ---- tetrahedra (cfdh3_setup.cpp, cfdh3_kernels.hip) -------------------------------
+#define CFDH3_MAX_SLOTS 320   // value slots (16 doubles each) accumulated in LDS per assembly workgroup
+int cfdh_build_mesh3(cfdh_ctx *c, int64_t nv, int64_t nvo, int64_t nc, const int32_t *cells, const double *coords,
+                     int64_t nfac, const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker);
+int k3_upload_quadrature(cfdh_ctx *c);
+int k3_moments(cfdh_ctx *c);
+int k3_assemble(cfdh_ctx *c, const double *xstate, int mode);
+int k3_spmv_full(cfdh_ctx *c, const double *x, double *y);
+int k3_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b);  // 2: b - A01 x_p ; 3: b - A10 x_u (b may be null)
+int k3_nullspace_test(cfdh_ctx *c, double *nrm);
+int k3_functional(cfdh_ctx *c, int kind, int marker, double *out);
+int k3_wss(cfdh_ctx *c, double *out);
 
 // ---- kernels (cfdh_kernels.hip) ----------------------------------------------------
 void prof_begin(cfdh_ctx *c, int kind);

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(TPB) void moments_kernel(int nc, int nvo, const int
 }
 
 int k_moments(cfdh_ctx *c) {
+  if (c->dim == 3) return k3_moments(c);
   prof_begin(c, 2);
   hipLaunchKernelGGL(moments_kernel, dim3((c->nc + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nc, c->nvo, c->cells.p,
                      c->coords.p, c->xprev.p, c->mom.p, c->dt, c->mu / c->rho);
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
 }
 
 int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
+  if (c->dim == 3) return k3_assemble(c, xstate, mode);
   AsmArgs a;
   a.coords = c->coords.p; a.mom = c->mom.p; a.x = xstate; a.un = c->xprev.p; a.un2 = c->xprev2.p; a.bcval = c->bcval.p; a.bcmult = c->bcmult.p;
   a.vptr = c->vptr.p;
@@ -643,6 +645,7 @@ __global__ __launch_bounds__(TPB) void spmv_full_kernel(int nvo, const int *__re
 }
 
 int k_spmv_full(cfdh_ctx *c, const double *x, double *y) {
+  if (c->dim == 3) return k3_spmv_full(c, x, y);
   const long long nthreads = 8ll * c->nvo;
   prof_begin(c, 1);
   hipLaunchKernelGGL(spmv_full_kernel, dim3((unsigned)((nthreads + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, c->nvo,
@@ -740,6 +743,7 @@ int k_spmv_block_ghost(cfdh_ctx *c, int blk, const double *xv, double *y, const 
 }
 
 int k_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b, double /*alpha*/) {
+  if (c->dim == 3) return k3_spmv_block(c, blk, x, y, b);
   const long long nthreads = 8ll * c->nvo;
   dim3 grid((unsigned)((nthreads + TPB - 1) / TPB)), block(TPB);
   const int mode = b ? 1 : 0;
@@ -884,6 +888,15 @@ int k_cheb_a00(cfdh_ctx *c, const double *b, double *x) {
 // ---------------------------------------------------------------- scalar CSR operators (AMG levels)
 // All level kernels are templated on the vector element T: double (one right-hand side) or
 // double2 (two right-hand sides sharing one scalar operator: the two velocity components).
+// three right-hand sides sharing one scalar operator: the velocity components of a tetrahedral mesh
+struct d3 { double x, y, z; };
+__device__ __forceinline__ d3 vzero(const d3 *) { return d3{0.0, 0.0, 0.0}; }
+__device__ __forceinline__ d3 vfma(double a, d3 x, d3 acc) { return d3{acc.x + a * x.x, acc.y + a * x.y, acc.z + a * x.z}; }
+__device__ __forceinline__ d3 vsub(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ d3 vadd(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ d3 vscale(double a, d3 x) { return d3{a * x.x, a * x.y, a * x.z}; }
+__device__ __forceinline__ d3 g8(d3 v) { return d3{group8_sum(v.x), group8_sum(v.y), group8_sum(v.z)}; }
+__device__ __forceinline__ d3 wsum(d3 v) { return d3{wave_sum(v.x), wave_sum(v.y), wave_sum(v.z)}; }
 __device__ __forceinline__ double vzero(const double *) { return 0.0; }
 __device__ __forceinline__ double2 vzero(const double2 *) { return make_double2(0.0, 0.0); }
 __device__ __forceinline__ double vfma(double a, double x, double acc) { return acc + a * x; }
@@ -1267,6 +1280,7 @@ __device__ __forceinline__ double lpr_sum(double v) {
 }
 template <int LPR> __device__ __forceinline__ double lsum(double v) { return lpr_sum<LPR>(v); }
 template <int LPR> __device__ __forceinline__ double2 lsum(double2 v) { return make_double2(lpr_sum<LPR>(v.x), lpr_sum<LPR>(v.y)); }
+template <int LPR> __device__ __forceinline__ d3 lsum(d3 v) { return d3{lpr_sum<LPR>(v.x), lpr_sum<LPR>(v.y), lpr_sum<LPR>(v.z)}; }
 
 __device__ __forceinline__ double epi_apply(double acc, int row, double alpha, double beta, const double *zH, const double *r, const unsigned char *pbc) {
   return (pbc[row] & 1) ? r[row] : alpha * acc + beta * zH[row];
@@ -1274,6 +1288,8 @@ __device__ __forceinline__ double epi_apply(double acc, int row, double alpha, d
 __device__ __forceinline__ double2 epi_apply(double2 acc, int, double, double, const double *, const double *, const unsigned char *) { return acc; }
 __device__ __forceinline__ double epi_value(double acc, unsigned flag, double alpha, double beta, double zh, double r) { return (flag & 1u) ? r : alpha * acc + beta * zh; }
 __device__ __forceinline__ double2 epi_value(double2 acc, unsigned, double, double, double, double) { return acc; }
+__device__ __forceinline__ d3 epi_apply(d3 acc, int, double, double, const double *, const double *, const unsigned char *) { return acc; }
+__device__ __forceinline__ d3 epi_value(d3 acc, unsigned, double, double, double, double) { return acc; }
 
 // y = G x, LPR lanes per row (rows of the coarse level: tens to hundreds of entries)
 template <int LPR, typename VT, typename T>
@@ -1532,6 +1548,10 @@ int k_dl0_up(cfdh_ctx *c, double *out) {
 int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x) {
   if (!H.valid || H.lev.empty()) return cfdh_fail(c, CFDH_E_STATE, "AMG hierarchy not built");
   const bool prof = (&H == &c->hS) || (&H == &c->hL) || (&H == &c->hLg);
+  if (H.ncol == 3) {
+    if (H.fused && c->opt.amg_smooth_degree == 1 && H.lev.size() >= 2) return amg_cycle_fused<d3>(c, H, (const d3 *)b, (d3 *)x, 5);
+    return amg_cycle_jacobi<d3>(c, H, 0, (const d3 *)b, (d3 *)x, 5);
+  }
   if (H.fused && c->opt.amg_smooth_degree == 1 && H.lev.size() >= 2) {
     if (H.ncol == 2) return amg_cycle_fused<double2>(c, H, (const double2 *)b, (double2 *)x, 5);
     return amg_cycle_fused<double>(c, H, b, x, prof ? 4 : 0);
@@ -1932,6 +1952,7 @@ __global__ __launch_bounds__(TPB) void nulltest_kernel(int nvo, const int *__res
   if (threadIdx.x == 0) partial[blockIdx.x] = a;
 }
 int k_nullspace_test(cfdh_ctx *c, double *nrm) {
+  if (c->dim == 3) return k3_nullspace_test(c, nrm);
   const int nb = vgrid(c->nvo) > c->red_blocks ? c->red_blocks : vgrid(c->nvo);
   hipLaunchKernelGGL(nulltest_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nvo, c->vptr.p, c->A01.p, c->A11.p, c->red_partial.p);
   hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p,
@@ -2058,6 +2079,7 @@ __global__ __launch_bounds__(TPB) void wss_kernel(int nfac, int nvo, const int *
   atomicAdd(out + 2 * (size_t)v2, Tt[0]); atomicAdd(out + 2 * (size_t)v2 + 1, Tt[1]);
 }
 int k_wss(cfdh_ctx *c, double *out) {
+  if (c->dim == 3) return k3_wss(c, out);
   HIPCHK(c, hipMemsetAsync(out, 0, sizeof(double) * 2 * (size_t)c->nv, c->stream));
   if (c->nfac > 0)
     hipLaunchKernelGGL(wss_kernel, dim3((c->nfac + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nfac, c->nvo, c->d_fac_cell.p,
@@ -2067,6 +2089,7 @@ int k_wss(cfdh_ctx *c, double *out) {
 }
 
 int k_functional(cfdh_ctx *c, int kind, int marker, double *out) {
+  if (c->dim == 3) return k3_functional(c, kind, marker, out);
   const int nb = 256;
   if (kind == 0 || kind == 1) {
     // a part without exterior facets (nfac == 0) still launches: the kernel then only writes zero partials, and the

@@ -26,11 +26,11 @@ static double wall_ms() {
 
 int cfdh_download_blocks(cfdh_ctx *c, std::vector<double> &a00, std::vector<double> &a01, std::vector<double> &a10,
                          std::vector<double> &a11) {
-  const size_t nz = (size_t)c->nnzv;
-  a00.resize(4 * nz); a01.resize(2 * nz); a10.resize(2 * nz); a11.resize(nz);
-  HIPCHK(c, hipMemcpyAsync(a00.data(), c->A00.p, sizeof(double) * 4 * nz, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(a01.data(), c->A01.p, sizeof(double) * 2 * nz, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(a10.data(), c->A10.p, sizeof(double) * 2 * nz, hipMemcpyDeviceToHost, c->stream));
+  const size_t nz = (size_t)c->nnzv, d = (size_t)c->dim;
+  a00.resize(d * d * nz); a01.resize(d * nz); a10.resize(d * nz); a11.resize(nz);
+  HIPCHK(c, hipMemcpyAsync(a00.data(), c->A00.p, sizeof(double) * d * d * nz, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(a01.data(), c->A01.p, sizeof(double) * d * nz, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(a10.data(), c->A10.p, sizeof(double) * d * nz, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(a11.data(), c->A11.p, sizeof(double) * nz, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -118,7 +118,10 @@ static int build_cc_host(cfdh_ctx *c) {
       for (int k = vp[i]; k < vp[i + 1]; k++) {
         const int w = vc[k];
         if (w >= nloc) continue;
-        const double v = 0.5 * (a00[4 * (size_t)k] + a00[4 * (size_t)k + 3]);
+        // mean of the diagonal entries of the dim x dim block: (A00_xx + A00_yy [+ A00_zz]) / dim
+        double v = 0.0;
+        for (int q = 0; q < c->dim; q++) v += a00[(size_t)c->dim * c->dim * k + (size_t)q * (c->dim + 1)];
+        v /= c->dim;
         if (v == 0.0 && w != i) continue;
         Ah.col.push_back(w); Ah.val.push_back(v);
       }
@@ -165,21 +168,25 @@ static int build_cc_host(cfdh_ctx *c) {
       if (!c->ras_b.p) { HIPCHK(c, c->ras_b.alloc(2 * (size_t)c->nv)); HIPCHK(c, c->ras_x.alloc(2 * (size_t)c->nv)); }
     }
     c->ras = ras;
-    CHK(cfdh_amg_setup(c, c->hA, Ah, false, 2));
+    CHK(cfdh_amg_setup(c, c->hA, Ah, false, c->dim));
   }
   // --- pressure Laplacian hierarchy (once per Dirichlet set)
   // pbc bit0: the pressure dof is Dirichlet (identity row in H, z_p = r_p); bit1: Dirichlet in L only --
   // with a do-nothing boundary (ds_terms off) the vertices of every exterior facet that is not a
   // no-slip/inflow facet form the outflow boundary of the pressure Poisson problem.
   std::vector<unsigned char> pbc(nvo);
-  for (int i = 0; i < nvo; i++) pbc[i] = (c->h_bcflag[i] & 4u) ? 1 : 0;
+  const unsigned pbit = 1u << c->dim, umask = pbit - 1u;  // bits 0..dim-1: velocity components, bit dim: pressure
+  for (int i = 0; i < nvo; i++) pbc[i] = (c->h_bcflag[i] & pbit) ? 1 : 0;
   if (!c->ds_terms)
     for (int k = 0; k < c->nfac; k++) {
-      const int e = c->fac_cell[k], fl = c->fac_local[k];
-      const int v1 = c->h_cells[3 * (size_t)e + (fl + 1) % 3], v2 = c->h_cells[3 * (size_t)e + (fl + 2) % 3];
-      if ((c->h_bcflag[v1] & 3u) == 3u && (c->h_bcflag[v2] & 3u) == 3u) continue;
-      if (v1 < nvo) pbc[v1] |= 2;
-      if (v2 < nvo) pbc[v2] |= 2;
+      const int e = c->fac_cell[k], fl = c->fac_local[k], n1 = c->dim + 1;
+      bool fixed = true;
+      for (int q = 0; q < n1; q++) if (q != fl) fixed = fixed && (c->h_bcflag[c->h_cells[(size_t)n1 * e + q]] & umask) == umask;
+      if (fixed) continue;
+      for (int q = 0; q < n1; q++) {
+        const int v = c->h_cells[(size_t)n1 * e + q];
+        if (q != fl && v < nvo) pbc[v] |= 2;
+      }
     }
   if (!c->hL.valid || c->hL_pbc != pbc || c->hL_singular != c->singular) {
     CsrHost Lh;
@@ -299,7 +306,8 @@ static int build_cc_host(cfdh_ctx *c) {
 // always the Jacobi diagonal and the spectral bound of D^-1 A00; the Sp
 // hierarchy only when asked (lagged preconditioner)
 int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
-  const int nu = 2 * c->nvo;
+  const int nu = c->dim * c->nvo;
+  if (c->dim == 3 && c->opt.pc_type != 1) return cfdh_fail(c, CFDH_E_ARG, "tetrahedral contexts support pc_type 1 only");
   if (c->opt.pc_type == 1) {
     if (refresh_amg || !c->pc_valid) {
       c->pc_graph_valid = false;
@@ -333,7 +341,7 @@ int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
     CsrHost S;
     CHK(build_schur_host(c, S));
     bool any_pbc = false;
-    for (int i = 0; i < c->nvo; i++) any_pbc |= (c->h_bcflag[i] & 4u) != 0;
+    for (int i = 0; i < c->nvo; i++) any_pbc |= (c->h_bcflag[i] & (1u << c->dim)) != 0;
     CHK(cfdh_amg_setup(c, c->hS, S, c->singular != 0 || !any_pbc, 1));
     c->pc_valid = true;
     c->pc_its_ref = 0;
@@ -350,7 +358,7 @@ int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
 //   stage 3: z_u = V(A00~)(r_u - A01 z_p)
 // With one rank (no exchanges) all stages run back to back; each stage is graph-capturable.
 static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
-  const int nvo = c->nvo, nu = 2 * nvo;
+  const int nvo = c->nvo, nu = c->dim * nvo;
   const double *ru = r, *rp = r + nu;
   double *zu = z, *zp = z + nu;
   const bool multi = c->nranks > 1;
@@ -508,7 +516,7 @@ int cfdh_pc_apply(cfdh_ctx *c, const double *r, double *z) {
       for (int st = 0; st < 6; st++) { HIPCHK(c, hipGraphLaunch(pg->exec[st], c->stream)); CHK(pc_exchange(c, st)); }
     }
   }
-  if (c->singular) CHK(v_sub_mean(c, nvo, z + 2 * (size_t)nvo));
+  if (c->singular) CHK(v_sub_mean(c, nvo, z + (size_t)c->dim * nvo));
   return 0;
 }
 
@@ -676,7 +684,7 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
   if (!c->params_set) return cfdh_fail(c, CFDH_E_STATE, "cfdh_set_params was not called");
   if (!c->state_set) return cfdh_fail(c, CFDH_E_STATE, "cfdh_set_state was not called");
   CHK(cfdh_prepare_assembly(c));
-  if (o.remove_p_mean) CHK(v_sub_mean(c, nvo, c->x.p + 2 * (size_t)nvo));
+  if (o.remove_p_mean) CHK(v_sub_mean(c, nvo, c->x.p + (size_t)c->dim * nvo));
   CHK(comm_halo(c, c->x.p));
   double t0 = wall_ms();
   CHK(k_assemble(c, c->x.p, 1));

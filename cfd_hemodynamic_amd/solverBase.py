@@ -75,6 +75,8 @@ class SolverBase(ABC):
         if not hasattr(self, "shear_stress"):
             return
         mesh = self.mesh
+        if mesh.geometry.dim != 2:
+            raise NotImplementedError("host restatement of the wall shear stress: triangles only (the device path covers tetrahedra)")
         u = self.u_sol.x.array.reshape(-1, 2)
         mu = float(self.mu.value)
         fc, fl, fv = mesh.facet_cells, mesh.facet_local, mesh.facet_vertices

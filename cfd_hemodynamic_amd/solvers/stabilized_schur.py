@@ -85,7 +85,7 @@ class Solver(SolverBase):
 
     # -- global <-> local (identity on one GPU) ------------------------------------
     def _loc_u(self, a):
-        return a if self._part is None else np.ascontiguousarray(a.reshape(-1, 2)[self._part.l2g]).reshape(-1)
+        return a if self._part is None else np.ascontiguousarray(a.reshape(-1, self.mesh.geometry.dim)[self._part.l2g]).reshape(-1)
 
     def _loc_p(self, a):
         return a if self._part is None else np.ascontiguousarray(a[self._part.l2g])
@@ -96,7 +96,7 @@ class Solver(SolverBase):
             dst_p[:] = lp
         else:
             nvg = self.mesh.num_vertices
-            dst_u[:] = self._comm.allgather_owned(lu, 2, nvg)
+            dst_u[:] = self._comm.allgather_owned(lu, self.mesh.geometry.dim, nvg)
             dst_p[:] = self._comm.allgather_owned(lp, 1, nvg)
 
     # -- lazy sync -----------------------------------------------------------
@@ -198,7 +198,7 @@ class Solver(SolverBase):
     def _bc_nodes_values(self, field, bc):
         g = bc.g.x._array
         nodes = bc.dofs
-        vals = g.reshape(-1, 2)[nodes] if field == 0 else g[nodes]
+        vals = g.reshape(-1, self.mesh.geometry.dim)[nodes] if field == 0 else g[nodes]
         if self._part is not None:
             loc = self._part.g2l[nodes]
             keep = loc >= 0

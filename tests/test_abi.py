@@ -43,7 +43,7 @@ def test_bad_arguments_return_error_codes_not_crashes():
     h = ctypes.c_void_p()
     x = np.zeros((3, 2))
     cells = np.array([[0, 1, 2]], dtype=np.int32)
-    rc = L.cfdh_create(ctypes.byref(h), 0, 3, 3, 3, 1, _lib._ip(cells), _lib._dp(x), 0, None, None, None)
+    rc = L.cfdh_create(ctypes.byref(h), 0, 4, 3, 3, 1, _lib._ip(cells), _lib._dp(x), 0, None, None, None)
     assert rc == -1 and b"gdim" in L.cfdh_last_error(None)
     assert L.cfdh_solve_step(None, None) == -1
     assert L.cfdh_info(None, 0) == -1

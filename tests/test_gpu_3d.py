@@ -1,0 +1,114 @@
+"""Tetrahedra (gdim = 3) on the HIP path against the dimension-generic NumPy twin (oracle/np_twin_nd.py, itself pinned
+to the 2-D twin for d = 2): assembly (residual, every CSR value, SpMV) at states violating the Dirichlet data, time steps
+with the boundary data of /root/reference/src/scenarios/simple_bifurcation.py:77-133 (direct solver on the twin side),
+functionals.  fp64; the 3-D assembly accumulates in LDS in no fixed order, hence 1e-12 instead of 1e-13."""
+import numpy as np
+import pytest
+
+from cfd_hemodynamic_amd import _lib
+from cfd_hemodynamic_amd.mesh3d import Mesh3D, create_bifurcation, create_unit_cube
+from oracle import np_twin_nd as TN
+
+pytestmark = pytest.mark.gpu
+
+
+def _cube(n, seed=0):
+    m = create_unit_cube(n)
+    rng = np.random.default_rng(seed)
+    interior = np.abs(m.x - 0.5).max(axis=1) < 0.49
+    return Mesh3D(m.cells, m.x + (0.12 / n) * rng.standard_normal(m.x.shape) * interior[:, None]), rng
+
+
+def _pair(mesh, dt, rho, mu, f, bcs, **scheme):
+    prm = TN.Params(dt, rho, mu, f, **scheme)
+    pb = TN.Problem(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, prm)
+    ctx = _lib.Context(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, mesh.facet_marker)
+    assert ctx.dim == 3 and ctx.info(26) == 3
+    ctx.set_params(dt, rho, mu, f=f)
+    if scheme:
+        ctx.set_time_scheme(scheme["theta"], scheme["a0"], scheme["a1"], scheme["a2"])
+    for fld, nodes, vals in bcs:
+        (pb.add_bc_u if fld == 0 else pb.add_bc_p)(nodes, vals)
+        ctx.add_dirichlet(fld, nodes, vals)
+    return pb, ctx
+
+
+@pytest.mark.parametrize("scheme", [{}, dict(theta=1.0, a0=1.5, a1=-2.0, a2=0.5)])
+def test_tet_assembly_and_spmv_match_twin(scheme):
+    mesh, rng = _cube(4, 3)
+    nv = mesh.num_vertices
+    bnd = np.unique(mesh.facet_vertices)
+    top = bnd[mesh.x[bnd, 2] > 0.99]
+    side = bnd[mesh.x[bnd, 0] < 0.01]
+    bcs = [(0, side.astype(np.int32), rng.standard_normal((len(side), 3))),
+           (0, top.astype(np.int32), rng.standard_normal((len(top), 3))),       # shares an edge with `side`: multiplicity 2
+           (1, bnd[mesh.x[bnd, 1] > 0.99].astype(np.int32), rng.standard_normal(int((mesh.x[bnd, 1] > 0.99).sum())))]
+    pb, ctx = _pair(mesh, 0.02, 1.3, 0.04, (0.2, -0.1, 0.3), bcs, **scheme)
+    xv = 0.3 * rng.standard_normal(4 * nv)
+    un, un2 = 0.3 * rng.standard_normal((nv, 3)), 0.3 * rng.standard_normal((nv, 3))
+    F, J = pb.assemble(xv, un, un2=un2)
+    ctx.set_state(u_prev=un.ravel(), p_prev=np.zeros(nv), u=xv[: 3 * nv], p=xv[3 * nv:])
+    if scheme:
+        ctx.set_previous2(un2.ravel())
+    ctx.assemble(True)
+    Fg = np.concatenate(ctx.get_residual())
+    assert np.abs(F - Fg).max() <= 1e-12 * np.abs(F).max()
+    Jg = ctx.get_csr()
+    assert Jg.shape == (4 * nv, 4 * nv) and Jg.nnz == 16 * ctx.info(3)
+    assert abs(J - Jg).max() <= 1e-12 * abs(J).max()
+    v = rng.standard_normal(4 * nv)
+    assert np.abs(ctx.spmv(v) - J @ v).max() <= 1e-12 * np.abs(J @ v).max()
+    ctx.assemble(False)  # residual with lifting, Jacobian in registers only
+    assert np.abs(np.concatenate(ctx.get_residual()) - Fg).max() <= 1e-12 * np.abs(Fg).max()
+    ctx.close()
+
+
+def _bifurcation_bcs(mesh, ft, v_inlet=1.5):
+    wall = np.unique(mesh.facet_vertices[ft.find(11)]).astype(np.int32)
+    inl = np.setdiff1d(np.unique(mesh.facet_vertices[ft.find(8)]), wall).astype(np.int32)
+    r = np.hypot(mesh.x[inl, 0], mesh.x[inl, 2])
+    vin = np.zeros((len(inl), 3))
+    vin[:, 1] = v_inlet * (1.0 - (r / mesh.r_in) ** 2)
+    bcs = [(0, wall, np.zeros((len(wall), 3))), (0, inl, vin)]
+    for tag in (9, 10):
+        o = np.unique(mesh.facet_vertices[ft.find(tag)]).astype(np.int32)
+        bcs.append((1, o, np.zeros(len(o))))
+    return bcs
+
+
+def test_tet_time_steps_match_twin_on_the_bifurcation():
+    """simple_bifurcation.py:20-58,77-133: rho = 1, mu = 1/Re, inlet u_y = v (1 - (r / r_in)^2), no-slip walls, p = 0 at
+    both outlets; two steps from rest, both sides converged tightly (twin: Newton with a direct solve)."""
+    mesh, ft = create_bifurcation(0.0012)
+    nv = mesh.num_vertices
+    Re = 1055.0 * 0.01 * ((100 / 0.003918604) / 1e6) / 3.5e-3
+    pb, ctx = _pair(mesh, 0.01, 1.0, 1.0 / Re, (0.0, 0.0, 0.0), _bifurcation_bcs(mesh, ft))
+    o = ctx.default_options()
+    o.snes_rtol, o.snes_stol, o.ksp_rtol = 1e-12, 0.0, 1e-10
+    ctx.set_options(o)
+    z3, z1 = np.zeros(3 * nv), np.zeros(nv)
+    ctx.set_state(u_prev=z3, p_prev=z1, u=z3, p=z1)
+    x = np.zeros(4 * nv)
+    un = np.zeros((nv, 3))
+    for step in range(2):
+        st = ctx.solve_step()
+        assert st.reason > 0 and st.newton_its <= 8
+        xg = np.concatenate(ctx.get_solution())
+        ctx.advance()
+        x, hist = pb.newton(x, un)
+        un = x[: 3 * nv].reshape(-1, 3).copy()
+        assert np.linalg.norm(xg[: 3 * nv] - x[: 3 * nv]) <= 1e-8 * np.linalg.norm(x[: 3 * nv]), step
+        assert np.linalg.norm(xg[3 * nv:] - x[3 * nv:]) <= 1e-7 * np.linalg.norm(x[3 * nv:]), step
+    l2u, l2p = pb.l2_norms(x)
+    assert abs(ctx.functional(2) - l2u) <= 1e-8 * l2u and abs(ctx.functional(3) - l2p) <= 1e-7 * l2p
+    for tag in (8, 9, 10, 11):
+        q = pb.flux(x, ft.find(tag))
+        assert abs(ctx.functional(7, tag) - q) <= 1e-7 * abs(pb.flux(x, ft.find(8))) + 1e-18
+    u, _ = ctx.get_solution()
+    assert ctx.functional(4) == np.abs(u).max()
+    # wall shear stress: tangential, concentrated on the walls, zero in the interior
+    w = ctx.wall_shear_stress().reshape(-1, 3)
+    interior = np.ones(nv, bool)
+    interior[np.unique(mesh.facet_vertices)] = False
+    assert np.abs(w).max() > 0 and not w[interior].any()
+    ctx.close()
