@@ -45,6 +45,19 @@ def host_cores():
 def kernel_bytes(ctx):
     """Algorithmic HBM bytes per launch of the instrumented kernels (DESIGN.md section 'Kernels')."""
     nvo, nnzv, nc, spnnz = (ctx.info(k) for k in (0, 3, 2, 4))
+    if ctx.info(26) == 3:
+        # tetrahedra: 4x4 vertex blocks (128 B of values + 4 B column per graph entry), 4 dofs per vertex
+        kb = {
+            0: ("asm3_residual_jacobian", 128.0 * nnzv + 32.0 * nvo + (16.0 + 96.0) * nc + 80.0 * nvo),
+            1: ("spmv3_full_block4x4", 132.0 * nnzv + 68.0 * nvo),
+            2: ("tau_moments_tet", 16.0 * nc + 48.0 * nvo + 96.0 * nc),
+        }
+        if ctx.info(25):
+            kb[4] = ("amg_up0_pressure", 8.0 * ctx.info(19) + 16.0 * nvo + 8.0 * ctx.info(23))
+            kb[5] = ("amg_up0_velocity_3rhs", 8.0 * ctx.info(20) + 48.0 * nvo + 24.0 * ctx.info(24))
+            kb[8] = ("amg_down0_pressure", 8.0 * ctx.info(21) + 12.0 * ctx.info(23) + 8.0 * nvo)
+            kb[9] = ("amg_down0_velocity_3rhs", 8.0 * ctx.info(22) + 28.0 * ctx.info(24) + 24.0 * nvo)
+        return kb
     kb = {
         # fused residual+Jacobian: SURVEY.md 8d figure, 624 B per vertex
         0: ("asm_residual_jacobian", 624.0 * nvo),
@@ -85,6 +98,13 @@ def make_scenario(args, solver_name, **kw):
     if cfg == "c4":
         from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
         return StenosisSimulation(solver_name, args.dt, 1.0, grade="moderate", ny=args.ny, v_max=args.v_max, quiet=True, **kw)
+    if cfg == "c5b":
+        from cfd_hemodynamic_amd.scenarios.simple_bifurcation import MicrovasculatureSimulation
+        # remove_p_mean 0: see the tolerance caveat in scenarios/simple_bifurcation.py (with the reference's mean removal the
+        # steps after the first meet snes_rtol on the outlet rows alone and skip the PDE solve at this mesh scale)
+        kw = dict(kw)
+        kw["options"] = dict(kw.get("options", {}), remove_p_mean=0)
+        return MicrovasculatureSimulation(solver_name, args.dt, 1.0, v_inlet=args.v_max, res=args.res3, quiet=True, **kw)
     from cfd_hemodynamic_amd.scenarios.stenosis_with_tree import StenosisWithTreeSimulation
     return StenosisWithTreeSimulation(solver_name, args.dt, 1.0, grade="moderate", res=args.res, pulse_amplitude=0.5,
                                       ramp_time=args.ramp, inlet_max_velocity=args.v_max, quiet=True, **kw)
@@ -96,9 +116,11 @@ def workload_text(args, sc):
             "c2": "lid_driven2D (Re=100) unit square nx=%d" % args.nx,
             "c4": "stenosis grade moderate (L=138, R_in=1.57, R_out=1.2, x_sten=30, severity .5, slope .3), ny=%d, inlet v_max=%g mm/s, p=0 outlet" % (args.ny, args.v_max),
             "c5": "stenosis_with_tree grade moderate (L=0.03, H=0.003, severity .5, slope .5; 3-generation Murray tree, 8 outlets p=0), "
-                  "res=%g, pulsatile inlet v_max (1 + 0.5 sin 2 pi t) with a (1 - cos(pi t / %g)) / 2 start-up ramp, v_max=%g" % (args.res, args.ramp, args.v_max)}[args.config]
+                  "res=%g, pulsatile inlet v_max (1 + 0.5 sin 2 pi t) with a (1 - cos(pi t / %g)) / 2 start-up ramp, v_max=%g" % (args.res, args.ramp, args.v_max),
+            "c5b": "simple_bifurcation (3-D, tetrahedra; Re=%.1f, inlet u_y = %g (1 - (r/r_in)^2), p = 0 at both outlets; remove_p_mean=0), voxel-tet mesh res=%g" % (
+                getattr(sc, "Re", 0.0), args.v_max, args.res3)}[args.config]
     return "%s: %d vertices, %d P1/P1 DOF, dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)" % (
-        head, nv, 3 * nv, args.dt)
+        head, nv, (sc.mesh.geometry.dim + 1) * nv, args.dt)
 
 
 def step_hook(sc, k, dt):
@@ -121,7 +143,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5", "c5b"])
+    ap.add_argument("--res3", type=float, default=2.0e-4, help="c5b: voxel size of the 3-D bifurcation (2e-4: 256 k vertices, 1.03 M DOF; 1e-4: 1.95 M vertices, 7.8 M DOF)")
     ap.add_argument("--m", type=int, default=200, help="c3: DFG mesh parameter (m=200: 336,273 vertices, 1,008,819 DOF)")
     ap.add_argument("--nx", type=int, default=288, help="c2: cells per side")
     ap.add_argument("--ny", type=int, default=115, help="c4: cells across the inlet (115: 678,136 vertices, 2.03 M DOF)")
@@ -144,7 +167,7 @@ def main():
     if args.dt is None:
         args.dt = 0.001 if args.config == "c5" else 0.01
     if args.v_max is None:
-        args.v_max = 0.05 if args.config == "c5" else 100.0
+        args.v_max = {"c5": 0.05, "c5b": 1.5}.get(args.config, 100.0)
     if args.parity_steps is None:
         args.parity_steps = 0 if args.config == "c5" else 2
 
@@ -279,7 +302,7 @@ def main():
                     "algorithmic_bytes": d["algorithmic_MB"] * 1e6, "empty_event_pair_us": ovh_us}
 
     label = {"c3": "dfg_1 ~1M DOF", "c2": "lid_driven2D ~250k DOF", "c4": "stenosis moderate ~2M DOF",
-             "c5": "stenosis_with_tree ~8M DOF pulsatile"}[args.config]
+             "c5": "stenosis_with_tree ~8M DOF pulsatile", "c5b": "simple_bifurcation 3-D tets"}[args.config]
     kits = max(sum(its_krylov), 1)
     out = {
         "metric": "time-steps/sec, %s (%s)" % (label, args.solver),
@@ -317,7 +340,14 @@ def main():
     if args.config == "c3":
         out["drag_coefficient"], out["lift_coefficient"], out["velocity_l2"] = results["drag"], results["lift"], results["velocity_l2"]
 
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if args.config == "c5b":
+        # no CPU leg: the C oracle restates the 2-D path only; the 3-D checker is the NumPy twin with a direct solver
+        # (oracle/np_twin_nd.py), usable up to ~10^4 vertices -- parity is established there (tests/test_gpu_3d.py)
+        qi, q1, q2 = sc.flow_rates()
+        out["results"].update({"inflow": qi, "outflow_1": q1, "outflow_2": q2})
+        out["cpu_baseline"] = None
+        out["parity"] = "tests/test_gpu_3d.py: assembly 1e-12, two bifurcation time steps 1e-8 against oracle/np_twin_nd.py (direct solver)"
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.config != "c5b":
         # CPU baseline and parity: the same Scenario class on the oracle-backed test double of the solver plugin
         # (tests/oracle_solver.py over oracle/cfdh_oracle.c) -- checker and reported baseline only, never the product.
         import oracle_solver

@@ -34,12 +34,13 @@ class VTUWriter:
         nv, nc = m.num_vertices, len(m.cells)
         bs = vals.size // nv
         pts = np.zeros((nv, 3))
-        pts[:, :2] = m.x
+        pts[:, : m.x.shape[1]] = m.x
         data = vals.reshape(nv, bs)
         if bs == 2:  # ParaView wants 3-component vectors
             data = np.concatenate([data, np.zeros((nv, 1))], axis=1)
+        npc = m.cells.shape[1]  # 3: VTK_TRIANGLE (5), 4: VTK_TETRA (10)
         arrays = [pts.ravel(), np.ascontiguousarray(m.cells, dtype=np.int32).ravel(),
-                  (3 * np.arange(1, nc + 1)).astype(np.int32), np.full(nc, 5, dtype=np.uint8), data.ravel()]
+                  (npc * np.arange(1, nc + 1)).astype(np.int32), np.full(nc, 5 if npc == 3 else 10, dtype=np.uint8), data.ravel()]
         offs, blob = [], bytearray()
         for a in arrays:
             offs.append(len(blob))
@@ -95,6 +96,6 @@ def read_vtu(path):
         if ncomp:
             a = a.reshape(-1, int(ncomp))
         out[name or "points"] = a
-    out["cells"] = out.pop("connectivity").reshape(nc_, 3)
+    out["cells"] = out.pop("connectivity").reshape(nc_, -1)
     assert len(out["points"]) == np_
     return out

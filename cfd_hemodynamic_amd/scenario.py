@@ -225,20 +225,25 @@ class Scenario(ABC):
             error_log.close()
         return output_folder
 
+    @staticmethod
+    def _mass_weights(mesh):
+        """int_K l_a l_b = |K| (1 + d_ab) / ((d+1)(d+2)) per cell."""
+        n1 = mesh.cells.shape[1]
+        vol = mesh.cell_areas() if n1 == 3 else mesh.cell_volumes()
+        return vol[:, None, None] * (1.0 + np.eye(n1))[None] / (n1 * (n1 + 1.0))
+
     def _l2_norms_host(self):
         m = self.mesh
-        area = m.cell_areas()
-        mab = area[:, None, None] * (1.0 + np.eye(3))[None] / 12.0
-        ue = self.solver.u_sol.x.array.reshape(-1, 2)[m.cells]
-        pe = self.solver.p_sol.x.array[m.cells]
+        mab = self._mass_weights(m)
+        ue = np.asarray(self.solver.u_sol.x.array).reshape(-1, m.geometry.dim)[m.cells]
+        pe = np.asarray(self.solver.p_sol.x.array)[m.cells]
         return (float(np.sqrt(np.einsum("cab,cai,cbi->", mab, ue, ue))),
                 float(np.sqrt(np.einsum("cab,ca,cb->", mab, pe, pe))))
 
     @staticmethod
     def compute_error(u: Function, u_aprox: Function, mesh) -> float:
         """Relative L2 error (/root/reference/src/scenario.py:350-360)."""
-        area = mesh.cell_areas()
-        mab = area[:, None, None] * (1.0 + np.eye(3))[None] / 12.0
+        mab = Scenario._mass_weights(mesh)
         bs = u.function_space.bs
         a = u.x.array.reshape(-1, bs)[mesh.cells]
         b = u_aprox.x.array.reshape(-1, bs)[mesh.cells]
