@@ -28,7 +28,7 @@ int cfdh_default_options(cfdh_options *o) {
   o->snes_rtol = 1e-8; o->snes_atol = 1e-50; o->snes_stol = 1e-8; o->snes_max_it = 100;
   o->ksp_rtol = 1e-5; o->ksp_atol = 1e-50; o->ksp_max_it = 1000; o->ksp_restart = 200;
   o->cheb_degree = 3; o->cheb_ratio = 10.0; o->schur_full = 2;
-  o->amg_smooth_degree = 1; o->amg_smooth_ratio = 8.0; o->amg_theta = 0.08; o->amg_max_coarse = 1000;
+  o->amg_smooth_degree = 1; o->amg_smooth_ratio = 8.0; o->amg_theta = -1.0; o->amg_max_coarse = 1000;
   o->pc_refresh = 0; o->remove_p_mean = 1; o->verbose = 0; o->pc_type = 1; o->cc_smooth_degree = 2;
   return 0;
 }

@@ -2009,6 +2009,33 @@ __global__ __launch_bounds__(TPB) void draglift_kernel(int nfac, int marker, int
   aL = block_sum(aL, sh);
   if (threadIdx.x == 0) { partial[blockIdx.x] = aD; partial[gridDim.x + blockIdx.x] = aL; }
 }
+// kind 7: volume flux  sum_facets |e| n . (u_a + u_b) / 2  with the outward normal n = -grad(lambda_fl) / |grad(lambda_fl)|
+// and |e| |grad(lambda_fl)| = |det|
+__global__ __launch_bounds__(TPB) void flux_kernel(int nfac, int marker, int nvo, const int *__restrict__ fcell,
+                                                   const int *__restrict__ flocal, const int *__restrict__ fmarker,
+                                                   const int *__restrict__ cells, const unsigned char *__restrict__ cown,
+                                                   const double *__restrict__ coords, const double *__restrict__ x,
+                                                   double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double q = 0;
+  for (int k = blockIdx.x * TPB + threadIdx.x; k < nfac; k += gridDim.x * TPB) {
+    if (fmarker[k] != marker) continue;
+    const int e = fcell[k], fl = flocal[k];
+    if (!cown[e]) continue;
+    int vs[3];
+    double X[3][2];
+    for (int a = 0; a < 3; a++) { vs[a] = cells[3 * e + a]; X[a][0] = coords[2 * vs[a]]; X[a][1] = coords[2 * vs[a] + 1]; }
+    const double det = (X[1][0] - X[0][0]) * (X[2][1] - X[0][1]) - (X[1][1] - X[0][1]) * (X[2][0] - X[0][0]);
+    const int a1 = (fl + 1) % 3, a2 = (fl + 2) % 3;
+    // det * grad(lambda_fl) = rot(X[a1] - X[a2])
+    const double gx = X[a1][1] - X[a2][1], gy = X[a2][0] - X[a1][0];
+    const int u1 = uoff(vs[a1], nvo), u2 = uoff(vs[a2], nvo);
+    const double sgn = det > 0 ? -0.5 : 0.5;
+    q += sgn * (gx * (x[u1] + x[u2]) + gy * (x[u1 + 1] + x[u2 + 1]));
+  }
+  q = block_sum(q, sh);
+  if (threadIdx.x == 0) { partial[blockIdx.x] = q; partial[gridDim.x + blockIdx.x] = 0.0; }
+}
 // kind 2/3: int u.u, int p^2; with overlapping parts a cell is integrated only by
 // the rank that owns its first vertex (cell_owned), so global sums count it once
 __global__ __launch_bounds__(TPB) void l2_kernel(int nc, int nvo, const int *__restrict__ cells, const unsigned char *__restrict__ cown,
@@ -2097,6 +2124,9 @@ int k_functional(cfdh_ctx *c, int kind, int marker, double *out) {
     hipLaunchKernelGGL(draglift_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nfac, marker, c->nvo, c->d_fac_cell.p,
                        c->d_fac_local.p, c->d_fac_marker.p, c->cells.p, c->cell_owned.p, c->coords.p, c->x.p, c->mu,
                        c->red_partial.p);
+  } else if (kind == 7) {
+    hipLaunchKernelGGL(flux_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nfac, marker, c->nvo, c->d_fac_cell.p, c->d_fac_local.p,
+                       c->d_fac_marker.p, c->cells.p, c->cell_owned.p, c->coords.p, c->x.p, c->red_partial.p);
   } else if (kind == 2 || kind == 3) {
     hipLaunchKernelGGL(l2_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nc, c->nvo, c->cells.p, c->cell_owned.p, c->coords.p,
                        c->x.p, c->red_partial.p);
@@ -2118,7 +2148,7 @@ int k_functional(cfdh_ctx *c, int kind, int marker, double *out) {
   CHK(finish_scalars(c, c->red_out.p, 2, 0));
   double v[2];
   CHK(read_scalars(c, c->red_out.p, 2, v));
-  if (kind == 0) *out = v[0];
+  if (kind == 0 || kind == 7) *out = v[0];
   else if (kind == 1) *out = v[1];
   else if (kind == 2) *out = sqrt(v[0]);
   else *out = sqrt(v[1]);

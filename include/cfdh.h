@@ -24,8 +24,14 @@
  * Local numbering (multi-GPU): a context holds the vertices [0,nv) of its
  * part, the first nv_owned of them owned, the rest ghosts (one-cell overlap;
  * SURVEY.md 8e).  Velocity arrays are vertex-major/component-minor
- * (u[2*v+i]), as DOLFINx lays out the blocked P1 space
+ * (u[gdim*v+i]), as DOLFINx lays out the blocked P1 space
  * (stabilized_schur.py:55-57).
+ *
+ * Dimension: gdim = 2 (triangles) or 3 (tetrahedra,
+ * /root/reference/src/scenarios/simple_bifurcation.py, scenario_factory.py:47-49)
+ * is fixed at cfdh_create; "d" below stands for it.  Tetrahedral contexts are
+ * single-GPU in this version (cfdh_set_halo and the backflow term return
+ * CFDH_E_ARG) and use pc_type 1.
  */
 #ifndef CFDH_H
 #define CFDH_H
@@ -78,7 +84,7 @@ typedef struct cfdh_options {
                              * solves), 0: LOWER.  All are right preconditioners of the same FGMRES. */
   int32_t amg_smooth_degree;
   double amg_smooth_ratio;
-  double amg_theta;         /* strength threshold of the aggregation */
+  double amg_theta;         /* strength threshold of the aggregation; < 0 (default): 0.08 for gdim 2, 0.02 for gdim 3 */
   int32_t amg_max_coarse;
   int32_t pc_refresh;       /* 0: adaptive lagging of the Sp hierarchy, n>0: every n steps, -1: every Jacobian */
   int32_t remove_p_mean;    /* nullsp.remove(x_n), stabilized_schur.py:319 */
@@ -96,11 +102,11 @@ typedef struct cfdh_stats {
 
 /* ---- life cycle --------------------------------------------------------- */
 
-/* Upload a (part of a) P1 triangle mesh and build the fixed CSR pattern.
+/* Upload a (part of a) P1 triangle or tetrahedron mesh and build the fixed CSR pattern.
  * Replaces: functionspace/Function/create_matrix_block/create_vector_block
  * (solverBase.py:104-142, stabilized_schur.py:55-57,191-193) and the DG0 cell
  * size h = mesh.h (stabilized_schur.py:82-88).
- * gdim must be 2.  cells [nc][3]; coords [nv][gdim];
+ * gdim 2 or 3.  cells [nc][gdim+1] (any orientation); coords [nv][gdim];
  * exterior facets: owning cell, local facet index (= local index of the
  * opposite vertex), marker (0 = untagged; facet_marker may be NULL, see
  * cfdh_set_facet_markers). */
@@ -118,7 +124,7 @@ void cfdh_destroy(cfdh_ctx *ctx);
 const char *cfdh_last_error(const cfdh_ctx *ctx); /* ctx may be NULL after a failed create */
 int cfdh_abi_version(void);
 
-/* dt, rho, mu Constants and body force (solverBase.py:36-40); mu_facet is the
+/* dt, rho, mu Constants and body force (solverBase.py:36-40; f[2] is read for gdim 3 only); mu_facet is the
  * raw python float used in the ds term (stabilized_schur.py:79). */
 int cfdh_set_params(cfdh_ctx *ctx, double dt, double rho, double mu, double mu_facet, const double f[3]);
 int cfdh_default_options(cfdh_options *opt);
@@ -171,7 +177,7 @@ int cfdh_set_time_scheme(cfdh_ctx *ctx, double theta, double a0, double a1, doub
  * for its estimated degree 3. */
 int cfdh_set_boundary_terms(cfdh_ctx *ctx, int ds_terms, int backflow_marker, double beta);
 
-/* u_prev2 (stabilized_schur_bdf2.py:72): upload / download; nv local vertices x 2 */
+/* u_prev2 (stabilized_schur_bdf2.py:72): upload / download; nv local vertices x gdim */
 int cfdh_set_previous2(cfdh_ctx *ctx, const double *u_prev2);
 int cfdh_get_previous2(cfdh_ctx *ctx, double *u_prev2);
 /* device-side u_prev2 <- u_prev (stabilized_schur_bdf2.py:324, end of solveStep) */
@@ -186,8 +192,8 @@ int cfdh_assemble(cfdh_ctx *ctx, int want_jacobian);
  * ([all u dofs | all p dofs], stabilized_schur.py:194-196,237-252), local
  * column numbering.  Call with rowptr=col=vals=NULL to query nnz. */
 int cfdh_get_csr(cfdh_ctx *ctx, int64_t *nnz, int32_t *rowptr, int32_t *col, double *vals);
-/* y = J x on the device with the assembled Jacobian; x: [2*nv | nv] monolithic
- * local vector, y: owned rows [2*nv_owned | nv_owned]. */
+/* y = J x on the device with the assembled Jacobian; x: [gdim*nv | nv] monolithic
+ * local vector, y: owned rows [gdim*nv_owned | nv_owned]. */
 int cfdh_spmv(cfdh_ctx *ctx, const double *x, double *y);
 
 /* ---- the step ------------------------------------------------------------- */
@@ -200,14 +206,16 @@ int cfdh_solve_step(cfdh_ctx *ctx, cfdh_stats *stats);
 /* kind 0: F_D, 1: F_L over the exterior facets of `marker`
  * (/root/reference/src/scenarios/dfg_1.py:183-202; the scenario prints 500*F),
  * 2: ||u||_L2, 3: ||p||_L2 (/root/reference/src/scenario.py:315-324),
- * 4: ||u_sol||_inf, 5: ||u_prev||_inf, 6: ||u_sol-u_prev||_inf (scenario.py:268-280).
+ * 4: ||u_sol||_inf, 5: ||u_prev||_inf, 6: ||u_sol-u_prev||_inf (scenario.py:268-280),
+ * 7: volume flux  int u_sol . n ds  over the exterior facets of `marker` (outward normal; the outlet flow rates the
+ * tree and bifurcation scenarios report).  Kinds 0/1 exist for gdim 2 only.
  * Sums/maxima over the owned part; the caller (or the communicator) reduces. */
 int cfdh_functional(cfdh_ctx *ctx, int kind, int marker, double *out);
 
 /* Wall shear stress, the per-step `assemble_wss()` of solverBase.py:163-195,
  * (1/FacetArea) * inner(w, Tt) * ds with T = -sigma(u_sol, p_sol) n, Tt = T - (T.n) n, assembled on
  * the device from the current solution into a P1 vector field (zero away from the boundary).
- * shear: nv x 2 host array, or NULL to compute without downloading. */
+ * shear: nv x gdim host array, or NULL to compute without downloading. */
 int cfdh_wall_shear_stress(cfdh_ctx *ctx, double *shear);
 
 /* ---- multi-GPU ---------------------------------------------- */
@@ -258,7 +266,7 @@ int cfdh_profile_reset(cfdh_ctx *ctx);
  * counters since cfdh_create / cfdh_profile_reset: 13 all-reduce calls, 14 halo exchanges, 15 host synchronisations
  * (stream/event waits for scalars), 16 FGMRES iterations, 17 all-gathers; 18: communicator size;
  * fused AMG cycle: 19 / 20 entries of Sb + Sc on level 0 (pressure / velocity hierarchy), 21 / 22 entries of G on
- * level 0, 23 / 24 size of level 1, 25: fused cycle in use */
+ * level 0, 23 / 24 size of level 1, 25: fused cycle in use; 26: gdim */
 int64_t cfdh_info(const cfdh_ctx *ctx, int what);
 
 #ifdef __cplusplus

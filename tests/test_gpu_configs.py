@@ -99,6 +99,10 @@ def test_config5_tree_with_pulsatile_inlet_matches_oracle(oracle_double):
     want = 4 * 0.05 * y * (0.003 - y) / 0.003 ** 2 * (1 + 0.5 * np.sin(2 * np.pi * t4)) * 0.5 * (1 - np.cos(np.pi * t4 / 0.005))
     assert np.allclose(xg[: 2 * g.mesh.num_vertices].reshape(-1, 2)[inl, 0], want, rtol=0, atol=1e-13)
     assert np.allclose(g.outlet_flow_rates(), o.outlet_flow_rates(), rtol=1e-7, atol=1e-16)
+    # device-side flux functional (cfdh_functional kind 7): all outlet caps together, and the inlet with the other sign
+    qo = g.outlet_flow_rates().sum()
+    assert abs(g.solver.functional(7, g.outlet_marker) - qo) <= 1e-12 * abs(qo)
+    assert g.solver.functional(7, g.inlet_marker) < 0 < qo   # outward normal: the inlet flux is negative
 
 
 def test_config4_full_size_properties():
