@@ -3,9 +3,9 @@
 //
 //  * moments3_kernel : M_ab = int_K tau l_a l_b (10 values) and L = int_K tau_LSIC on the 343-point rule
 //                      (stabilized_schur.py:100-118; u_prev only -> once per time step)
-//  * asm3_kernel     : fused element residual + Jacobian + Dirichlet rows/cols + lifting (stabilized_schur.py:67-123,
-//                      144-175,185-189).  One lane per (row vertex, cell) incidence computes the 4x16 row block of its
-//                      cell.  Unlike triangles around a vertex, tetrahedra around a vertex form no fan, so the blocks of
+//  * asm3q_kernel    : fused element residual + Jacobian + Dirichlet rows/cols + lifting (stabilized_schur.py:67-123,
+//                      144-175,185-189).  Four lanes per (row vertex, cell) incidence, one 4x4 column block each.
+//                      Unlike triangles around a vertex, tetrahedra around a vertex form no fan, so the blocks of
 //                      a workgroup's rows are accumulated in LDS with ds_add_f64 and written out coalesced -- no global
 //                      atomics; the summation order inside LDS is not fixed, so 3-D assembly is reproducible to
 //                      round-off, not bitwise.
@@ -34,6 +34,15 @@ __device__ __forceinline__ double dpp3(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// quad-local permutation (every source lane lies in the reader's own quad, so no lane ever reads an undefined value and
+// the destination needs no initialisation: one v_mov_b32_dpp per half instead of v_mov + v_mov_b32_dpp)
+template <int CTRL>
+__device__ __forceinline__ double dppq(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double g8sum(double v) {
@@ -119,8 +128,8 @@ __global__ __launch_bounds__(TPB) void moments3_kernel(int nc, int nv, const int
     const double uz = l0 * U[0][2] + l1 * U[1][2] + l2 * U[2][2] + l3 * U[3][2];
     const double s = ux * ux + uy * uy + uz * uz;
     const double t1 = fmax(4.0 * s, 1e-30) * ih2;
-    const double tau = 1.0 / sqrt(t1 + t2 + t3);
-    const double vn = sqrt(s), Re = vn * hr;
+    const double tau = cfdh_rsqrt(t1 + t2 + t3);
+    const double vn = s > 1e-280 ? s * cfdh_rsqrt(s) : 0.0, Re = vn * hr;
     const double z = (Re <= 3.0) ? Re * (1.0 / 3.0) : 1.0;
     L += wq * vn * h * z * 0.5;
     const double w = wq * tau;
@@ -146,6 +155,10 @@ int k3_moments(cfdh_ctx *c) {
 }
 
 // ---------------------------------------------------------------- fused assembly
+// LDS image of a workgroup's CSR rows: 16 values per slot at a stride of 17 doubles.  With stride 16 (128 B) the k-th value
+// of every slot lies in the same pair of LDS banks, and each ds_add_f64 of a wave (64 different slots, same k) is a
+// 32-way bank conflict.
+#define A3S 17
 struct Asm3Args {
   const double *coords, *mom, *x, *un, *un2, *bcval, *bcmult;
   const int *cells, *vptr, *vdiag, *blk_row, *blk_iptr, *inc_cell, *inc_row;
@@ -158,227 +171,255 @@ struct Asm3Args {
   int ds_terms, hist2;
 };
 
-// MODE 0: residual only; 1: residual + Jacobian; 2: residual with lifting (Jacobian in registers only)
+// MODE 0: residual only; 1: residual + Jacobian; 2: residual with lifting (Jacobian values of Dirichlet columns only)
+//
+// Four lanes per incidence.  Lanes 4k .. 4k+3 of a workgroup share incidence k (row vertex a of cell e); lane q owns local vertex q of the cell: it loads
+// that vertex's data, computes grad(lambda_q) and the q-th column block (16 values) of the row.  Everything that couples the
+// vertices (G, grad p, the tau-weighted sums, the residual) is a sum over q and is formed with quad-local DPP butterflies,
+// which leave the same value in all four lanes.  Per lane this is a quarter of the gathers and ~60 % of the registers of the
+// first version (one lane per incidence computing all four column blocks: 338 registers, one wave per SIMD, 2.1 ms at
+// 1.0 M DOF; this kernel: 206 registers, two waves per SIMD, 0.99 ms -- of which 0.35 ms came from the LDS stride alone).
+__device__ __forceinline__ double quad_allsum(double v) {
+  v += dppq<0xB1>(v);  // quad_perm [1,0,3,2]
+  v += dppq<0x4E>(v);  // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ int tet_mom_index(int r, int c) {  // packed upper triangle: 00 01 02 03 11 12 13 22 23 33
+  const int lo = r < c ? r : c, hi = r < c ? c : r;
+  return (lo == 0 ? 0 : (lo == 1 ? 4 : (lo == 2 ? 7 : 9))) + hi - lo;
+}
+
+#ifndef CFDH3_ASMQ_OCC
+#define CFDH3_ASMQ_OCC 2  // 3 waves per SIMD (168 registers) spills 36 of them: 1.67 ms instead of 0.99
+#endif
 template <int MODE>
-__global__ __launch_bounds__(TPB, 1) void asm3_kernel(Asm3Args p) {
+__global__ __launch_bounds__(TPB, CFDH3_ASMQ_OCC) void asm3q_kernel(Asm3Args p) {
   constexpr bool JAC = (MODE != 0);
   constexpr bool WJ = (MODE == 1);
   extern __shared__ double lds[];  // [nslots][16] value accumulators (MODE 1), then [nrows][4] residual accumulators
-  const int blk = blockIdx.x, t = threadIdx.x;
+  const int blk = blockIdx.x, t = threadIdx.x, q = t & 3, lane = t & 63;
   const int row0 = p.blk_row[blk], row1 = p.blk_row[blk + 1], nrows = row1 - row0;
   const int slot0 = p.vptr[row0], nslots = p.vptr[row1] - slot0;
   double *accJ = lds;
-  double *accF = lds + (WJ ? 16 * nslots : 0);
-  for (int i = t; i < (WJ ? 16 * nslots : 0) + 4 * nrows; i += TPB) lds[i] = 0.0;
+  double *accF = lds + (WJ ? A3S * nslots : 0);
+  for (int i = t; i < (WJ ? A3S * nslots : 0) + 4 * nrows; i += TPB) lds[i] = 0.0;
   __syncthreads();
   const int nv = p.nv;
   const double rho = p.rho, mu = p.mu, idt = 1.0 / p.dt, th = p.theta, a0idt = p.a0 * idt;
-  for (int inc = p.blk_iptr[blk] + t; inc < p.blk_iptr[blk + 1]; inc += TPB) {
+  const int i0 = p.blk_iptr[blk], i1 = p.blk_iptr[blk + 1];
+  for (int base = i0; base < i1; base += TPB / 4) {
+    const int inc_raw = base + (t >> 2);
+    const bool valid = inc_raw < i1;  // a whole quad is valid or not; invalid quads recompute the last incidence and add nothing
+    const int inc = valid ? inc_raw : i1 - 1;
     const int ca = p.inc_cell[inc], e = ca >> 2, a = ca & 3;
     const int rloc = p.inc_row[inc];
-    const unsigned long long sl = p.inc_slots[inc];
-    int vs[4];
-    double X[4][3], ub[4][3], w[4][3], ue[4][3], pe[4];
-    unsigned fl[4];
+    const unsigned slot = (unsigned)((p.inc_slots[inc] >> (16 * q)) & 0xffffull);
+    const int vq = p.cells[4 * (size_t)e + q];
+    const unsigned flq = p.bcflag[vq];
+    const double pq = p.x[3 * (size_t)nv + vq];
+    double Xq[3], ubq[3], wq[3];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      vs[b] = p.cells[4 * (size_t)e + b];
-      fl[b] = p.bcflag[vs[b]];
-      pe[b] = p.x[3 * (size_t)nv + vs[b]];
+    for (int i = 0; i < 3; i++) {
+      Xq[i] = p.coords[3 * (size_t)vq + i];
+      const double u = p.x[3 * (size_t)vq + i], un = p.un[3 * (size_t)vq + i];
+      ubq[i] = th * u + (1.0 - th) * un;
+      double wt = p.a0 * u + p.a1 * un;
+      if (p.hist2) wt += p.a2 * p.un2[3 * (size_t)vq + i];
+      wq[i] = wt * idt;
+    }
+    const double *mo = p.mom + 12 * (size_t)e;
+    double Mq[4];  // row q of the symmetric moment matrix
+#pragma unroll
+    for (int d = 0; d < 4; d++) Mq[d] = mo[tet_mom_index(q, d)];
+    const double Lm = mo[10];
+    // ---- grad(lambda_q) = n / (n . (A - B)), n = (C - B) x (D - B), with (A, B, C, D) = vertices (q, q+1, q+2, q+3) mod 4
+    double gq[3], vol;
+    {
+      double cb[3], db[3], ab[3];
 #pragma unroll
       for (int i = 0; i < 3; i++) {
-        X[b][i] = p.coords[3 * (size_t)vs[b] + i];
-        const double u = p.x[3 * (size_t)vs[b] + i], un = p.un[3 * (size_t)vs[b] + i];
-        ue[b][i] = u;
-        ub[b][i] = th * u + (1.0 - th) * un;
-        double wt = p.a0 * u + p.a1 * un;
-        if (p.hist2) wt += p.a2 * p.un2[3 * (size_t)vs[b] + i];
-        w[b][i] = wt * idt;
+        const double B = dppq<0x39>(Xq[i]), C = dppq<0x4E>(Xq[i]), D = dppq<0x93>(Xq[i]);
+        cb[i] = C - B; db[i] = D - B; ab[i] = Xq[i] - B;
+      }
+      const double n0 = cb[1] * db[2] - cb[2] * db[1], n1 = cb[2] * db[0] - cb[0] * db[2], n2 = cb[0] * db[1] - cb[1] * db[0];
+      const double den = n0 * ab[0] + n1 * ab[1] + n2 * ab[2];
+      const double iden = 1.0 / den;
+      gq[0] = n0 * iden; gq[1] = n1 * iden; gq[2] = n2 * iden;
+      vol = dppq<0x00>(fabs(den)) * (1.0 / 6.0);  // lane 0 of the quad speaks for all
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- quantities of the row vertex a (lane a of the quad)
+    const int srcA = (lane & ~3) | a;
+    double ga[3], uA[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { ga[i] = __shfl(gq[i], srcA); uA[i] = __shfl(ubq[i], srcA); }
+    const unsigned flA = (unsigned)__shfl((int)flq, srcA);
+    const double dqa = (q == a) ? 2.0 : 1.0;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- sums over the cell's vertices
+    double G[3][3], gp[3], usum[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      gp[i] = quad_allsum(pq * gq[i]);
+      usum[i] = quad_allsum(ubq[i]);
+#pragma unroll
+      for (int j = 0; j < 3; j++) G[i][j] = quad_allsum(gq[i] * ubq[j]);
+    }
+    const double psum = quad_allsum(pq);
+    const double divu = G[0][0] + G[1][1] + G[2][2];
+    double wcq[3], Rq[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const double cn = ubq[0] * G[0][j] + ubq[1] * G[1][j] + ubq[2] * G[2][j];
+      wcq[j] = wq[j] + cn;
+      Rq[j] = rho * wcq[j] + gp[j] - rho * p.f[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const double mtq = Mq[0] + Mq[1] + Mq[2] + Mq[3];
+    const double T = quad_allsum(mtq);
+    const double betaAq = ubq[0] * ga[0] + ubq[1] * ga[1] + ubq[2] * ga[2];  // beta[q][a]
+    // MBa[q] = sum_d M[q][d] beta[d][a],  Q[q][i] = sum_c M[q][c] R[c][i]
+    double MBaq = 0.0, Qq[3] = {0, 0, 0};
+    {
+      const double b0 = dppq<0x00>(betaAq), b1 = dppq<0x55>(betaAq), b2 = dppq<0xAA>(betaAq), b3 = dppq<0xFF>(betaAq);
+      MBaq = Mq[0] * b0 + Mq[1] * b1 + Mq[2] * b2 + Mq[3] * b3;
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+        Qq[i] = Mq[0] * dppq<0x00>(Rq[i]) + Mq[1] * dppq<0x55>(Rq[i]) + Mq[2] * dppq<0xAA>(Rq[i]) + Mq[3] * dppq<0xFF>(Rq[i]);
+    }
+    const double m1 = vol * (1.0 / 20.0);
+    double s1[3], s2[3], s3[3];  // m1 (sum_d ubar_d + ubar_a), sum_d MBa[d] ubar_d, sum_d mt[d] ubar_d
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      s1[i] = m1 * (usum[i] + uA[i]);
+      s2[i] = quad_allsum(MBaq * ubq[i]);
+      s3[i] = quad_allsum(mtq * ubq[i]);
+    }
+    const double mtBA = s3[0] * ga[0] + s3[1] * ga[1] + s3[2] * ga[2];
+    double Gg[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) Gg[j] = G[j][0] * ga[0] + G[j][1] * ga[1] + G[j][2] * ga[2];
+    const double pbar = 0.25 * psum;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- exterior facets containing vertex a: n_f |f| = -3 vol grad(lambda_f); SN = sum over the flagged facets f != a
+    const unsigned cf = p.ds_terms ? (unsigned)p.cflag[e] : 0u;
+    double SN[3] = {0, 0, 0}, NFq[3] = {0, 0, 0};
+    const bool facet_q = ((cf >> q) & 1u) && q != a;
+    if (cf) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        NFq[i] = facet_q ? -3.0 * vol * gq[i] : 0.0;
+        SN[i] = quad_allsum(NFq[i]);
       }
     }
-    double g[4][3], vol, hh;
-    tet_geom(X, g, vol, hh);
-    // moments
-    const double *mo = p.mom + 12 * (size_t)e;
-    double M[4][4];
-    M[0][0] = mo[0]; M[0][1] = M[1][0] = mo[1]; M[0][2] = M[2][0] = mo[2]; M[0][3] = M[3][0] = mo[3];
-    M[1][1] = mo[4]; M[1][2] = M[2][1] = mo[5]; M[1][3] = M[3][1] = mo[6];
-    M[2][2] = mo[7]; M[2][3] = M[3][2] = mo[8]; M[3][3] = mo[9];
-    const double Lm = mo[10];
-    double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gp[3] = {0, 0, 0};
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        gp[i] += pe[b] * g[b][i];
-#pragma unroll
-        for (int j = 0; j < 3; j++) G[i][j] += g[b][i] * ub[b][j];
-      }
-    const double divu = G[0][0] + G[1][1] + G[2][2];
-    double Rr[4][3], wc[4][3], beta[4][4], mt[4], Q[4][3];
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const double cn = ub[b][0] * G[0][j] + ub[b][1] * G[1][j] + ub[b][2] * G[2][j];
-        wc[b][j] = w[b][j] + cn;
-        Rr[b][j] = rho * wc[b][j] + gp[j] - rho * p.f[j];
-      }
-#pragma unroll
-    for (int d = 0; d < 4; d++)
-#pragma unroll
-      for (int b = 0; b < 4; b++) beta[d][b] = ub[d][0] * g[b][0] + ub[d][1] * g[b][1] + ub[d][2] * g[b][2];
-    double T = 0.0;
-#pragma unroll
-    for (int b = 0; b < 4; b++) { mt[b] = M[b][0] + M[b][1] + M[b][2] + M[b][3]; T += mt[b]; }
-#pragma unroll
-    for (int d = 0; d < 4; d++)
-#pragma unroll
-      for (int i = 0; i < 3; i++) Q[d][i] = M[0][d] * Rr[0][i] + M[1][d] * Rr[1][i] + M[2][d] * Rr[2][i] + M[3][d] * Rr[3][i];
-    const double pbar = 0.25 * (pe[0] + pe[1] + pe[2] + pe[3]);
-    const double m1 = vol * (1.0 / 20.0);
-    // quantities of the row vertex a (runtime index: selected once)
-    double ga[3], betaA[4], QA_unused = 0.0;
-    (void)QA_unused;
-#pragma unroll
-    for (int i = 0; i < 3; i++) ga[i] = a == 0 ? g[0][i] : (a == 1 ? g[1][i] : (a == 2 ? g[2][i] : g[3][i]));
-#pragma unroll
-    for (int d = 0; d < 4; d++) betaA[d] = ub[d][0] * ga[0] + ub[d][1] * ga[1] + ub[d][2] * ga[2];  // beta[d][a]
-    const double mtA = a == 0 ? mt[0] : (a == 1 ? mt[1] : (a == 2 ? mt[2] : mt[3]));
-    const unsigned flA = a == 0 ? fl[0] : (a == 1 ? fl[1] : (a == 2 ? fl[2] : fl[3]));
-    // ---- residual rows of vertex a
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- residual of row a: this lane's share (terms of vertex q; the terms without a vertex sum go to lane 0)
     double Fr[4];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      double v = 0.0;
+      double v = rho * m1 * dqa * wcq[i] + betaAq * Qq[i];
+      if (q == 0) {
+        double Eg = 0.0;
 #pragma unroll
-      for (int b = 0; b < 4; b++) v += rho * m1 * ((b == a) ? 2.0 : 1.0) * wc[b][i];
-      v -= rho * p.f[i] * vol * 0.25;
-      double Eg = 0.0;
-#pragma unroll
-      for (int k = 0; k < 3; k++) Eg += 0.5 * (G[i][k] + G[k][i]) * ga[k];
-      v += vol * (2.0 * mu * Eg - pbar * ga[i]);
-#pragma unroll
-      for (int d = 0; d < 4; d++) v += betaA[d] * Q[d][i];
-      v += rho * Lm * divu * ga[i];
+        for (int k = 0; k < 3; k++) Eg += 0.5 * (G[i][k] + G[k][i]) * ga[k];
+        v += vol * (2.0 * mu * Eg - pbar * ga[i]) - rho * p.f[i] * vol * 0.25 + rho * Lm * divu * ga[i];
+      }
       Fr[i] = v;
     }
-    {
-      double v = vol * 0.25 * divu;
+    Fr[3] = mtq * (Rq[0] * ga[0] + Rq[1] * ga[1] + Rq[2] * ga[2]) / rho + (q == 0 ? vol * 0.25 * divu : 0.0);
+    if (cf) {
+      const double pAv = __shfl(pq, srcA);
+      if (facet_q) {
+        // facet f = q (f != a): pint = (sum_k p_k (1 + delta_ka) - p_f) / 12
+        const double pint = (psum + pAv - pq) * (1.0 / 12.0);
 #pragma unroll
-      for (int b = 0; b < 4; b++) v += mt[b] * (Rr[b][0] * ga[0] + Rr[b][1] * ga[1] + Rr[b][2] * ga[2]) / rho;
-      Fr[3] = v;
-    }
-    // exterior facets containing vertex a (every facet f != a)
-    const unsigned cf = p.ds_terms ? (unsigned)p.cflag[e] : 0u;
-    double mtBA = 0.0;  // mtB[a] = sum_d mt[d] beta[d][a]
-#pragma unroll
-    for (int d = 0; d < 4; d++) mtBA += mt[d] * betaA[d];
-    double MBa[4];  // MB[c][a] = sum_d M[c][d] beta[d][a]
-#pragma unroll
-    for (int cI = 0; cI < 4; cI++) MBa[cI] = M[cI][0] * betaA[0] + M[cI][1] * betaA[1] + M[cI][2] * betaA[2] + M[cI][3] * betaA[3];
-    // ---- one column block at a time: 16 values, Dirichlet handling, LDS accumulation
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-      double J00[3][3], J01[3], J10[3], J11 = 0.0;
-      if (JAC) {
-        const double mab = m1 * ((b == a) ? 2.0 : 1.0);
-        double mBab = 0.0, BMB = 0.0, mtBb = 0.0;
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          mBab += m1 * ((d == a) ? 2.0 : 1.0) * beta[d][b];
-          BMB += beta[d][b] * MBa[d];
-          mtBb += mt[d] * beta[d][b];
+        for (int i = 0; i < 3; i++) {
+          const double GN = G[i][0] * NFq[0] + G[i][1] * NFq[1] + G[i][2] * NFq[2];
+          Fr[i] += NFq[i] * pint - p.muf * GN * (1.0 / 3.0);
         }
-        const double gg = ga[0] * g[b][0] + ga[1] * g[b][1] + ga[2] * g[b][2];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- column block q of row a: the 16 values are produced one at a time and go straight to their LDS accumulator
+    //      (never all live).  Dirichlet handling on the way: a Dirichlet column j of vertex q lifts F += J[:, j] (g - x) and
+    //      is zeroed, a Dirichlet row of vertex a is zeroed (its diagonal is set at write-out).  MODE 2 needs the values of
+    //      Dirichlet columns only.
+    if (JAC && (WJ || flq)) {
+      const double mab = m1 * dqa;
+      const double gg = ga[0] * gq[0] + ga[1] * gq[1] + ga[2] * gq[2];
+      const double mBab = s1[0] * gq[0] + s1[1] * gq[1] + s1[2] * gq[2];
+      const double BMB = s2[0] * gq[0] + s2[1] * gq[1] + s2[2] * gq[2];
+      const double mtBb = s3[0] * gq[0] + s3[1] * gq[1] + s3[2] * gq[2];
+      const double cG = rho * th * (mab + MBaq);
+      const double cD = rho * a0idt * (mab + MBaq) + rho * th * (mBab + BMB) + vol * mu * th * gg;
+      const double vmt = vol * mu * th, rlt = rho * Lm * th, cf3 = p.muf * th * (1.0 / 3.0);
+      double *dst = accJ + A3S * (size_t)slot;
+      const bool store = WJ && valid;
+      if (!(flq | flA)) {
+        // interior quad lanes: no masks
 #pragma unroll
         for (int i = 0; i < 3; i++) {
 #pragma unroll
           for (int j = 0; j < 3; j++) {
-            const double dij = (i == j) ? 1.0 : 0.0;
-            double v = rho * mab * dij * a0idt;
-            v += rho * th * (mab * G[j][i] + dij * mBab);
-            v += vol * mu * th * (g[b][i] * ga[j] + gg * dij);
-            v += rho * ((dij * a0idt + th * G[j][i]) * MBa[b] + th * dij * BMB);
-            v += th * ga[j] * Q[b][i];
-            v += rho * Lm * th * g[b][j] * ga[i];
-            J00[i][j] = v;
+            double v = cG * G[j][i] + vmt * gq[i] * ga[j] + th * ga[j] * Qq[i] + rlt * gq[j] * ga[i];
+            if (i == j) v += cD;
+            if (cf) v -= cf3 * gq[i] * SN[j];
+            if (store) atomicAdd(dst + 3 * i + j, v);
           }
-          J01[i] = -vol * 0.25 * ga[i] + g[b][i] * mtBA;
+          double v = -vol * 0.25 * ga[i] + gq[i] * mtBA;
+          if (cf) v += (SN[i] - NFq[i]) * dqa * (1.0 / 12.0);  // facets f != a, f != q
+          if (store) atomicAdd(dst + 9 + i, v);
         }
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-          const double Gg = G[j][0] * ga[0] + G[j][1] * ga[1] + G[j][2] * ga[2];
-          J10[j] = vol * 0.25 * th * g[b][j] + mt[b] * (ga[j] * a0idt + th * Gg) + th * ga[j] * mtBb;
+          const double v = vol * 0.25 * th * gq[j] + mtq * (ga[j] * a0idt + th * Gg[j]) + th * ga[j] * mtBb;
+          if (store) atomicAdd(dst + 12 + j, v);
         }
-        J11 = T * gg / rho;
-      }
-      // facet terms
-      if (cf) {
+        if (store) atomicAdd(dst + 15, T * gg / rho);
+      } else {
+        double gx[4] = {0, 0, 0, 0};  // g - x on the Dirichlet columns of vertex q, zero elsewhere
 #pragma unroll
-        for (int f = 0; f < 4; f++) {
-          if (f == a || !((cf >> f) & 1u)) continue;
-          const double gl = sqrt(g[f][0] * g[f][0] + g[f][1] * g[f][1] + g[f][2] * g[f][2]);
-          const double n[3] = {-g[f][0] / gl, -g[f][1] / gl, -g[f][2] / gl};
-          const double fm = 3.0 * vol * gl;
-          if (b == 0) {  // residual part once per incidence
-            double pint = 0.0;
+        for (int jc = 0; jc < 3; jc++)
+          if ((flq >> jc) & 1u) gx[jc] = p.bcval[4 * (size_t)vq + jc] - p.x[3 * (size_t)vq + jc];
+        if (flq & 8u) gx[3] = p.bcval[4 * (size_t)vq + 3] - pq;
 #pragma unroll
-            for (int q = 0; q < 4; q++) if (q != f) pint += pe[q] * ((q == a) ? 2.0 : 1.0);
-            pint *= (1.0 / 12.0);
+        for (int i = 0; i < 3; i++) {
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-              const double Gn = G[i][0] * n[0] + G[i][1] * n[1] + G[i][2] * n[2];
-              Fr[i] += n[i] * fm * pint - p.muf * Gn * fm * (1.0 / 3.0);
-            }
+          for (int j = 0; j < 3; j++) {
+            double v = cG * G[j][i] + vmt * gq[i] * ga[j] + th * ga[j] * Qq[i] + rlt * gq[j] * ga[i];
+            if (i == j) v += cD;
+            if (cf) v -= cf3 * gq[i] * SN[j];
+            Fr[i] += v * gx[j];
+            if (((flq >> j) | (flA >> i)) & 1u) v = 0.0;
+            if (store) atomicAdd(dst + 3 * i + j, v);
           }
-          if (JAC) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-              if (b != f) J01[i] += n[i] * fm * ((b == a) ? 2.0 : 1.0) * (1.0 / 12.0);
-#pragma unroll
-              for (int j = 0; j < 3; j++) J00[i][j] -= p.muf * th * g[b][i] * n[j] * fm * (1.0 / 3.0);
-            }
-          }
+          double v = -vol * 0.25 * ga[i] + gq[i] * mtBA;
+          if (cf) v += (SN[i] - NFq[i]) * dqa * (1.0 / 12.0);
+          Fr[i] += v * gx[3];
+          if (((flq >> 3) | (flA >> i)) & 1u) v = 0.0;
+          if (store) atomicAdd(dst + 9 + i, v);
         }
-      }
-      // Dirichlet columns of vertex b: lifting F += J[:, bc] (g - x), then zero the column
-      if (JAC && fl[b]) {
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-          if ((fl[b] >> j) & 1u) {
-            const double gx = p.bcval[4 * (size_t)vs[b] + j] - ue[b][j];
-            Fr[0] += J00[0][j] * gx; Fr[1] += J00[1][j] * gx; Fr[2] += J00[2][j] * gx; Fr[3] += J10[j] * gx;
-            J00[0][j] = 0.0; J00[1][j] = 0.0; J00[2][j] = 0.0; J10[j] = 0.0;
-          }
-        if (fl[b] & 8u) {
-          const double gx = p.bcval[4 * (size_t)vs[b] + 3] - pe[b];
-          Fr[0] += J01[0] * gx; Fr[1] += J01[1] * gx; Fr[2] += J01[2] * gx; Fr[3] += J11 * gx;
-          J01[0] = 0.0; J01[1] = 0.0; J01[2] = 0.0; J11 = 0.0;
+        for (int j = 0; j < 3; j++) {
+          double v = vol * 0.25 * th * gq[j] + mtq * (ga[j] * a0idt + th * Gg[j]) + th * ga[j] * mtBb;
+          Fr[3] += v * gx[j];
+          if (((flq >> j) | (flA >> 3)) & 1u) v = 0.0;
+          if (store) atomicAdd(dst + 12 + j, v);
         }
-      }
-      if (WJ) {
-        // Dirichlet rows of vertex a: zero (the diagonal is set at write-out)
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-          if ((flA >> i) & 1u) { J00[i][0] = 0.0; J00[i][1] = 0.0; J00[i][2] = 0.0; J01[i] = 0.0; }
-        if (flA & 8u) { J10[0] = 0.0; J10[1] = 0.0; J10[2] = 0.0; J11 = 0.0; }
-        double *dst = accJ + 16 * (size_t)((sl >> (16 * b)) & 0xffffull);
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-          for (int j = 0; j < 3; j++) atomicAdd(dst + 3 * i + j, J00[i][j]);
-#pragma unroll
-        for (int i = 0; i < 3; i++) { atomicAdd(dst + 9 + i, J01[i]); atomicAdd(dst + 12 + i, J10[i]); }
-        atomicAdd(dst + 15, J11);
+        {
+          double v = T * gg / rho;
+          Fr[3] += v * gx[3];
+          if (((flq | flA) >> 3) & 1u) v = 0.0;
+          if (store) atomicAdd(dst + 15, v);
+        }
       }
     }
-    // Dirichlet rows: residual replaced at write-out
+    // ---- residual: sum of the four shares; lane q adds component q (Dirichlet rows are replaced at write-out)
 #pragma unroll
-    for (int i = 0; i < 3; i++) if ((flA >> i) & 1u) Fr[i] = 0.0;
-    if (flA & 8u) Fr[3] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) atomicAdd(accF + 4 * rloc + i, Fr[i]);
+    for (int i = 0; i < 4; i++) Fr[i] = quad_allsum(Fr[i]);
+    const double Fq = q == 0 ? Fr[0] : (q == 1 ? Fr[1] : (q == 2 ? Fr[2] : Fr[3]));
+    const bool rowbc = (flA >> q) & 1u;  // bits 0-2: velocity components, bit 3: pressure
+    if (valid && !rowbc) atomicAdd(accF + 4 * rloc + q, Fq);
   }
   __syncthreads();
   // ---- Dirichlet rows: diagonal = number of bc objects, F = x - g
@@ -386,7 +427,7 @@ __global__ __launch_bounds__(TPB, 1) void asm3_kernel(Asm3Args p) {
     const int row = row0 + r;
     const unsigned flr = p.bcflag[row];
     if (!flr) continue;
-    double *dg = accJ + 16 * (size_t)(p.vdiag[row] - slot0);
+    double *dg = accJ + A3S * (size_t)(p.vdiag[row] - slot0);
 #pragma unroll
     for (int i = 0; i < 3; i++)
       if ((flr >> i) & 1u) {
@@ -401,12 +442,12 @@ __global__ __launch_bounds__(TPB, 1) void asm3_kernel(Asm3Args p) {
   __syncthreads();
   // ---- coalesced write-out of the workgroup's slot range
   if (WJ) {
-    for (int i = t; i < 9 * nslots; i += TPB) p.A00[9 * (size_t)slot0 + i] = accJ[16 * (i / 9) + (i % 9)];
+    for (int i = t; i < 9 * nslots; i += TPB) p.A00[9 * (size_t)slot0 + i] = accJ[A3S * (i / 9) + (i % 9)];
     for (int i = t; i < 3 * nslots; i += TPB) {
-      p.A01[3 * (size_t)slot0 + i] = accJ[16 * (i / 3) + 9 + (i % 3)];
-      p.A10[3 * (size_t)slot0 + i] = accJ[16 * (i / 3) + 12 + (i % 3)];
+      p.A01[3 * (size_t)slot0 + i] = accJ[A3S * (i / 3) + 9 + (i % 3)];
+      p.A10[3 * (size_t)slot0 + i] = accJ[A3S * (i / 3) + 12 + (i % 3)];
     }
-    for (int i = t; i < nslots; i += TPB) p.A11[(size_t)slot0 + i] = accJ[16 * i + 15];
+    for (int i = t; i < nslots; i += TPB) p.A11[(size_t)slot0 + i] = accJ[A3S * i + 15];
   }
   for (int i = t; i < 3 * nrows; i += TPB) p.F[3 * (size_t)row0 + i] = accF[4 * (i / 3) + (i % 3)];
   for (int i = t; i < nrows; i += TPB) p.F[3 * (size_t)nv + row0 + i] = accF[4 * i + 3];
@@ -422,11 +463,11 @@ int k3_assemble(cfdh_ctx *c, const double *xstate, int mode) {
   a.nv = c->nv; a.dt = c->dt; a.rho = c->rho; a.mu = c->mu; a.muf = c->muf; a.f[0] = c->f[0]; a.f[1] = c->f[1]; a.f[2] = c->f[2];
   a.theta = c->ts_theta; a.a0 = c->ts_a[0]; a.a1 = c->ts_a[1]; a.a2 = c->ts_a[2];
   a.ds_terms = c->ds_terms ? 1 : 0; a.hist2 = c->ts_a[2] != 0.0 ? 1 : 0;
-  const size_t lds = sizeof(double) * (16 * (size_t)CFDH3_MAX_SLOTS + 4 * 64);
+  const size_t lds = sizeof(double) * (A3S * (size_t)CFDH3_MAX_SLOTS + 4 * 64);
   prof_begin(c, 0);
-  if (mode == 1) hipLaunchKernelGGL((asm3_kernel<1>), dim3(c->a3_nblk), dim3(TPB), lds, c->stream, a);
-  else if (mode == 2) hipLaunchKernelGGL((asm3_kernel<2>), dim3(c->a3_nblk), dim3(TPB), sizeof(double) * 4 * 64, c->stream, a);
-  else hipLaunchKernelGGL((asm3_kernel<0>), dim3(c->a3_nblk), dim3(TPB), sizeof(double) * 4 * 64, c->stream, a);
+  if (mode == 1) hipLaunchKernelGGL((asm3q_kernel<1>), dim3(c->a3_nblk), dim3(TPB), lds, c->stream, a);
+  else if (mode == 2) hipLaunchKernelGGL((asm3q_kernel<2>), dim3(c->a3_nblk), dim3(TPB), sizeof(double) * 4 * 64, c->stream, a);
+  else hipLaunchKernelGGL((asm3q_kernel<0>), dim3(c->a3_nblk), dim3(TPB), sizeof(double) * 4 * 64, c->stream, a);
   prof_end(c, 0);
   HIPCHK(c, hipGetLastError());
   if (mode == 1) c->jac_valid = true;

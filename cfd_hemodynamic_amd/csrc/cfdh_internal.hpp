@@ -11,11 +11,32 @@
 
 #include "cfdh.h"
 
+// geometry of a 2-D assembly workgroup (overridable for tuning experiments, tools/build_variant.sh)
+#ifndef CFDH_MAX_INC
 #define CFDH_MAX_INC 256   // incidences (= threads) per assembly workgroup
-#define CFDH_MAX_SLOTS 320 // vertex-graph slots per assembly workgroup (LDS 72 B each)
+#endif
+#ifndef CFDH_MAX_BV
 #define CFDH_MAX_BV 192    // distinct vertices staged in LDS per assembly workgroup (8-bit local index)
+#endif
+#ifndef CFDH_MAX_BC
 #define CFDH_MAX_BC 192    // distinct cells staged in LDS per assembly workgroup
+#endif
+#ifndef CFDH_MAX_ROWS
 #define CFDH_MAX_ROWS 128  // rows per assembly workgroup
+#endif
+
+#if defined(__HIPCC__)
+// 1/sqrt(x) for normal positive x: hardware estimate (v_rsq_f64) + two Newton steps (error -> ~1 ulp); the compiler's
+// IEEE sequence for 1.0 / sqrt(x) (sqrt with scaling + full division) is ~3x as many instructions, and the tau-moment
+// kernels evaluate it at 49 / 343 points per cell
+__device__ __forceinline__ double cfdh_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
+  y = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
+  return y;
+}
+#endif
 
 template <class T>
 struct dbuf {

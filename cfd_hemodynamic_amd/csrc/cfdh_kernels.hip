@@ -159,8 +159,8 @@ __global__ __launch_bounds__(TPB) void moments_kernel(int nc, int nvo, const int
     double uy = l0 * u0y + l1 * u1y + l2 * u2y;
     double s = ux * ux + uy * uy;
     double t1 = fmax(4.0 * s, 1e-30) * ih2;  // (max(2|u|, eps))^2 / h^2, eps = 1e-15
-    double tau = 1.0 / sqrt(t1 + t2 + t3);
-    double vn = sqrt(s);
+    double tau = cfdh_rsqrt(t1 + t2 + t3);
+    double vn = s > 1e-280 ? s * cfdh_rsqrt(s) : 0.0;
     double Re = vn * hr;
     double z = (Re <= 3.0) ? Re * (1.0 / 3.0) : 1.0;
     double tl = vn * h * z * 0.5;
@@ -197,6 +197,9 @@ struct AsmArgs {
   double theta, a0, a1, a2;  // time scheme (cfdh_set_time_scheme)
   double beta_bf;            // backflow coefficient beta*rho on facets flagged in cflag bits 3..5 (cfdh_set_boundary_terms)
   int ds_terms;              // the ds pair of stabilized_schur.py:79 on all exterior facets
+#ifdef CFDH_ASM_TIMING
+  long long *dbg;            // [nblk][8] phase time stamps of wave 0 (diagnostic build only)
+#endif
 };
 
 // MODE 0: residual only; 1: residual + Jacobian; 2: residual with lifting (Jacobian in registers only)
@@ -211,7 +214,13 @@ struct AsmArgs {
 #define CFDH_BF_OCC 2  // the backflow variant needs ~10 more VGPRs than the 168 of 3 waves/SIMD: run it at 2
 #endif
 // BF: backflow facets present (compiled out otherwise so that the base solver keeps its register budget).
-template <int MODE, bool HIST2 = false, bool BF = false, int OCC = (BF ? CFDH_BF_OCC : 3)>
+#ifndef CFDH_ASM_OCC
+#define CFDH_ASM_OCC 3
+#endif
+#ifndef MOMS
+#define MOMS 5
+#endif
+template <int MODE, bool HIST2 = false, bool BF = false, int OCC = (BF ? CFDH_BF_OCC : CFDH_ASM_OCC)>
 __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
   constexpr bool JAC = (MODE != 0);
   constexpr bool WJ = (MODE == 1);
@@ -220,13 +229,23 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
   __shared__ double sP[CFDH_MAX_BV];
   __shared__ int sVid[CFDH_MAX_BV];
   __shared__ unsigned char sFl[CFDH_MAX_BV];
-  __shared__ double2 sMom[CFDH_MAX_BC * 4];
+  __shared__ double2 sMom[CFDH_MAX_BC * MOMS];  // 64-B records at a stride of 80 B: with stride 64 the k-th quarter of every record
+                                                // falls into the same 4 of the 64 LDS banks (16-way conflict on every read)
   __shared__ unsigned char sCf[CFDH_MAX_BC];
   __shared__ int sRow[CFDH_MAX_ROWS + 1];
   const int t = threadIdx.x, blk = blockIdx.x;
+#ifdef CFDH_ASM_TIMING
+  long long ts[6];
+  ts[0] = __builtin_readcyclecounter();
+#endif
   const int row0 = p.blk_row[blk], row1 = p.blk_row[blk + 1];
   const int nrows = row1 - row0;
   const int nvo = p.nvo;
+  // the lane's own incidence record does not depend on the staged data: requested first, so that its latency
+  // overlaps the staging loads instead of following the barrier
+  const size_t lk = (size_t)blk * CFDH_MAX_INC + t;
+  const unsigned loc = p.inc_loc[lk], meta = p.inc_slot[lk], seg = p.inc_rank[lk];
+  const int wmax = p.wave_maxlen[blk * (CFDH_MAX_INC / 64) + (t >> 6)];
   {
     const int v0 = p.blk_vptr[blk], nvl = p.blk_vptr[blk + 1] - v0;
     for (int i = t; i < nvl; i += CFDH_MAX_INC) {
@@ -243,15 +262,19 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
     const int c0 = p.blk_cptr[blk], ncl = p.blk_cptr[blk + 1] - c0;
     for (int i = t; i < 4 * ncl; i += CFDH_MAX_INC) {  // 4 x 16 B per cell record, consecutive lanes
       const int cid = p.blk_clist[c0 + (i >> 2)];
-      sMom[i] = *(const double2 *)(p.mom + 8 * (size_t)cid + 2 * (i & 3));
+      sMom[MOMS * (i >> 2) + (i & 3)] = *(const double2 *)(p.mom + 8 * (size_t)cid + 2 * (i & 3));
     }
     for (int i = t; i < ncl; i += CFDH_MAX_INC) sCf[i] = p.cflag[p.blk_clist[c0 + i]];
     for (int i = t; i <= nrows; i += CFDH_MAX_INC) sRow[i] = p.vptr[row0 + i];
   }
+#ifdef CFDH_ASM_TIMING
+  ts[1] = __builtin_readcyclecounter();
+#endif
   __syncthreads();
+#ifdef CFDH_ASM_TIMING
+  ts[2] = __builtin_readcyclecounter();
+#endif
 
-  const size_t lk = (size_t)blk * CFDH_MAX_INC + t;
-  const unsigned loc = p.inc_loc[lk], meta = p.inc_slot[lk], seg = p.inc_rank[lk];
   const bool active = loc != 0xFFFFFFFFu;
   double Fr[3] = {0, 0, 0};
   double J00[3][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}}, J01[3][2] = {{0, 0}, {0, 0}, {0, 0}},
@@ -272,7 +295,7 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
     cb = ((cb >> a) | (cb << (3 - a))) & 7u;
     if (!p.ds_terms) cf = 0;
     // moments, rotated
-    const double2 m0 = sMom[4 * lc], m1 = sMom[4 * lc + 1], m2 = sMom[4 * lc + 2], m3 = sMom[4 * lc + 3];
+    const double2 m0 = sMom[MOMS * lc], m1 = sMom[MOMS * lc + 1], m2 = sMom[MOMS * lc + 2], m3 = sMom[MOMS * lc + 3];
     const double o00 = m0.x, o01 = m0.y, o02 = m1.x, o11 = m1.y, o12 = m2.x, o22 = m2.y, Lm = m3.x;
     double M[3][3];
     M[0][0] = a == 0 ? o00 : (a == 1 ? o11 : o22);
@@ -503,11 +526,13 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
       }
     }
   }
+#ifdef CFDH_ASM_TIMING
+  ts[3] = __builtin_readcyclecounter();
+#endif
   // ---- wavefront-level segmented reduction (all 64 lanes take part; idle lanes carry zeros)
   const int lane = t & 63;
   const int seg_pos = seg & 255, seg_len = (seg >> 8) & 255, prev_off = (int)((seg >> 16) & 255) - 64;
   const bool has_prev = (meta >> 27) & 1u, emit_v2 = (meta >> 26) & 1u;
-  const int wmax = p.wave_maxlen[blk * (CFDH_MAX_INC / 64) + (t >> 6)];
   if (WJ) {
     // off-diagonal block of the edge (i, v1): this cell's B1 plus B2 of the previous cell of the fan
     const int src = lane + (has_prev ? prev_off : 0);
@@ -536,6 +561,9 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
       { const double v = __shfl_down(J11[0], off); if (take) J11[0] += v; }
     }
   }
+#ifdef CFDH_ASM_TIMING
+  ts[4] = __builtin_readcyclecounter();
+#endif
   // ---- every block of the row now sits complete in exactly one lane: plain stores
   if (active) {
     const size_t sb = (size_t)sRow[row - row0];
@@ -576,6 +604,12 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
       p.F[2 * (size_t)nvo + row] = Fr[2];
     }
   }
+#ifdef CFDH_ASM_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  ts[5] = __builtin_readcyclecounter();
+  if (t == 0 && p.dbg)
+    for (int k = 0; k < 6; k++) p.dbg[8 * (size_t)blk + k] = ts[k];
+#endif
 }
 
 int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
@@ -591,6 +625,12 @@ int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
   a.theta = c->ts_theta; a.a0 = c->ts_a[0]; a.a1 = c->ts_a[1]; a.a2 = c->ts_a[2];
   a.beta_bf = c->bf_beta * c->rho; a.ds_terms = c->ds_terms ? 1 : 0;
   const bool hist2 = c->ts_a[2] != 0.0;
+#ifdef CFDH_ASM_TIMING
+  static long long *dbg = nullptr;
+  static int dbg_calls = 0;
+  if (!dbg) hipMalloc(&dbg, sizeof(long long) * 8 * (size_t)c->nblk);
+  a.dbg = dbg;
+#endif
   prof_begin(c, 0);
   const dim3 gr(c->nblk), bl(CFDH_MAX_INC);
   const bool bf = c->bf_beta > 0.0 && c->bf_marker >= 0;
@@ -607,6 +647,21 @@ int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
 #undef CFDH_ASM_LAUNCH
   prof_end(c, 0);
   HIPCHK(c, hipGetLastError());
+#ifdef CFDH_ASM_TIMING
+  if (mode == 1 && (++dbg_calls % 20) == 0) {
+    std::vector<long long> h(8 * (size_t)c->nblk);
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(h.data(), dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+    double acc[5] = {0, 0, 0, 0, 0};
+    long long tmin = h[0], tmax = h[5];
+    for (int b = 0; b < c->nblk; b++) {
+      for (int k = 0; k < 5; k++) acc[k] += (double)(h[8 * (size_t)b + k + 1] - h[8 * (size_t)b + k]);
+      tmin = std::min(tmin, h[8 * (size_t)b]); tmax = std::max(tmax, h[8 * (size_t)b + 5]);
+    }
+    fprintf(stderr, "[asm timing] ticks per block: stage-issue %.0f, barrier %.0f, element %.0f, reduce %.0f, stores+drain %.0f; kernel span %lld ticks, %d blocks\n",
+            acc[0] / c->nblk, acc[1] / c->nblk, acc[2] / c->nblk, acc[3] / c->nblk, acc[4] / c->nblk, tmax - tmin, c->nblk);
+  }
+#endif
   if (mode == 1) c->jac_valid = true;
   return 0;
 }

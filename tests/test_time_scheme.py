@@ -279,7 +279,7 @@ def test_gpu_backflow_solver_class_on_stenosis_scenario():
     # the Scenario wraps constructor errors like the reference does (scenario.py:95-103)
     with pytest.raises(RuntimeError, match="ValueError: v_max is required"):
         StenosisSimulation("stabilized_schur_backflow", 0.01, 0.02, ny=8, L=12.0, x_sten=5.0, quiet=True)
-    kw = dict(ny=8, L=12.0, x_sten=5.0, v_max=100.0, quiet=True, beta_backflow=0.2,
+    kw = dict(grade="moderate", ny=8, L=12.0, x_sten=5.0, v_max=100.0, quiet=True, beta_backflow=0.2,
               options=dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10))
     sc = StenosisSimulation("stabilized_schur_backflow", 0.01, 0.035, **kw)
     assert sc.solver.bcp_d == []
