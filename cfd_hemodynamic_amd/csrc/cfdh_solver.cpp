@@ -703,6 +703,11 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
   bool force_refresh = (o.pc_refresh > 0 && c->steps_since_refresh >= o.pc_refresh);
   int reason = 0;
   double *x = c->x.p, *xt = c->xt.p, *d = c->dvec.p;
+  // The trial point of the line search is assembled with its Jacobian, because an accepted point that has not converged
+  // needs it next.  When the previous reduction predicts that the trial WILL meet the tolerance, only the residual is
+  // assembled there (mode 2: same residual bit for bit, no matrix written); a wrong prediction costs one more pass.
+  bool jac_current = true;
+  double fn_before = 0.0;
   for (int it = 0;; it++) {
     if (o.verbose) fprintf(stderr, "[cfdh]   newton %d |F| = %.6e\n", it, fn);
     if (!std::isfinite(fn)) { reason = CFDH_DIVERGED_FNORM_NAN; break; }
@@ -710,6 +715,14 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
     if (it > 0 && fn <= o.snes_rtol * st->fnorm0) { reason = CFDH_CONVERGED_FNORM_RELATIVE; break; }
     if (it >= o.snes_max_it) { reason = CFDH_DIVERGED_MAX_IT; break; }
     t0 = wall_ms();
+    if (!jac_current) {
+      CHK(k_assemble(c, x, 1));
+      jac_current = true;
+      st->ms_assemble += wall_ms() - t0;
+      t0 = wall_ms();
+    }
+    const bool expect_converged = it > 0 && fn_before > 0.0 && 10.0 * (fn / fn_before) * fn <= o.snes_rtol * st->fnorm0;
+    fn_before = fn;
     CHK(cfdh_pc_update(c, force_refresh || o.pc_refresh < 0));
     force_refresh = false;
     st->ms_pc_setup += wall_ms() - t0;
@@ -734,7 +747,7 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
     for (int ls = 0; ls < 40; ls++) {
       CHK(v_waxpy(c, n, -lam, d, x, xt));
       CHK(comm_halo(c, xt));
-      CHK(k_assemble(c, xt, 1));  // residual and Jacobian at the trial point in one pass
+      CHK(k_assemble(c, xt, expect_converged ? 2 : 1));  // residual (and Jacobian) at the trial point in one pass
       CHK(v_norm2(c, n, c->F.p, &fnew));
       if (std::isfinite(fnew) && (fnew * fnew <= fn * fn * (1.0 - 2.0e-4 * lam) || fnew < o.snes_atol)) { ok = true; break; }
       double l2 = std::isfinite(fnew) ? fn * fn * lam * lam / (2.0 * (0.5 * fnew * fnew - 0.5 * fn * fn + fn * fn * lam)) : 0.0;
@@ -749,6 +762,7 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
     if (o.verbose) fprintf(stderr, "[cfdh]     step length %.3e, |dx| = %.3e, |x| = %.3e, %d FGMRES iterations\n", lam, dn, xn, kits);
     std::swap(c->x.p, c->xt.p);
     x = c->x.p; xt = c->xt.p;
+    jac_current = !expect_converged;
     st->newton_its = it + 1;
     fn = fnew;
     if (lam * dn < o.snes_stol * xn && fn > o.snes_rtol * st->fnorm0 && fn >= o.snes_atol) {

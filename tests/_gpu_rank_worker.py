@@ -33,7 +33,8 @@ def main():
     case = os.environ.get("CFDH_TEST_CASE", "dfg")
     if case == "lid":       # singular pressure (no pressure condition)
         from cfd_hemodynamic_amd.scenarios.lid_driven2D import LidDriven2DSimulation
-        sc = LidDriven2DSimulation("stabilized_schur", 0.01, 0.035, nx=48, mu=0.01, quiet=True, device=0, comm=comm, options=tight)
+        sc = LidDriven2DSimulation("stabilized_schur", 0.01, 0.035, nx=48, mu=0.01, quiet=True, device=0, comm=comm, options=tight,
+                                   verbose=int(os.environ.get("CFDH_TEST_VERBOSE", "0")))
     elif case == "stenosis_c4":  # BASELINE config 4 at size: stenosis "moderate", reference geometry
         from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
         sc = StenosisSimulation("stabilized_schur", 0.01, float(os.environ.get("CFDH_TEST_T", "0.015")), grade="moderate",

@@ -170,14 +170,16 @@ def test_part_without_exterior_facets_takes_part_in_facet_functionals(tmp_path):
     fake = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
     if not os.path.exists(fake):
         subprocess.check_call(["make", "-C", os.path.join(HERE, "fake_rccl"), "-s"])
-    tight = dict(snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-9)
+    # singular system (no pressure condition): a Krylov target below ~1e-18 absolute cannot be met (round-off leaves a
+    # component of F outside the range of J), so the tolerances stay a decade above the other partition tests
+    tight = dict(snes_rtol=1e-10, snes_stol=0.0, ksp_rtol=1e-8)
     ref = LidDriven2DSimulation("stabilized_schur", 0.01, 0.035, nx=48, mu=0.01, quiet=True, options=tight)
     ref.solve(None)
     fd, fl = ref.solver.functional(0, 0), ref.solver.functional(1, 0)
     for backend, extra in (("host", {}), ("rccl", {"CFDH_RCCL_LIB": fake})):
         out = str(tmp_path / ("island_%s.npz" % backend))
         r = _run(2, out, timeout=300, CFDH_TEST_BACKEND=backend, CFDH_TEST_CASE="lid", CFDH_TEST_PARTITION="interior_island",
-                 CFDH_TEST_SNES_RTOL="1e-11", CFDH_TEST_KSP_RTOL="1e-9", **extra)
+                 CFDH_TEST_SNES_RTOL="1e-10", CFDH_TEST_KSP_RTOL="1e-8", **extra)
         assert int(np.load(out + ".nfac1.npy")[0]) == 0 and int(np.load(out + ".nfac0.npy")[0]) > 0
         assert abs(float(r["fd_all"]) - fd) <= 1e-7 * abs(fd) + 1e-12
         assert abs(float(r["fl_all"]) - fl) <= 1e-7 * abs(fl) + 1e-12

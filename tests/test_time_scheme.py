@@ -283,6 +283,7 @@ def test_gpu_backflow_solver_class_on_stenosis_scenario():
               options=dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10))
     sc = StenosisSimulation("stabilized_schur_backflow", 0.01, 0.035, **kw)
     assert sc.solver.bcp_d == []
+    u0 = np.array(sc.solver.u_prev.x.array, dtype=float)  # the flow-rate-conserving initial profile (stenosis.py:219-259)
     sc.solve(None, device_resident=True)
     assert sc.num_steps == 4
     case = stenosis_backflow_case(8, L=12.0, x_sten=5.0, beta=0.2)
@@ -290,8 +291,8 @@ def test_gpu_backflow_solver_class_on_stenosis_scenario():
     nv = case.nv
     o = orc.default_opts(pc_kind=1)
     o.snes_rtol, o.snes_stol, o.ksp_rtol = 1e-12, 0.0, 1e-12
-    x = np.zeros(3 * nv)
-    O.set_un(np.zeros(2 * nv))
+    x = np.concatenate([u0, np.zeros(nv)])
+    O.set_un(u0)
     for _ in range(4):
         x, _ = O.solve_step(x, o)
         O.set_un(x[: 2 * nv])
