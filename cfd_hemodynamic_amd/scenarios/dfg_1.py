@@ -39,7 +39,10 @@ class DFG1Benchmark(Scenario):
     @property
     def mesh(self):
         if not self._mesh:
-            if self.mesh_file:
+            if self.mesh_file and str(self.mesh_file).lower().endswith(".xdmf"):
+                from ..xdmf import read_xdmf  # dfg_1.py:43-48: read_mesh(name="Grid"), read_meshtags(name="Facet markers")
+                self._mesh, self._ft = read_xdmf(self.mesh_file, "Grid", "Facet markers")
+            elif self.mesh_file:
                 from ..meshio import read_msh
                 self._mesh, self._ft = read_msh(self.mesh_file)
             else:

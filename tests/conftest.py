@@ -23,3 +23,14 @@ def _built():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "cfd_hemodynamic_amd", "csrc"), "-s", "-j4"])
     assert os.path.exists(so), "libcfdh.so missing and hipcc not available"
     yield
+
+
+@pytest.fixture()
+def oracle_backend(monkeypatch):
+    """Registers the oracle-backed test double as the solver plugin "_oracle_double" (host-logic tests without a GPU)."""
+    import types
+    import oracle_solver
+    mod = types.ModuleType("cfd_hemodynamic_amd.solvers._oracle_double")
+    mod.Solver = oracle_solver.Solver
+    monkeypatch.setitem(sys.modules, "cfd_hemodynamic_amd.solvers._oracle_double", mod)
+    return "_oracle_double"

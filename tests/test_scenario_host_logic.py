@@ -12,14 +12,6 @@ from cfd_hemodynamic_amd.fem import Function, FunctionSpace
 from cfd_hemodynamic_amd.mesh import create_unit_square
 
 
-@pytest.fixture()
-def oracle_backend(monkeypatch):
-    mod = types.ModuleType("cfd_hemodynamic_amd.solvers._oracle_double")
-    mod.Solver = oracle_solver.Solver
-    monkeypatch.setitem(sys.modules, "cfd_hemodynamic_amd.solvers._oracle_double", mod)
-    return "_oracle_double"
-
-
 def test_function_interpolate_layout():
     m = create_unit_square(2)
     V = FunctionSpace(m, 2)
