@@ -43,12 +43,13 @@ class MicrovasculatureSimulation(Scenario):
     U_c = 0.01
 
     def __init__(self, solver_name, dt, T, f: tuple[float, float, float] = (0, 0, 0), v_inlet=1.5, p_outlet1=0, p_outlet2=0, *,
-                 rho=None, mu=None, res=4.0e-4, **solver_kwargs):
+                 rho=None, mu=None, res=4.0e-4, mesh_file=None, **solver_kwargs):
         self._mesh = None
         self._ft = None
         self._bcu = None
         self._bcp = None
         self.res = float(res)
+        self.mesh_file = mesh_file  # a gmsh .msh (the reference's meshes/simple_bifurcation.msh, :71-75) or an .xdmf pair
         self.Re = self.rho_real * self.U_c * self.L_c / self.mu_real
         p_c = self.rho_real * self.U_c ** 2
         self.v_inlet = float(v_inlet)
@@ -68,7 +69,14 @@ class MicrovasculatureSimulation(Scenario):
     @property
     def mesh(self):
         if self._mesh is None:
-            self._mesh, self._ft = create_bifurcation(self.res, r_in=self.r_mesh_in)
+            if self.mesh_file and str(self.mesh_file).lower().endswith(".xdmf"):
+                from ..xdmf import read_xdmf
+                self._mesh, self._ft = read_xdmf(self.mesh_file, "mesh", "mesh_tags")
+            elif self.mesh_file:
+                from ..meshio import read_msh
+                self._mesh, self._ft = read_msh(self.mesh_file)
+            else:
+                self._mesh, self._ft = create_bifurcation(self.res, r_in=self.r_mesh_in)
         return self._mesh
 
     @staticmethod

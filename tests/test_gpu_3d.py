@@ -136,3 +136,19 @@ def test_simple_bifurcation_scenario_through_the_plugin_surface(tmp_path):
     fine.solver.solveStep()
     f_i, f_1, f_2 = fine.flow_rates()
     assert abs((f_1 + f_2) / f_i - 1.0) < abs((q1 + q2) / qi - 1.0)
+
+
+def test_simple_bifurcation_from_a_gmsh_file(tmp_path):
+    """The reference's own route: `gmshio.read_from_msh("meshes/simple_bifurcation.msh", ..., gdim=3)`
+    (simple_bifurcation.py:71-75).  The same mesh through a .msh file gives the same step."""
+    from cfd_hemodynamic_amd.meshio import write_msh
+    from cfd_hemodynamic_amd.scenarios.simple_bifurcation import MicrovasculatureSimulation
+    a = MicrovasculatureSimulation("stabilized_schur", 0.01, 0.025, res=8e-4, quiet=True)
+    p = str(tmp_path / "simple_bifurcation.msh")
+    write_msh(p, a.mesh, a._ft, cell_tag=a.fluid_tag)
+    b = MicrovasculatureSimulation("stabilized_schur", 0.01, 0.025, mesh_file=p, quiet=True)
+    assert b.mesh.num_cells == a.mesh.num_cells and (b.mesh.cell_tags == a.fluid_tag).all()
+    a.solver.solveStep(); b.solver.solveStep()
+    ua, ub = np.asarray(a.solver.u_sol.x.array), np.asarray(b.solver.u_sol.x.array)
+    assert np.abs(ua - ub).max() <= 1e-9 * np.abs(ua).max()
+    assert abs(a.flow_rates()[1] - b.flow_rates()[1]) <= 1e-9 * abs(a.flow_rates()[1])

@@ -100,3 +100,65 @@ def test_gmsh_reader_v41_and_roundtrip(tmp_path):
     assert np.array_equal(m1.facet_marker, m0.facet_marker)
     for mk in (2, 3, 4, 5):
         assert np.array_equal(np.sort(ft1.find(mk)), np.sort(ft0.find(mk)))
+
+
+def test_gmsh_reader_tetrahedra_v22_roundtrip_and_v41(tmp_path):
+    """3-D `.msh` (gmshio.read_from_msh(..., gdim=3) of /root/reference/src/scenarios/simple_bifurcation.py:71-75):
+    tetrahedra (type 4) + physical triangles -> Mesh3D + facet markers; 2.2 round trip and a hand-written 4.1 file."""
+    from cfd_hemodynamic_amd.mesh3d import create_bifurcation
+    from cfd_hemodynamic_amd.meshio import read_msh, write_msh
+    mesh, ft = create_bifurcation(1.2e-3)
+    p = str(tmp_path / "simple_bifurcation.msh")
+    write_msh(p, mesh, ft, cell_tag=7)
+    m2, ft2 = read_msh(p)
+    assert m2.topology.dim == 3 and np.array_equal(m2.x, mesh.x) and m2.num_cells == mesh.num_cells
+    assert (m2.cell_tags == 7).all()
+    for tag in (8, 9, 10, 11):
+        a = {tuple(sorted(v)) for v in mesh.facet_vertices[ft.find(tag)]}
+        b = {tuple(sorted(v)) for v in m2.facet_vertices[ft2.find(tag)]}
+        assert a == b and len(a) > 0
+    # format 4.1: one tetrahedron, volume 1 in physical group 7, its four faces on surfaces 1..4 (physical 8, 9, 10, 11)
+    q = str(tmp_path / "tet41.msh")
+    with open(q, "w") as f:
+        f.write("""$MeshFormat
+4.1 0 8
+$EndMeshFormat
+$Entities
+0 0 4 1
+1 0 0 0 1 1 0 1 8 0
+2 0 0 0 1 1 1 1 9 0
+3 0 0 0 1 1 1 1 10 0
+4 0 0 0 1 1 1 1 11 0
+1 0 0 0 1 1 1 1 7 0
+$EndEntities
+$Nodes
+1 4 1 4
+3 1 0 4
+1
+2
+3
+4
+0 0 0
+1 0 0
+0 1 0
+0 0 1
+$EndNodes
+$Elements
+5 5 1 5
+2 1 2 1
+1 1 2 3
+2 2 2 1
+2 1 2 4
+2 3 2 1
+3 1 3 4
+2 4 2 1
+4 2 3 4
+3 1 4 1
+5 1 2 3 4
+$EndElements
+""")
+    m3, ft3 = read_msh(q)
+    assert m3.num_cells == 1 and m3.num_vertices == 4 and m3.num_facets == 4 and (m3.cell_tags == 7).all()
+    assert {tuple(sorted(v)) for v in m3.facet_vertices[ft3.find(8)]} == {(0, 1, 2)}
+    assert {tuple(sorted(v)) for v in m3.facet_vertices[ft3.find(11)]} == {(1, 2, 3)}
+    assert abs(m3.cell_volumes()[0] - 1.0 / 6.0) < 1e-15
