@@ -152,3 +152,28 @@ def test_simple_bifurcation_from_a_gmsh_file(tmp_path):
     ua, ub = np.asarray(a.solver.u_sol.x.array), np.asarray(b.solver.u_sol.x.array)
     assert np.abs(ua - ub).max() <= 1e-9 * np.abs(ua).max()
     assert abs(a.flow_rates()[1] - b.flow_rates()[1]) <= 1e-9 * abs(a.flow_rates()[1])
+
+
+@pytest.mark.parametrize("res", [4e-4, 2e-4])
+def test_tet_assembly_matches_twin_on_the_bifurcation_at_size(res):
+    """Workgroup packing at size: res 4e-4 = 138 264 DOF (174 984 tetrahedra), res 2e-4 = 1 025 036 DOF (the c5b bench mesh,
+    1.47 M tetrahedra, 62 M scalar CSR values); boundary data of the scenario, state off the Dirichlet values: residual, every
+    CSR value and the SpMV against the NumPy twin."""
+    mesh, ft = create_bifurcation(res)
+    nv = mesh.num_vertices
+    pb, ctx = _pair(mesh, 0.01, 1.0, 0.013, (0.0, 0.0, 0.0), _bifurcation_bcs(mesh, ft))
+    rng = np.random.default_rng(11)
+    xv = 0.3 * rng.standard_normal(4 * nv)
+    un = 0.3 * rng.standard_normal((nv, 3))
+    F, J = pb.assemble(xv, un)
+    ctx.set_state(u_prev=un.ravel(), p_prev=np.zeros(nv), u=xv[: 3 * nv], p=xv[3 * nv:])
+    ctx.assemble(True)
+    Fg = np.concatenate(ctx.get_residual())
+    assert np.abs(F - Fg).max() <= 1e-12 * np.abs(F).max()
+    Jg = ctx.get_csr()
+    assert Jg.nnz == 16 * ctx.info(3) and abs(J - Jg).max() <= 1e-12 * abs(J).max()
+    v = rng.standard_normal(4 * nv)
+    assert np.abs(ctx.spmv(v) - J @ v).max() <= 1e-12 * np.abs(J @ v).max()
+    ctx.assemble(False)
+    assert np.abs(np.concatenate(ctx.get_residual()) - Fg).max() <= 1e-12 * np.abs(Fg).max()
+    ctx.close()
