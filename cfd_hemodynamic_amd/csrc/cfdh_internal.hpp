@@ -179,6 +179,7 @@ struct cfdh_ctx {
 
   // incidences (row vertex, cell), grouped in workgroup blocks of whole rows
   int ninc = 0, nblk = 0;
+  bool gs_refine_long = false;  // FGMRES: a long cycle lost orthogonality on this context once (cfdh_solver.cpp)
   dbuf<unsigned> inc_slot;   // per lane: slot0 | slot1<<8 | slot2<<16 | a<<24 | emit_v2<<26 | has_prev<<27
   dbuf<unsigned> inc_rank;   // per lane: position in row | row length<<8 | (lane offset of the fan predecessor + 64)<<16
   dbuf<int> blk_row;         // [nblk+1]

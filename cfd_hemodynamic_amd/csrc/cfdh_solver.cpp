@@ -555,6 +555,8 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
   const double tol = std::max(o.ksp_rtol * bn, o.ksp_atol);
   double *V = c->kV.p, *Z = c->kZ.p, *w = c->kw.p, *hd = c->kh.p;
   bool first = true;
+  double est_prev = 0.0, beta_start = bn;  // residual estimate at the end / true residual at the start of the last cycle
+  int j_prev = 0;
   for (;;) {
     double beta;
     if (first) {
@@ -564,6 +566,23 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       CHK(k_spmv_full(c, x, w));
       CHK(v_waxpy(c, n, -1.0, w, b, V));
       CHK(v_norm2(c, n, V, &beta));
+      // Orthogonality watchdog.  Unrefined classical Gram-Schmidt (PETSc's default) can lose the basis in a long cycle:
+      // the recurrence then reports convergence while the true residual, formed here after every cycle anyway, does not
+      // follow.  Once that is seen on a context, long cycles are re-orthogonalised (DGKS) from then on, and a cycle that
+      // made the residual worse is taken back.
+      if (!c->gs_refine_long && beta > 10.0 * std::max(est_prev, tol)) {
+        c->gs_refine_long = true;
+        if (o.verbose) fprintf(stderr, "[cfdh]     fgmres: true residual %.3e vs recurrence %.3e after a %d-vector cycle: re-orthogonalising long cycles from now on\n", beta, est_prev, j_prev);
+        if (beta > beta_start && j_prev > 0) {
+          for (int i = 0; i < j_prev; i++) y[i] = -y[i];
+          HIPCHK(c, hipMemcpyAsync(c->ky.p, y.data(), sizeof(double) * j_prev, hipMemcpyHostToDevice, c->stream));
+          CHK(v_lincomb(c, n, Z, (int)ld, j_prev, c->ky.p, x));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          est_prev = beta_start;  // do not trip again on the restored iterate
+          continue;
+        }
+      }
+      beta_start = beta;
     }
     if (beta <= tol) { reason = 2; break; }
     if (its >= o.ksp_max_it) { reason = -3; break; }
@@ -599,10 +618,13 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       // PETSc's default never refines.  Here: tolerances down to ~1e-7 refine only when two digits
       // cancel; tighter solves (parity runs at 1e-10) use the DGKS criterion (|w'| < |w|/sqrt(2)),
       // because classical Gram-Schmidt then loses the orthogonality the deep convergence needs
-      // ... and so does a long Krylov cycle: beyond ~two dozen vectors the unrefined basis drifts far enough from
+      // ... and so can a long Krylov cycle: beyond ~two dozen vectors the unrefined basis may drift far enough from
       // orthogonality that the least-squares solution picks up huge spurious components (Newton corrections ten times
-      // the size of the iterate on the tree domain, config 5) although the residual norm looks converged
-      static const int refine_from = getenv("CFDH_GS_REFINE_FROM") ? atoi(getenv("CFDH_GS_REFINE_FROM")) : 24;
+      // the size of the iterate on the tree domain, config 5) although the residual norm looks converged.  Paying the
+      // second pass on every long cycle costs 14 % of a 3-D step whose 47-vector cycles never need it, so it is switched
+      // on by the watchdog above (CFDH_GS_REFINE_FROM=<j> forces it from vector j on)
+      static const int refine_env = getenv("CFDH_GS_REFINE_FROM") ? atoi(getenv("CFDH_GS_REFINE_FROM")) : -1;
+      const int refine_from = refine_env >= 0 ? refine_env : (c->gs_refine_long ? 24 : (1 << 30));
       const double eta2 = (o.ksp_rtol < 1e-7 || j >= refine_from) ? 0.5 : 1e-2;
       bool refine = !(nrm2 > eta2 * ww);
       double hnorm;
@@ -648,6 +670,8 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
     HIPCHK(c, hipMemcpyAsync(c->ky.p, y.data(), sizeof(double) * j, hipMemcpyHostToDevice, c->stream));
     CHK(v_lincomb(c, n, Z, (int)ld, j, c->ky.p, x));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // y is a host temporary
+    est_prev = std::fabs(g[j]);
+    j_prev = j;
     (void)done;
   }
   c->n_krylov += its;
