@@ -81,7 +81,7 @@ struct CsrDev {
   // SELL-64 copy (sliced ELLPACK, slices of 64 consecutive rows, column-major inside a slice):
   // one lane per row streams fully coalesced, no cross-lane reduction.  sptr[s] = first padded
   // entry of slice s (in units of entries); width of slice s = (sptr[s+1]-sptr[s]) / 64.
-  int nslice = 0;
+  int nslice = 0, sell_maxw = 0;  // widest slice (entries per row)
   dbuf<int> sptr, scol;
   // SELL values are kept in fp32: they feed preconditioner sweeps only (FGMRES is flexible and measures the
   // true fp64 residual), and the matrix stream is 60 % of a fine-level sweep's traffic
@@ -105,7 +105,8 @@ struct AmgLevel {
   CsrDev G, Sb, Sc;
   dbuf<float> D;
   int Dn = 0;        // columns of D (= size of the coarsest level); 0: not folded
-  bool fine = false; // SELL / fp32 formats are in use on this level (short regular rows)
+  bool fine = false; // short regular rows: fp32 values in G (down-sweep)
+  bool sell = false; // ... and SELL-64 / fp32 for Sb, Sc (up-sweep); not for three right-hand sides on tetrahedra (measured slower)
 };
 
 // One smoothed-aggregation hierarchy.  ncol = 2 applies the same scalar operators to two

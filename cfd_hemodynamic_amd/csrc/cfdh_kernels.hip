@@ -1432,8 +1432,8 @@ __global__ __launch_bounds__(TPB) void fused_up_csr_kernel(int n, const int *__r
   a = g8(a);
   if (row < n && l == 0) x[row] = epbc ? epi_apply(a, row, ea, eb, ezH, er, epbc) : a;
 }
-// the same on SELL-64 (fp32 values), one lane per row
-template <typename T>
+// the same on SELL-64 (fp32 values), one lane per row.  WIDE: rows longer than one chunk of preloaded entries (tetrahedra)
+template <typename T, bool WIDE>
 __global__ __launch_bounds__(TPB) void fused_up_sell_kernel(int n, const int *__restrict__ spB, const int *__restrict__ scB,
                                                             const float *__restrict__ svB, const T *__restrict__ b,
                                                             const int *__restrict__ spC, const int *__restrict__ scC,
@@ -1448,29 +1448,35 @@ __global__ __launch_bounds__(TPB) void fused_up_sell_kernel(int n, const int *__
   double e_zh = 0.0, e_r = 0.0;
   unsigned e_f = 0;
   if (epbc) { e_f = epbc[row]; e_zh = ezH[row]; e_r = er[row]; }
-  // both matrices together: slice pointers, then ALL column/value loads of the row, then ALL gathers (three
-  // dependent round trips; the straightforward loops make about ten)
+  // both matrices together: slice pointers, then ALL column/value loads of a chunk of the row, then ALL its gathers (three
+  // dependent round trips; the straightforward loops make about ten).  Triangle meshes need one chunk (rows of <= 10
+  // entries), the 15- to 25-entry rows of tetrahedral meshes two or three.
   constexpr int MW = sizeof(T) > 8 ? 8 : 10;
   const int pB = spB[sl], wB = (spB[sl + 1] - pB) >> 6;
   int pC = 0, wC = 0;
   if (spC) { pC = spC[sl]; wC = (spC[sl + 1] - pC) >> 6; }
-  int cB[MW], cC[MW];
-  float vB[MW], vC[MW];
+  const int wmax = wB > wC ? wB : wC;
+  for (int k0 = 0; k0 < (WIDE ? wmax : 1); k0 += MW) {
+    int cB[MW], cC[MW];
+    float vB[MW], vC[MW];
 #pragma unroll
-  for (int k = 0; k < MW; k++) if (k < wB) { const int p = pB + k * 64 + lane; cB[k] = NTLOAD(scB + p); vB[k] = NTLOAD(svB + p); }
+    for (int k = 0; k < MW; k++) if (k0 + k < wB) { const int p = pB + (k0 + k) * 64 + lane; cB[k] = NTLOAD(scB + p); vB[k] = NTLOAD(svB + p); }
 #pragma unroll
-  for (int k = 0; k < MW; k++) if (k < wC) { const int p = pC + k * 64 + lane; cC[k] = NTLOAD(scC + p); vC[k] = NTLOAD(svC + p); }
-  T gB[MW], gC[MW];
+    for (int k = 0; k < MW; k++) if (k0 + k < wC) { const int p = pC + (k0 + k) * 64 + lane; cC[k] = NTLOAD(scC + p); vC[k] = NTLOAD(svC + p); }
+    T gB[MW], gC[MW];
 #pragma unroll
-  for (int k = 0; k < MW; k++) if (k < wB) gB[k] = b[cB[k]];
+    for (int k = 0; k < MW; k++) if (k0 + k < wB) gB[k] = b[cB[k]];
 #pragma unroll
-  for (int k = 0; k < MW; k++) if (k < wC) gC[k] = xc[cC[k]];
+    for (int k = 0; k < MW; k++) if (k0 + k < wC) gC[k] = xc[cC[k]];
 #pragma unroll
-  for (int k = 0; k < MW; k++) if (k < wB) a = vfma((double)vB[k], gB[k], a);
+    for (int k = 0; k < MW; k++) if (k0 + k < wB) a = vfma((double)vB[k], gB[k], a);
 #pragma unroll
-  for (int k = 0; k < MW; k++) if (k < wC) a = vfma((double)vC[k], gC[k], a);
-  for (int k = MW; k < wB; k++) { const int p = pB + k * 64 + lane; a = vfma((double)svB[p], b[scB[p]], a); }
-  for (int k = MW; k < wC; k++) { const int p = pC + k * 64 + lane; a = vfma((double)svC[p], xc[scC[p]], a); }
+    for (int k = 0; k < MW; k++) if (k0 + k < wC) a = vfma((double)vC[k], gC[k], a);
+  }
+  if (!WIDE) {  // rows beyond the chunk (none on triangle meshes)
+    for (int k = MW; k < wB; k++) { const int p = pB + k * 64 + lane; a = vfma((double)svB[p], b[scB[p]], a); }
+    for (int k = MW; k < wC; k++) { const int p = pC + k * 64 + lane; a = vfma((double)svC[p], xc[scC[p]], a); }
+  }
   x[row] = epbc ? epi_value(a, e_f, ea, eb, e_zh, e_r) : a;
 }
 // x = Sb b + D bc with the dense folded coarse correction D [n][nc] (fp32), one wave per row
@@ -1533,8 +1539,8 @@ static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof) 
     } else {
       if (H.coarse_n > 0)
         hipLaunchKernelGGL((dense_mv_kernel<T>), dim3(H.coarse_n), dim3(64), 0, c->stream, H.coarse_n, H.coarse_inv.p, bl, xl);
-      else if (L->fine)
-        hipLaunchKernelGGL((fused_up_sell_kernel<T>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
+      else if (L->sell)
+        hipLaunchKernelGGL((fused_up_sell_kernel<T, true>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
                            L->Sb.sptr.p, L->Sb.scol.p, L->Sb.sval.p, bl, (const int *)nullptr, (const int *)nullptr,
                            (const float *)nullptr, (const T *)nullptr, xl, 0.0, 0.0, (const double *)nullptr, (const double *)nullptr,
                            (const unsigned char *)nullptr);
@@ -1558,8 +1564,12 @@ static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof) 
     const unsigned char *epbc = epi ? c->epi.pbc : nullptr;
     if (epi) { xl = (T *)c->epi.out; c->epi.done = true; }
     if (prof && l == 0) prof_begin(c, prof);
-    if (L->fine)
-      hipLaunchKernelGGL((fused_up_sell_kernel<T>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
+    if (L->sell && L->Sb.sell_maxw <= (sizeof(T) > 8 ? 8 : 10) && L->Sc.sell_maxw <= (sizeof(T) > 8 ? 8 : 10))
+      hipLaunchKernelGGL((fused_up_sell_kernel<T, false>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
+                         L->Sb.sptr.p, L->Sb.scol.p, L->Sb.sval.p, bl, L->Sc.sptr.p, L->Sc.scol.p, L->Sc.sval.p, (const T *)N->x.p, xl,
+                         ea, eb, ezH, er, epbc);
+    else if (L->sell)
+      hipLaunchKernelGGL((fused_up_sell_kernel<T, true>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
                          L->Sb.sptr.p, L->Sb.scol.p, L->Sb.sval.p, bl, L->Sc.sptr.p, L->Sc.scol.p, L->Sc.sval.p, (const T *)N->x.p, xl,
                          ea, eb, ezH, er, epbc);
     else

@@ -496,10 +496,12 @@ static int upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vecto
   // SELL-64
   const int ns = (H.n + 63) / 64;
   std::vector<int> sptr(ns + 1, 0);
+  D.sell_maxw = 0;
   for (int sl = 0; sl < ns; sl++) {
     int w = 0;
     for (int r = sl * 64; r < std::min(H.n, sl * 64 + 64); r++) w = std::max(w, H.rowptr[r + 1] - H.rowptr[r]);
     sptr[sl + 1] = sptr[sl] + 64 * w;
+    D.sell_maxw = std::max(D.sell_maxw, w);
   }
   std::vector<int> scol((size_t)sptr[ns], 0);
   std::vector<float> sval((size_t)sptr[ns], 0.0f), svalw;
@@ -621,7 +623,9 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
     std::vector<double> w;  // Jacobi weights of this level
     CHK(cfdh_level_setup(c, *L, A, o.amg_smooth_ratio, ncol, &w));
     if (keep0) { H.h_wdinv0 = w; H.h_A0 = A; }
-    L->fine = A.nnz() <= 12ll * A.n && A.n >= 16384;
+    // short regular rows (finest level of a P1 operator: ~7 entries on triangles, ~15 on tetrahedra): SELL-64 / fp32 kernels
+    L->fine = A.nnz() <= 20ll * A.n && A.n >= 16384;
+    L->sell = L->fine && (A.nnz() <= 12ll * A.n || ncol == 1);
     prevW.swap(curW); curW = w;
     const double lm = L->lmax / 1.1;
     if (A.n <= o.amg_max_coarse || (int)H.lev.size() >= maxlev) break;
@@ -687,8 +691,8 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
       spgemm_host(RA, P, Ac);
       const int fmt = L->fine ? CFDH_UP_CSRF : CFDH_UP_CSR;
       CHK(upload_csr(c, G, L->G, nullptr, fmt));
-      CHK(upload_csr(c, Sb, L->Sb, nullptr, L->fine ? CFDH_UP_SELL : CFDH_UP_CSR));
-      CHK(upload_csr(c, Sc, L->Sc, nullptr, L->fine ? CFDH_UP_SELL : CFDH_UP_CSR));
+      CHK(upload_csr(c, Sb, L->Sb, nullptr, L->sell ? CFDH_UP_SELL : CFDH_UP_CSR));
+      CHK(upload_csr(c, Sc, L->Sc, nullptr, L->sell ? CFDH_UP_SELL : CFDH_UP_CSR));
       if (H.lev.size() == 1) { H.nnz_G0 = G.nnz(); H.nnz_S0 = (long long)Sb.nnz() + Sc.nnz(); }
       lastSc.n = Sc.n; lastSc.m = Sc.m; lastSc.rowptr.swap(Sc.rowptr); lastSc.col.swap(Sc.col); lastSc.val.swap(Sc.val);
     } else {
@@ -712,7 +716,7 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
       for (int i = 0; i < A.n; i++) { Dg.rowptr[i] = i; Dg.col[i] = i; Dg.val[i] = 2.0 * curW[i]; }
       Dg.rowptr[A.n] = A.n;
       csr_axpby_scaled(A, -1.0, curW.data(), curW.data(), Dg, Sb);
-      CHK(upload_csr(c, Sb, L->Sb, nullptr, L->fine ? CFDH_UP_SELL : CFDH_UP_CSR));
+      CHK(upload_csr(c, Sb, L->Sb, nullptr, L->sell ? CFDH_UP_SELL : CFDH_UP_CSR));
       H.fused = H.lev.size() >= 1;
     }
     H.valid = true;
@@ -746,7 +750,7 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
       AmgLevel *U = H.lev[H.lev.size() - 2];
       const long long ent = (long long)lastSc.n * n;
       U->Dn = 0;
-      if (lastSc.m == n && ent <= 8000000ll && !U->fine) {
+      if (lastSc.m == n && ent <= 8000000ll && !U->sell) {
         std::vector<float> Df((size_t)ent);
 #pragma omp parallel for schedule(static) num_threads(cfdh_host_threads())
         for (int i = 0; i < lastSc.n; i++) {
