@@ -484,6 +484,7 @@ __global__ __launch_bounds__(TPB) void spmv3_full_kernel(int nv, const int *__re
   const int row = gid >> 3, l = gid & 7;
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
   if (row < nv) {
+    // (requesting the two blocks of a lane together -- 60 doubles in flight -- was measured: 159 us instead of 107)
     for (int k = vptr[row] + l, ke = vptr[row + 1]; k < ke; k += 8) {
       const int w = vcol[k];
       const double x0 = x[3 * (size_t)w], x1 = x[3 * (size_t)w + 1], x2 = x[3 * (size_t)w + 2], xp = x[3 * (size_t)nv + w];
@@ -540,9 +541,51 @@ __global__ __launch_bounds__(TPB) void spmv3_blk_kernel(int nv, const int *__res
     }
   }
 }
+// y_u = b_u - A01 x_p, once per FGMRES iteration: four lanes per row, the first four entries of every lane requested
+// together (the 8-lane loop above moves 24 B of matrix per load round: 27.9 us at 1 M DOF; this form: see DESIGN.md)
+__global__ __launch_bounds__(TPB) void spmv3_a01_resid_kernel(int nv, const int *__restrict__ vptr, const int *__restrict__ vcol,
+                                                              const double *__restrict__ A, const double *__restrict__ x,
+                                                              double *__restrict__ y, const double *__restrict__ bvec) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 2, l = gid & 3;
+  double a0 = 0, a1 = 0, a2 = 0;
+  if (row < nv) {
+    const int ks = vptr[row], ke = vptr[row + 1];
+    int kq[4], wq[4];
+    double cq[4][3], xq[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int k = ks + l + 4 * q; kq[q] = k < ke ? k : ks; wq[q] = vcol[kq[q]]; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double *cc = A + 3 * (size_t)kq[q];
+      cq[q][0] = cc[0]; cq[q][1] = cc[1]; cq[q][2] = cc[2];
+      xq[q] = x[wq[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double xp = (ks + l + 4 * q < ke) ? xq[q] : 0.0;
+      a0 += cq[q][0] * xp; a1 += cq[q][1] * xp; a2 += cq[q][2] * xp;
+    }
+    for (int k = ks + l + 16; k < ke; k += 4) {
+      const double xp = x[vcol[k]];
+      const double *cc = A + 3 * (size_t)k;
+      a0 += cc[0] * xp; a1 += cc[1] * xp; a2 += cc[2] * xp;
+    }
+  }
+  a0 += dpp3<0xB1>(a0); a0 += dpp3<0x4E>(a0);
+  a1 += dpp3<0xB1>(a1); a1 += dpp3<0x4E>(a1);
+  a2 += dpp3<0xB1>(a2); a2 += dpp3<0x4E>(a2);
+  if (row < nv && l == 0) {
+    const size_t o = 3 * (size_t)row;
+    y[o] = bvec[o] - a0; y[o + 1] = bvec[o + 1] - a1; y[o + 2] = bvec[o + 2] - a2;
+  }
+}
 int k3_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b) {
   dim3 grid((unsigned)((8ll * c->nvo + TPB - 1) / TPB)), block(TPB);
-  if (blk == 2) hipLaunchKernelGGL((spmv3_blk_kernel<2>), grid, block, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A01.p, x, y, b);
+  if (blk == 2 && b)
+    hipLaunchKernelGGL(spmv3_a01_resid_kernel, dim3((unsigned)((4ll * c->nvo + TPB - 1) / TPB)), block, 0, c->stream, c->nvo, c->vptr.p,
+                       c->vcol.p, c->A01.p, x, y, b);
+  else if (blk == 2) hipLaunchKernelGGL((spmv3_blk_kernel<2>), grid, block, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A01.p, x, y, b);
   else if (blk == 3) hipLaunchKernelGGL((spmv3_blk_kernel<3>), grid, block, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A10.p, x, y, b);
   else return cfdh_fail(c, CFDH_E_ARG, "k3_spmv_block: block %d not available for tetrahedra", blk);
   HIPCHK(c, hipGetLastError());

@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(TPB) void sell_cheb2_scale_kernel(int n, const int 
 // x = Cheb2(H) b and y = ml .* x; false when the level does not qualify (the caller takes the generic path)
 bool k_cc_cheb2_scale(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, const double *ml, double *y) {
   const int n = L->n;
-  if (!(L->A.nnz <= 12ll * n && n >= 16384)) return false;
+  if (!(L->A.nnz <= 20ll * n && n >= 16384)) return false;  // rows of up to ~15 entries (tetrahedra): 10 preloaded + tail
   const double theta = 0.5 * (L->lmax + L->lmin), delta = 0.5 * (L->lmax - L->lmin), sigma = theta / delta;
   const double rho = 1.0 / sigma, rho_new = 1.0 / (2.0 * sigma - rho);
   const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
