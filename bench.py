@@ -186,7 +186,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # gloo carries only the bootstrap (RCCL unique id) and the timing reduction;
         # halo exchange and Krylov all-reduces run on RCCL inside libcfdh.so
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its mesh on the C-level stdout ("[Gloo] Rank 0 is connected to ..."): keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libcfdh.so has no CPU fallback")
     if os.environ.get("CFDH_SHARE_GPU") == "1":
