@@ -15,12 +15,20 @@ import sys
 NAMES = {
     "cheb_a00_step_kernel": "cheb_step_A00",
     "spmv_full_kernel": "spmv_full_block3x3",
+    "spmv3_full_kernel": "spmv3_full_block4x4",
     "asm_kernel<1": "asm_residual_jacobian",
+    "asm_kernel<2": "asm_residual_only",
+    "asm3q_kernel<1": "asm3_residual_jacobian",
     "moments_kernel": "tau_moments",
-    "sell_jacobi_pre_kernel<HIP_vector_type<double, 2": "amg_sweep_velocity_2rhs",
-    "sell_jacobi_post_kernel<HIP_vector_type<double, 2": "amg_sweep_velocity_2rhs",
-    "sell_jacobi_pre_kernel<double>": "amg_sweep_pressure",
-    "sell_jacobi_post_kernel<double>": "amg_sweep_pressure",
+    "moments3_kernel": "tau_moments_tet",
+    "spmv_a01_resid_kernel": "coupling_product_A01",
+    "fused_up_sell_kernel<HIP_vector_type<double, 2": "amg_up0_velocity_2rhs",
+    "fused_up_sell_kernel<double": "amg_up0_pressure",
+    "fused_down_kernel<16, float, HIP_vector_type<double, 2": "amg_down0_velocity_2rhs",
+    "fused_down_kernel<16, float, double": "amg_down0_pressure",
+    "sell_cheb2_scale_kernel": "cheb2_scale_H",
+    "multidot_kernel": "multidot",
+    "gs_update_normalize_kernel": "gs_update_normalize",
 }
 
 
