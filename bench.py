@@ -117,8 +117,8 @@ def workload_text(args, sc):
             "c4": "stenosis grade moderate (L=138, R_in=1.57, R_out=1.2, x_sten=30, severity .5, slope .3), ny=%d, inlet v_max=%g mm/s, p=0 outlet" % (args.ny, args.v_max),
             "c5": "stenosis_with_tree grade moderate (L=0.03, H=0.003, severity .5, slope .5; 3-generation Murray tree, 8 outlets p=0), "
                   "res=%g, pulsatile inlet v_max (1 + 0.5 sin 2 pi t) with a (1 - cos(pi t / %g)) / 2 start-up ramp, v_max=%g" % (args.res, args.ramp, args.v_max),
-            "c5b": "simple_bifurcation (3-D, tetrahedra; Re=%.1f, inlet u_y = %g (1 - (r/r_in)^2), p = 0 at both outlets; remove_p_mean=0), voxel-tet mesh res=%g" % (
-                getattr(sc, "Re", 0.0), args.v_max, args.res3)}[args.config]
+            "c5b": "simple_bifurcation (3-D, tetrahedra; Re=%s, inlet u_y = %g (1 - (r/r_in)^2), p = 0 at both outlets; remove_p_mean=0), voxel-tet mesh res=%g" % (
+                ("%.1f" % sc.Re) if args.config == "c5b" else "-", args.v_max, args.res3)}[args.config]
     return "%s: %d vertices, %d P1/P1 DOF, dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)" % (
         head, nv, (sc.mesh.geometry.dim + 1) * nv, args.dt)
 
