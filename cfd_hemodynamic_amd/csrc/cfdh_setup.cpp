@@ -4,6 +4,7 @@
 // the smoothed-aggregation hierarchy for the SELFP Schur matrix
 // Sp = A11 - A10 diag(A00)^-1 A01 (stabilized_schur.py:235).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -604,7 +605,15 @@ int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, i
   return 0;
 }
 
+static double setup_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
 int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, int ncol) {
+  double tm[6] = {0, 0, 0, 0, 0, 0};  // level set-up (+uploads), aggregation, prolongator, Galerkin/composite products, uploads, dense
+  double tq = setup_ms();
+#define TICK(i) do { const double now_ = setup_ms(); tm[i] += now_ - tq; tq = now_; } while (0)
   H.clear();
   H.ncol = ncol;
   const cfdh_options &o = c->opt;
@@ -621,7 +630,9 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
     H.lev.push_back(L);
     const bool keep0 = H.keep_host0 && H.lev.size() == 1;
     std::vector<double> w;  // Jacobi weights of this level
+    tq = setup_ms();
     CHK(cfdh_level_setup(c, *L, A, o.amg_smooth_ratio, ncol, &w));
+    TICK(0);
     if (keep0) { H.h_wdinv0 = w; H.h_A0 = A; }
     // short regular rows (finest level of a P1 operator: ~7 entries on triangles, ~15 on tetrahedra): SELL-64 / fp32 kernels
     L->fine = A.nnz() <= 20ll * A.n && A.n >= 16384;
@@ -634,6 +645,7 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
     // aggregates fall apart (3-D bifurcation, 1.0 M DOF: 216 instead of 92 FGMRES iterations per step)
     const double theta = o.amg_theta >= 0 ? o.amg_theta : (c->dim == 3 ? 0.02 : 0.08);
     int na = aggregate_host(A, theta, agg);
+    TICK(1);
     if (na >= A.n || na < 1) break;  // no coarsening possible
     std::vector<double> dinv(A.n, 1.0);
     for (int i = 0; i < A.n; i++)
@@ -672,12 +684,15 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
       }
       if (!placed) { P.col[p] = agg[i]; P.val[p] = 1.0; p++; }
     }
+    TICK(2);
     CsrHost R, AP, Ac;
     transpose_host(P, R);
     spgemm_host(A, P, AP);
+    TICK(3);
     CHK(upload_csr(c, P, L->P));
     if (H.keep_host0 && H.lev.size() == 1) H.h_P0 = P;
     CHK(upload_csr(c, R, L->R));
+    TICK(4);
     if (want_fused) {
       // G = R - (R A) W ; Sb = 2W - W A W ; Sc = P - W (A P) ; A_c = (R A) P
       CsrHost RA, G, Sb, Sc, Dg;
@@ -689,14 +704,17 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
       csr_axpby_scaled(A, -1.0, curW.data(), curW.data(), Dg, Sb);
       csr_axpby_scaled(AP, -1.0, curW.data(), nullptr, P, Sc);
       spgemm_host(RA, P, Ac);
+      TICK(3);
       const int fmt = L->fine ? CFDH_UP_CSRF : CFDH_UP_CSR;
       CHK(upload_csr(c, G, L->G, nullptr, fmt));
       CHK(upload_csr(c, Sb, L->Sb, nullptr, L->sell ? CFDH_UP_SELL : CFDH_UP_CSR));
       CHK(upload_csr(c, Sc, L->Sc, nullptr, L->sell ? CFDH_UP_SELL : CFDH_UP_CSR));
       if (H.lev.size() == 1) { H.nnz_G0 = G.nnz(); H.nnz_S0 = (long long)Sb.nnz() + Sc.nnz(); }
+      TICK(4);
       lastSc.n = Sc.n; lastSc.m = Sc.m; lastSc.rowptr.swap(Sc.rowptr); lastSc.col.swap(Sc.col); lastSc.val.swap(Sc.val);
     } else {
       spgemm_host(R, AP, Ac);
+      TICK(3);
     }
     A.n = Ac.n; A.m = Ac.m;
     A.rowptr.swap(Ac.rowptr); A.col.swap(Ac.col); A.val.swap(Ac.val);
@@ -774,7 +792,10 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
   if (c->opt.verbose) {
     fprintf(stderr, "[cfdh] AMG hierarchy (ncol %d%s):", ncol, H.fused ? ", fused" : "");
     for (AmgLevel *l : H.lev) fprintf(stderr, " (%d, nnz %d; G %d Sb %d Sc %d D %d)", l->n, l->A.nnz, l->G.nnz, l->Sb.nnz, l->Sc.nnz, l->Dn);
-    fprintf(stderr, "\n");
+    TICK(5);
+    fprintf(stderr, "\n[cfdh]   host set-up ms: levels %.0f, aggregation %.0f, prolongator %.0f, products %.0f, uploads %.0f, dense %.0f\n", tm[0], tm[1],
+            tm[2], tm[3], tm[4], tm[5]);
   }
+#undef TICK
   return 0;
 }
