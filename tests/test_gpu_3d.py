@@ -177,3 +177,33 @@ def test_tet_assembly_matches_twin_on_the_bifurcation_at_size(res):
     ctx.assemble(False)
     assert np.abs(np.concatenate(ctx.get_residual()) - Fg).max() <= 1e-12 * np.abs(Fg).max()
     ctx.close()
+
+
+def test_bdf2_plugin_on_tetrahedra_matches_twin():
+    """`--solver stabilized_schur_bdf2` on the 3-D scenario: BDF1 first step, BDF2 afterwards (stabilized_schur_bdf2.py:
+    79-110,298-325), u_prev2 shifted on the device; three steps in lockstep with the twin (theta = 1 and the a0/a1/a2 of
+    each step, direct solves)."""
+    from cfd_hemodynamic_amd.scenarios.simple_bifurcation import MicrovasculatureSimulation
+    # remove_p_mean 0: with the mean removal the Newton tolerance is relative to the outlet-row misfit (see the scenario's
+    # docstring) and the momentum rows are solved to ~1e-7 only
+    tight = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10, remove_p_mean=0)
+    sc = MicrovasculatureSimulation("stabilized_schur_bdf2", 0.01, 1.0, res=1.2e-3, quiet=True, options=tight)
+    mesh, nv = sc.mesh, sc.mesh.num_vertices
+    assert sc.solver.u_prev2.x.array.shape == (3 * nv,)
+    bcs = _bifurcation_bcs(mesh, sc._ft)
+    x = np.zeros(4 * nv)
+    un = np.zeros((nv, 3)); un2 = np.zeros((nv, 3))
+    for step in range(3):
+        a = (1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5)
+        prm = TN.Params(0.01, 1.0, 1.0 / sc.Re, (0.0, 0.0, 0.0), theta=1.0, a0=a[0], a1=a[1], a2=a[2])
+        pb = TN.Problem(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, prm)
+        for fld, nodes, vals in bcs:
+            (pb.add_bc_u if fld == 0 else pb.add_bc_p)(nodes, vals)
+        x, _ = pb.newton(x, un, un2=un2)
+        un2, un = un, x[: 3 * nv].reshape(-1, 3).copy()
+        sc.solver.solveStep()
+        ug = np.asarray(sc.solver.u_sol.x.array)
+        assert np.linalg.norm(ug - x[: 3 * nv]) <= 1e-8 * np.linalg.norm(x[: 3 * nv]), step
+        sc.solver.advance()
+    assert sc.solver.step_count == 3
+    assert np.linalg.norm(np.asarray(sc.solver.u_prev2.x.array) - un2.ravel()) <= 1e-8 * np.linalg.norm(un2)

@@ -163,3 +163,4 @@ def test_config1_dfg_coarse_full_run_to_T1(oracle_double):
     od, ol = 500 * o.solver.functional(0, 5), 500 * o.solver.functional(1, 5)
     assert abs(g.drag - od) <= 1e-5 * abs(od) and abs(g.lift - ol) <= 5e-3 * abs(ol) + 1e-6
     assert 5.0 < g.drag < 6.5 and g.p_diff is not None and 0.09 < g.p_diff < 0.14
+    assert abs(g.p_diff - o.p_diff) <= 1e-5 * abs(o.p_diff)   # pressure difference p(0.15, 0.2) - p(0.25, 0.2), dfg_1.py:213-253
