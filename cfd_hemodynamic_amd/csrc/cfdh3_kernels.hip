@@ -169,6 +169,7 @@ struct Asm3Args {
   double dt, rho, mu, muf, f[3];
   double theta, a0, a1, a2;
   int ds_terms, hist2;
+  double beta_bf;  // backflow coefficient beta*rho on the facets flagged in cflag bits 4..7 (cfdh_set_boundary_terms)
 };
 
 // MODE 0: residual only; 1: residual + Jacobian; 2: residual with lifting (Jacobian values of Dirichlet columns only)
@@ -183,6 +184,10 @@ __device__ __forceinline__ double quad_allsum(double v) {
   v += dppq<0xB1>(v);  // quad_perm [1,0,3,2]
   v += dppq<0x4E>(v);  // quad_perm [2,3,0,1]
   return v;
+}
+__device__ __forceinline__ double quad_bcast(double v, int k) {  // value of lane k of the quad (k uniform in the quad)
+  const double b0 = dppq<0x00>(v), b1 = dppq<0x55>(v), b2 = dppq<0xAA>(v), b3 = dppq<0xFF>(v);
+  return k == 0 ? b0 : (k == 1 ? b1 : (k == 2 ? b2 : b3));
 }
 __device__ __forceinline__ int tet_mom_index(int r, int c) {  // packed upper triangle: 00 01 02 03 11 12 13 22 23 33
   const int lo = r < c ? r : c, hi = r < c ? c : r;
@@ -302,7 +307,9 @@ __global__ __launch_bounds__(TPB, CFDH3_ASMQ_OCC) void asm3q_kernel(Asm3Args p) 
     const double pbar = 0.25 * psum;
     __builtin_amdgcn_sched_barrier(0);
     // ---- exterior facets containing vertex a: n_f |f| = -3 vol grad(lambda_f); SN = sum over the flagged facets f != a
-    const unsigned cf = p.ds_terms ? (unsigned)p.cflag[e] : 0u;
+    const unsigned cfraw = p.cflag[e];
+    const unsigned cf = p.ds_terms ? (cfraw & 15u) : 0u;
+    const unsigned cb = p.beta_bf != 0.0 ? (cfraw >> 4) : 0u;  // backflow facets
     double SN[3] = {0, 0, 0}, NFq[3] = {0, 0, 0};
     const bool facet_q = ((cf >> q) & 1u) && q != a;
     if (cf) {
@@ -339,6 +346,42 @@ __global__ __launch_bounds__(TPB, CFDH3_ASMQ_OCC) void asm3q_kernel(Asm3Args p) 
         }
       }
     }
+    // ---- backflow stabilisation on the flagged facets f that contain row vertex a and this lane's vertex q
+    //      (stabilized_schur_backflow.py:165-176): F_a -= beta rho int_f (u_prev.n)_- lambda_a ubar ds, (s)_- = (s - |s|)/2, with the
+    //      6-point degree-3 rule; n_f |f| = -3 vol grad(lambda_f), so sigma = u_prev(x_k) . (n_f |f|) carries the facet measure.
+    //      Wbf = sum_f sum_k c_k lambda_a(x_k) lambda_q(x_k): -theta Wbf on the diagonal of J00, -Wbf ubar_q in the residual.
+    double Wbf = 0.0;
+    if (cb) {
+      double unq[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) unq[i] = p.un[3 * (size_t)vq + i];
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        if (!((cb >> f) & 1u) || f == a) continue;  // uniform in the quad
+        const double sc3 = -3.0 * vol;
+        const double G0 = sc3 * quad_bcast(gq[0], f), G1 = sc3 * quad_bcast(gq[1], f), G2 = sc3 * quad_bcast(gq[2], f);
+        const double tq = unq[0] * G0 + unq[1] * G1 + unq[2] * G2;
+        const double t0 = dppq<0x00>(tq), t1 = dppq<0x55>(tq), t2 = dppq<0xAA>(tq), t3 = dppq<0xFF>(tq);
+        // facet vertices in increasing local index (m0 < m1 < m2) and the positions of a and q among them
+        const double s0 = f == 0 ? t1 : t0, s1 = f <= 1 ? t2 : t1, s2 = f <= 2 ? t3 : t2;
+        const int ja = a - (a > f ? 1 : 0), jq = q - (q > f ? 1 : 0);
+        if (q != f) {
+          const double A = 0.659027622374092, B = 0.231933368553031, C = 0.109039009072877;
+          const double P[6][3] = {{A, B, C}, {A, C, B}, {B, A, C}, {B, C, A}, {C, A, B}, {C, B, A}};
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; k++) {
+            const double sg = P[k][0] * s0 + P[k][1] * s1 + P[k][2] * s2;
+            const double la = ja == 0 ? P[k][0] : (ja == 1 ? P[k][1] : P[k][2]);
+            const double lq = jq == 0 ? P[k][0] : (jq == 1 ? P[k][1] : P[k][2]);
+            acc += (sg - fabs(sg)) * la * lq;
+          }
+          Wbf += p.beta_bf * (0.5 / 6.0) * acc;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) Fr[i] -= Wbf * ubq[i];
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- column block q of row a: the 16 values are produced one at a time and go straight to their LDS accumulator
     //      (never all live).  Dirichlet handling on the way: a Dirichlet column j of vertex q lifts F += J[:, j] (g - x) and
@@ -351,7 +394,7 @@ __global__ __launch_bounds__(TPB, CFDH3_ASMQ_OCC) void asm3q_kernel(Asm3Args p) 
       const double BMB = s2[0] * gq[0] + s2[1] * gq[1] + s2[2] * gq[2];
       const double mtBb = s3[0] * gq[0] + s3[1] * gq[1] + s3[2] * gq[2];
       const double cG = rho * th * (mab + MBaq);
-      const double cD = rho * a0idt * (mab + MBaq) + rho * th * (mBab + BMB) + vol * mu * th * gg;
+      const double cD = rho * a0idt * (mab + MBaq) + rho * th * (mBab + BMB) + vol * mu * th * gg - th * Wbf;
       const double vmt = vol * mu * th, rlt = rho * Lm * th, cf3 = p.muf * th * (1.0 / 3.0);
       double *dst = accJ + A3S * (size_t)slot;
       const bool store = WJ && valid;
@@ -463,6 +506,7 @@ int k3_assemble(cfdh_ctx *c, const double *xstate, int mode) {
   a.nv = c->nv; a.dt = c->dt; a.rho = c->rho; a.mu = c->mu; a.muf = c->muf; a.f[0] = c->f[0]; a.f[1] = c->f[1]; a.f[2] = c->f[2];
   a.theta = c->ts_theta; a.a0 = c->ts_a[0]; a.a1 = c->ts_a[1]; a.a2 = c->ts_a[2];
   a.ds_terms = c->ds_terms ? 1 : 0; a.hist2 = c->ts_a[2] != 0.0 ? 1 : 0;
+  a.beta_bf = (c->bf_beta > 0.0 && c->bf_marker >= 0) ? c->bf_beta * c->rho : 0.0;
   const size_t lds = sizeof(double) * (A3S * (size_t)CFDH3_MAX_SLOTS + 4 * 64);
   prof_begin(c, 0);
   if (mode == 1) hipLaunchKernelGGL((asm3q_kernel<1>), dim3(c->a3_nblk), dim3(TPB), lds, c->stream, a);
@@ -592,18 +636,24 @@ int k3_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double
   return 0;
 }
 
-// ||J n|| for the normalised constant-pressure vector (MatNullSpaceTest, stabilized_schur.py:314)
+// ||J n|| and || |J| n || for the constant-pressure vector (MatNullSpaceTest, stabilized_schur.py:314)
 __global__ __launch_bounds__(TPB) void nulltest3_kernel(int nv, const int *__restrict__ vptr, const double *__restrict__ A01,
                                                         const double *__restrict__ A11, double *__restrict__ partial) {
   __shared__ double sh[4];
-  double a = 0;
+  double a = 0, b = 0;
   for (int row = blockIdx.x * TPB + threadIdx.x; row < nv; row += gridDim.x * TPB) {
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int k = vptr[row]; k < vptr[row + 1]; k++) { s0 += A01[3 * (size_t)k]; s1 += A01[3 * (size_t)k + 1]; s2 += A01[3 * (size_t)k + 2]; s3 += A11[k]; }
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    for (int k = vptr[row]; k < vptr[row + 1]; k++) {
+      const double c0 = A01[3 * (size_t)k], c1 = A01[3 * (size_t)k + 1], c2 = A01[3 * (size_t)k + 2], c3 = A11[k];
+      s0 += c0; s1 += c1; s2 += c2; s3 += c3;
+      t0 += fabs(c0); t1 += fabs(c1); t2 += fabs(c2); t3 += fabs(c3);
+    }
     a += s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3;
+    b += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
   }
   a = bsum3(a, sh);
-  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+  b = bsum3(b, sh);
+  if (threadIdx.x == 0) { partial[blockIdx.x] = a; partial[gridDim.x + blockIdx.x] = b; }
 }
 __global__ __launch_bounds__(TPB) void final3_kernel(int nb, int stride, const double *__restrict__ partial, double *__restrict__ out) {
   __shared__ double sh[4];
@@ -618,15 +668,16 @@ static int read2(cfdh_ctx *c, double *v, int n) {
   for (int i = 0; i < n; i++) v[i] = c->h_pinned[i];
   return 0;
 }
-int k3_nullspace_test(cfdh_ctx *c, double *nrm) {
+int k3_nullspace_test(cfdh_ctx *c, double *nrm, double *absnrm) {
   const int nb = 256;
   c->mirror_src = nullptr;
   hipLaunchKernelGGL(nulltest3_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nvo, c->vptr.p, c->A01.p, c->A11.p, c->red_partial.p);
-  hipLaunchKernelGGL(final3_kernel, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p);
+  hipLaunchKernelGGL(final3_kernel, dim3(2), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p);
   HIPCHK(c, hipGetLastError());
-  double s;
-  CHK(read2(c, &s, 1));
-  *nrm = sqrt(s);
+  double s[2];
+  CHK(read2(c, s, 2));
+  *nrm = sqrt(s[0]);
+  *absnrm = sqrt(s[1]);
   return 0;
 }
 

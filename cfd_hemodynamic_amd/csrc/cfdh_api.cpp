@@ -273,12 +273,13 @@ int cfdh_set_time_scheme(cfdh_ctx *c, double theta, double a0, double a1, double
   return 0;
 }
 
-// per-cell facet bits of the assembly kernel: bits 0-2 exterior facet, bits 3-5 backflow facet (marker == bf_marker)
+// per-cell facet bits of the assembly kernel: bits 0..d exterior facet, bits d+1..2d+1 backflow facet (marker == bf_marker)
 static int upload_cell_facet_flags(cfdh_ctx *c) {
   std::vector<unsigned char> cflag((size_t)c->nc, 0);
   for (int k = 0; k < c->nfac; k++) {
     cflag[c->fac_cell[k]] |= (unsigned char)(1u << c->fac_local[k]);
-    if (c->bf_marker >= 0 && c->fac_marker[k] == c->bf_marker) cflag[c->fac_cell[k]] |= (unsigned char)(8u << c->fac_local[k]);
+    if (c->bf_marker >= 0 && c->fac_marker[k] == c->bf_marker)
+      cflag[c->fac_cell[k]] |= (unsigned char)((c->dim == 3 ? 16u : 8u) << c->fac_local[k]);
   }
   HIPCHK(c, c->cflag.upload(cflag, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -290,7 +291,6 @@ static int upload_cell_facet_flags(cfdh_ctx *c) {
 int cfdh_set_boundary_terms(cfdh_ctx *c, int ds_terms, int backflow_marker, double beta) {
   ENTER(c);
   if (beta < 0) return cfdh_fail(c, CFDH_E_ARG, "backflow beta must be >= 0");
-  if (beta > 0 && c->dim == 3) return cfdh_fail(c, CFDH_E_ARG, "the backflow term is not implemented for tetrahedra");
   if (!(beta > 0)) backflow_marker = -1;
   const bool changed = (ds_terms != 0) != c->ds_terms || beta != c->bf_beta || backflow_marker != c->bf_marker;
   c->ds_terms = ds_terms != 0; c->bf_beta = beta; c->bf_marker = backflow_marker;

@@ -352,7 +352,7 @@ int k3_moments(cfdh_ctx *c);
 int k3_assemble(cfdh_ctx *c, const double *xstate, int mode);
 int k3_spmv_full(cfdh_ctx *c, const double *x, double *y);
 int k3_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b);  // 2: b - A01 x_p ; 3: b - A10 x_u (b may be null)
-int k3_nullspace_test(cfdh_ctx *c, double *nrm);
+int k3_nullspace_test(cfdh_ctx *c, double *nrm, double *absnrm);
 int k3_functional(cfdh_ctx *c, int kind, int marker, double *out);
 int k3_wss(cfdh_ctx *c, double *out);
 
@@ -383,7 +383,7 @@ int k_ext_pack(cfdh_ctx *c, const double *vec, double *out);  // [u | p | ghost 
 int k_scatter_global(cfdh_ctx *c, int n, const int *l2g, const double *loc, double *glob);
 int k_gather_global(cfdh_ctx *c, int n, const int *l2g, const double *glob, double *loc);
 int k_cc_combine(cfdh_ctx *c, int n, double alpha, double beta, const double *t, const double *z, const double *r, const unsigned char *pbc, double *out);
-int k_nullspace_test(cfdh_ctx *c, double *nrm);
+int k_nullspace_test(cfdh_ctx *c, double *nrm, double *absnrm);
 
 // vector ops on [0,n)
 int v_copy(cfdh_ctx *c, int n, const double *x, double *y);

@@ -2046,30 +2046,38 @@ int v_scale_inv_dev(cfdh_ctx *c, int n, const double *w, const double *nrm_dev, 
   return 0;
 }
 
-// ||J n|| for the normalised constant-pressure vector n (MatNullSpaceTest, stabilized_schur.py:314)
+// ||J n|| and || |J| n || for the constant-pressure vector n (MatNullSpaceTest, stabilized_schur.py:314; the second norm makes
+// the decision scale-free, see cfdh_newton_step)
 __global__ __launch_bounds__(TPB) void nulltest_kernel(int nvo, const int *__restrict__ vptr, const double *__restrict__ A01,
                                                        const double *__restrict__ A11, double *__restrict__ partial) {
   __shared__ double sh[4];
-  double a = 0;
+  double a = 0, b = 0;
   for (int row = blockIdx.x * TPB + threadIdx.x; row < nvo; row += gridDim.x * TPB) {
-    double s0 = 0, s1 = 0, s2 = 0;
-    for (int k = vptr[row]; k < vptr[row + 1]; k++) { s0 += A01[2 * (size_t)k]; s1 += A01[2 * (size_t)k + 1]; s2 += A11[k]; }
+    double s0 = 0, s1 = 0, s2 = 0, t0 = 0, t1 = 0, t2 = 0;
+    for (int k = vptr[row]; k < vptr[row + 1]; k++) {
+      const double c0 = A01[2 * (size_t)k], c1 = A01[2 * (size_t)k + 1], c2 = A11[k];
+      s0 += c0; s1 += c1; s2 += c2;
+      t0 += fabs(c0); t1 += fabs(c1); t2 += fabs(c2);
+    }
     a += s0 * s0 + s1 * s1 + s2 * s2;
+    b += t0 * t0 + t1 * t1 + t2 * t2;
   }
   a = block_sum(a, sh);
-  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+  b = block_sum(b, sh);
+  if (threadIdx.x == 0) { partial[blockIdx.x] = a; partial[gridDim.x + blockIdx.x] = b; }
 }
-int k_nullspace_test(cfdh_ctx *c, double *nrm) {
-  if (c->dim == 3) return k3_nullspace_test(c, nrm);
+int k_nullspace_test(cfdh_ctx *c, double *nrm, double *absnrm) {
+  if (c->dim == 3) return k3_nullspace_test(c, nrm, absnrm);
   const int nb = vgrid(c->nvo) > c->red_blocks ? c->red_blocks : vgrid(c->nvo);
   hipLaunchKernelGGL(nulltest_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nvo, c->vptr.p, c->A01.p, c->A11.p, c->red_partial.p);
-  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p,
-                     scalar_mirror(c, c->red_out.p, 1));
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(2), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p,
+                     scalar_mirror(c, c->red_out.p, 2));
   HIPCHK(c, hipGetLastError());
-  CHK(finish_scalars(c, c->red_out.p, 1, 0));
-  double s;
-  CHK(read_scalars(c, c->red_out.p, 1, &s));
-  *nrm = sqrt(s);
+  CHK(finish_scalars(c, c->red_out.p, 2, 0));
+  double s[2];
+  CHK(read_scalars(c, c->red_out.p, 2, s));
+  *nrm = sqrt(s[0]);
+  *absnrm = sqrt(s[1]);
   return 0;
 }
 

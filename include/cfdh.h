@@ -30,8 +30,7 @@
  * Dimension: gdim = 2 (triangles) or 3 (tetrahedra,
  * /root/reference/src/scenarios/simple_bifurcation.py, scenario_factory.py:47-49)
  * is fixed at cfdh_create; "d" below stands for it.  Tetrahedral contexts are
- * single-GPU in this version (cfdh_set_halo and the backflow term return
- * CFDH_E_ARG) and use pc_type 1.
+ * single-GPU in this version (cfdh_set_halo returns CFDH_E_ARG) and use pc_type 1.
  */
 #ifndef CFDH_H
 #define CFDH_H
@@ -173,8 +172,8 @@ int cfdh_set_time_scheme(cfdh_ctx *ctx, double theta, double a0, double a1, doub
  * (do-nothing outlet): ds_terms = 0.  beta > 0 adds the backflow stabilisation
  * -beta rho (u_prev.n)_- (u_mid . v) ds, (s)_- = (s-|s|)/2, on the exterior facets whose marker
  * (facet_marker of cfdh_create) equals backflow_marker (`ds_out`, tags["outlet"],
- * stabilized_schur_backflow.py:158-176), integrated with the 2-point Gauss rule FFCx picks
- * for its estimated degree 3. */
+ * stabilized_schur_backflow.py:158-176), integrated with a rule of FFCx's estimated degree 3:
+ * 2-point Gauss on edges, the 6-point Strang-Fix rule on the triangles of a tetrahedral mesh. */
 int cfdh_set_boundary_terms(cfdh_ctx *ctx, int ds_terms, int backflow_marker, double beta);
 
 /* u_prev2 (stabilized_schur_bdf2.py:72): upload / download; nv local vertices x gdim */

@@ -49,6 +49,19 @@ def quad_rule(d, n=7):
 _RULES = {}
 
 
+def facet_rule(d):
+    """Degree-3 rule on the reference facet: barycentric points (w.r.t. the facet's vertices in increasing local index) and
+    weights summing to 1.  Edge: 2-point Gauss-Legendre.  Triangle: the 6-point rule of Strang and Fix (the rule Basix would
+    hand FFCx for degree 3 is a 6-point Xiao-Gimbutas rule; the integrand is not polynomial, so the two differ at the
+    level the cell rules do)."""
+    if d == 2:
+        gq = 0.5 / np.sqrt(3.0)
+        return [(0.5 + gq, 0.5 - gq), (0.5 - gq, 0.5 + gq)], [0.5, 0.5]
+    a, b, c = 0.659027622374092, 0.231933368553031, 0.109039009072877
+    pts = [(a, b, c), (a, c, b), (b, a, c), (b, c, a), (c, a, b), (c, b, a)]
+    return pts, [1.0 / 6.0] * 6
+
+
 def _rule(d):
     if d not in _RULES:
         _RULES[d] = quad_rule(d)
@@ -56,12 +69,13 @@ def _rule(d):
 
 
 class Params:
-    def __init__(self, dt, rho, mu, f, mu_facet=None, theta=0.5, a0=1.0, a1=-1.0, a2=0.0, ds_terms=True):
+    def __init__(self, dt, rho, mu, f, mu_facet=None, theta=0.5, a0=1.0, a1=-1.0, a2=0.0, ds_terms=True, beta_backflow=0.0):
         self.dt, self.rho, self.mu = float(dt), float(rho), float(mu)
         self.f = np.asarray(f, dtype=np.float64)
         self.mu_facet = float(mu if mu_facet is None else mu_facet)
         self.theta, self.a0, self.a1, self.a2 = float(theta), float(a0), float(a1), float(a2)
         self.ds_terms = bool(ds_terms)
+        self.beta_backflow = float(beta_backflow)
 
 
 def geometry(x, cells):
@@ -166,6 +180,31 @@ def element_tensors(x, cells, u, un, p, prm, facet_flags=None, want_jac=True, un
                     v = v + th * g[:, a, j] * mtB[:, b]
                     Je[:, po + a, d * b + j] = v
                 Je[:, po + a, po + b] = T * gg[:, a, b] / rho
+    if facet_flags is not None and prm.beta_backflow != 0.0 and np.any(facet_flags.astype(np.int64) >> n1):
+        # backflow stabilisation (stabilized_schur_backflow.py:165-176): F -= beta rho int_out (u_prev.n)_- (ubar . v) ds,
+        # (s)_- = (s - |s|)/2, on the facets flagged in bits n1 .. 2 n1 - 1.  UFL's estimated degree is 3 (abs keeps the
+        # degree): 2-point Gauss-Legendre on an edge, a 6-point degree-3 rule on a triangle (facet_rule).
+        QF, WF = facet_rule(d)
+        for f in range(n1):
+            sel = np.nonzero((facet_flags.astype(np.int64) >> (n1 + f)) & 1)[0]
+            if len(sel) == 0:
+                continue
+            gf = g[sel, f]
+            gl = np.linalg.norm(gf, axis=1)
+            n = -gf / gl[:, None]
+            fm = d * vol[sel] * gl
+            ev = [a for a in range(n1) if a != f]
+            sv = [np.einsum("ci,ci->c", une[sel, a], n) for a in ev]
+            for lam, wq in zip(QF, WF):
+                sq = sum(l * s_ for l, s_ in zip(lam, sv))
+                cq = prm.beta_backflow * rho * 0.5 * (sq - np.abs(sq)) * wq * fm
+                uq = sum(l * ub[sel, a] for l, a in zip(lam, ev))
+                for la, a in zip(lam, ev):
+                    Fu[sel, a, :] -= (cq * la)[:, None] * uq
+                    if want_jac:
+                        for lb, b in zip(lam, ev):
+                            for i in range(d):
+                                Je[sel, d * a + i, d * b + i] -= th * cq * la * lb
     if facet_flags is not None and prm.ds_terms and np.any(facet_flags & ((1 << n1) - 1)):
         po = d * n1
         for f in range(n1):
@@ -207,6 +246,7 @@ class Problem:
         ff = np.zeros(self.nc, dtype=np.uint8)
         np.bitwise_or.at(ff, self.facet_cells, (1 << self.facet_local).astype(np.uint8))
         self.facet_flags = ff
+        self._ext_flags = ff.copy()
         self.ndof = n1 * self.nv
         self.nu = d * self.nv
         c = self.cells
@@ -219,6 +259,17 @@ class Problem:
         self.isbc = np.zeros(self.ndof, dtype=bool)
         self.bcval = np.zeros(self.ndof)
         self.bcmult = np.zeros(self.ndof)
+
+    def set_boundary_terms(self, ds_terms, backflow_facets=None, beta=0.0):
+        """backflow_facets: indices into the exterior-facet arrays (the facets tagged `outlet`)."""
+        self.prm.ds_terms = bool(ds_terms)
+        self.prm.beta_backflow = float(beta)
+        n1 = self.d + 1
+        ff = self._ext_flags.copy()
+        if backflow_facets is not None and len(backflow_facets):
+            k = np.asarray(backflow_facets, dtype=np.int64)
+            np.bitwise_or.at(ff, self.facet_cells[k], ((1 << n1) << self.facet_local[k]).astype(np.uint8))
+        self.facet_flags = ff
 
     def clear_bcs(self):
         self.isbc[:] = False
@@ -279,9 +330,15 @@ class Problem:
     def newton(self, x0, un, rtol=1e-12, atol=1e-14, max_it=25, un2=None):
         x = x0.copy()
         hist = []
-        singular = not self.isbc[self.nu:].any()
+        singular = None
         for it in range(max_it + 1):
             F, J = self.assemble(x, un, want_jac=True, un2=un2)
+            if singular is None:
+                # constant-pressure null vector?  Not with a pressure condition, and not with a do-nothing outlet either (the
+                # weak form without the ds pair fixes the pressure level): decided on the matrix, relative to |J| e
+                e = np.zeros(self.ndof)
+                e[self.nu:] = 1.0
+                singular = (not self.isbc[self.nu:].any()) and np.linalg.norm(J @ e) <= 1e-9 * np.linalg.norm(abs(J) @ e)
             fn = np.linalg.norm(F)
             hist.append(fn)
             if fn <= atol or (it > 0 and fn <= rtol * hist[0]):

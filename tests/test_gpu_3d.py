@@ -207,3 +207,65 @@ def test_bdf2_plugin_on_tetrahedra_matches_twin():
         sc.solver.advance()
     assert sc.solver.step_count == 3
     assert np.linalg.norm(np.asarray(sc.solver.u_prev2.x.array) - un2.ravel()) <= 1e-8 * np.linalg.norm(un2)
+
+
+def test_tet_backflow_term_matches_twin():
+    """stabilized_schur_backflow on tetrahedra: no ds pair, backflow stabilisation on the outlet facets (both outlets of the
+    bifurcation share marker 9 here), u_prev with reverse flow through them; residual and every CSR value against the twin,
+    then three time steps (do-nothing outlets, no pressure condition: singular pressure handled by the null-space logic)."""
+    mesh, ft = create_bifurcation(0.0012)
+    nv = mesh.num_vertices
+    marker = mesh.facet_marker.copy()
+    marker[marker == 10] = 9
+    out = np.nonzero(marker == 9)[0]
+    bcs = [b for b in _bifurcation_bcs(mesh, ft) if b[0] == 0]   # walls + inlet; no pressure condition
+    pb, ctx = _pair(mesh, 0.01, 1.0, 0.013, (0.0, 0.0, 0.0), bcs)
+    ctx.set_facet_markers(marker)
+    ctx.set_boundary_terms(False, 9, 0.5)
+    pb.set_boundary_terms(False, out, 0.5)
+    rng = np.random.default_rng(5)
+    xv = 0.3 * rng.standard_normal(4 * nv)
+    un = 0.3 * rng.standard_normal((nv, 3))
+    un[:, 1] -= 0.2          # net inflow through the outlets (their normals point along +y)
+    F, J = pb.assemble(xv, un)
+    pb.set_boundary_terms(False, None, 0.0)
+    F0, _ = pb.assemble(xv, un)
+    pb.set_boundary_terms(False, out, 0.5)
+    assert np.abs(F - F0).max() > 1e-9 * np.abs(F).max()          # the term is active
+    ctx.set_state(u_prev=un.ravel(), p_prev=np.zeros(nv), u=xv[: 3 * nv], p=xv[3 * nv:])
+    ctx.assemble(True)
+    Fg = np.concatenate(ctx.get_residual())
+    assert np.abs(F - Fg).max() <= 1e-12 * np.abs(F).max()
+    assert abs(J - ctx.get_csr()).max() <= 1e-12 * abs(J).max()
+    ctx.assemble(False)
+    assert np.abs(np.concatenate(ctx.get_residual()) - Fg).max() <= 1e-12 * np.abs(Fg).max()
+    # time steps from rest with the scenario's inlet: both sides converged tightly
+    o = ctx.default_options()
+    o.snes_rtol, o.snes_stol, o.ksp_rtol = 1e-11, 0.0, 1e-9
+    ctx.set_options(o)
+    z3, z1 = np.zeros(3 * nv), np.zeros(nv)
+    ctx.set_state(u_prev=z3, p_prev=z1, u=z3, p=z1)
+    x = np.zeros(4 * nv); unn = np.zeros((nv, 3))
+    for step in range(2):
+        st = ctx.solve_step()
+        assert st.reason > 0
+        xg = np.concatenate(ctx.get_solution())
+        ctx.advance()
+        x, _ = pb.newton(x, unn)
+        unn = x[: 3 * nv].reshape(-1, 3).copy()
+        assert np.linalg.norm(xg[: 3 * nv] - x[: 3 * nv]) <= 1e-7 * np.linalg.norm(x[: 3 * nv]), step
+        pg, pt = xg[3 * nv:], x[3 * nv:]
+        assert np.linalg.norm((pg - pg.mean()) - (pt - pt.mean())) <= 1e-6 * np.linalg.norm(pt - pt.mean()), step
+    ctx.close()
+
+
+def test_backflow_plugin_runs_the_bifurcation_scenario():
+    """`--simulation simple_bifurcation --solver stabilized_schur_backflow --v_max 1.5`: the plugin class on tetrahedra (pressure
+    conditions ignored, do-nothing outlets, backflow term on tags["outlet"] = outlet 1)."""
+    from cfd_hemodynamic_amd.scenarios.simple_bifurcation import MicrovasculatureSimulation
+    sc = MicrovasculatureSimulation("stabilized_schur_backflow", 0.01, 0.025, res=8e-4, quiet=True, v_max=1.5, beta_backflow=0.2)
+    assert sc.solver.bcp_d == [] and sc.solver.ctx.dim == 3
+    sc.solve(None)
+    qi, q1, q2 = sc.flow_rates()
+    assert sc.num_steps == 3 and qi > 0 and 0.5 * qi < q1 + q2 < 1.05 * qi
+    assert np.isfinite(sc.norm_p) and sc.norm_v > 0

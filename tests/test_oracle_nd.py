@@ -137,3 +137,60 @@ def test_bifurcation_mesh_and_a_newton_step():
     assert qin > 0 and 0.3 * qin < qout < qin
     assert abs(pb.flux(x, ft.find(9)) - pb.flux(x, ft.find(10))) < 0.05 * qin
     assert abs(pb.flux(x, ft.find(11))) < 1e-15
+
+
+def test_facet_rule_integrates_cubics_exactly():
+    """Degree-3 rules of the backflow term: int_T l1^p l2^q l3^r = 2 p! q! r! / (p + q + r + 2)! (unit measure), edge analogue."""
+    from math import factorial as fa
+    pts, w = TN.facet_rule(3)
+    assert abs(sum(w) - 1.0) < 1e-15
+    for p in range(4):
+        for q in range(4 - p):
+            for r in range(4 - p - q):
+                num = sum(wk * l[0] ** p * l[1] ** q * l[2] ** r for l, wk in zip(pts, w))
+                assert abs(num - 2.0 * fa(p) * fa(q) * fa(r) / fa(p + q + r + 2)) < 1e-14, (p, q, r)
+    pts, w = TN.facet_rule(2)
+    for p in range(4):
+        for q in range(4 - p):
+            num = sum(wk * l[0] ** p * l[1] ** q for l, wk in zip(pts, w))
+            assert abs(num - fa(p) * fa(q) / fa(p + q + 1)) < 1e-14
+
+
+def test_backflow_term_d2_equals_2d_twin_and_d3_jacobian_is_derivative():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__)))
+    from util import stenosis_backflow_case
+    from oracle import np_twin as T2
+    case = stenosis_backflow_case(6, L=10.0, x_sten=4.0, beta=0.3)
+    m, nv = case.mesh, case.mesh.num_vertices
+    rng = np.random.default_rng(1)
+    p2 = T2.Problem(m.x, m.cells, m.facet_cells, m.facet_local, T2.Params(case.dt, case.rho, case.mu, case.f))
+    pn = TN.Problem(m.x, m.cells, m.facet_cells, m.facet_local, TN.Params(case.dt, case.rho, case.mu, np.array([0.0, 0.0])))
+    for fld, nodes, vals in case.bcs:
+        (p2.add_bc_u if fld == 0 else p2.add_bc_p)(nodes, vals)
+        (pn.add_bc_u if fld == 0 else pn.add_bc_p)(nodes, vals)
+    p2.set_boundary_terms(False, case.backflow_facets, 0.3)
+    pn.set_boundary_terms(False, case.backflow_facets, 0.3)
+    x, un = rng.standard_normal(3 * nv), rng.standard_normal((nv, 2))
+    F2, J2 = p2.assemble(x, un)
+    Fn, Jn = pn.assemble(x, un)
+    assert np.abs(F2 - Fn).max() <= 1e-13 * np.abs(F2).max() and abs(J2 - Jn).max() <= 1e-13 * abs(J2).max()
+    # tetrahedra: outlet = top face of a cube, reverse flow through it; J = dF/dx by central differences
+    from cfd_hemodynamic_amd.mesh3d import create_unit_cube
+    mesh = create_unit_cube(2)
+    nv = mesh.num_vertices
+    top = np.nonzero(mesh.facet_midpoints()[:, 2] > 1.0 - 1e-9)[0]
+    pb = TN.Problem(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, TN.Params(0.05, 1.2, 0.03, (0.1, 0.0, -0.2)))
+    pb.set_boundary_terms(False, top, 0.7)
+    xv = 0.2 * rng.standard_normal(4 * nv)
+    un = 0.2 * rng.standard_normal((nv, 3))
+    un[:, 2] -= 0.5   # mostly entering through the top: (u_prev . n)_- active
+    F, J = pb.assemble(xv, un, apply_bc=False)
+    pb0 = TN.Problem(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, TN.Params(0.05, 1.2, 0.03, (0.1, 0.0, -0.2), ds_terms=False))
+    F0, _ = pb0.assemble(xv, un, apply_bc=False)
+    assert np.abs(F - F0).max() > 1e-4     # the term is there
+    eps = 1e-6
+    for k in rng.choice(3 * nv, 12, replace=False):
+        e = np.zeros(4 * nv); e[k] = eps
+        fd = (pb.assemble(xv + e, un, want_jac=False, apply_bc=False)[0] - pb.assemble(xv - e, un, want_jac=False, apply_bc=False)[0]) / (2 * eps)
+        assert np.abs(fd - J[:, k].toarray().ravel()).max() <= 1e-7 * max(1.0, abs(J[:, k]).max())
