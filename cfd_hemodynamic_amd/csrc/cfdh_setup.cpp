@@ -498,15 +498,17 @@ static int upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vecto
   const int ns = (H.n + 63) / 64;
   std::vector<int> sptr(ns + 1, 0);
   D.sell_maxw = 0;
+#pragma omp parallel for schedule(static) num_threads(cfdh_host_threads()) if (ns > 256)
   for (int sl = 0; sl < ns; sl++) {
     int w = 0;
     for (int r = sl * 64; r < std::min(H.n, sl * 64 + 64); r++) w = std::max(w, H.rowptr[r + 1] - H.rowptr[r]);
-    sptr[sl + 1] = sptr[sl] + 64 * w;
-    D.sell_maxw = std::max(D.sell_maxw, w);
+    sptr[sl + 1] = 64 * w;
   }
+  for (int sl = 0; sl < ns; sl++) { D.sell_maxw = std::max(D.sell_maxw, sptr[sl + 1] / 64); sptr[sl + 1] += sptr[sl]; }
   std::vector<int> scol((size_t)sptr[ns], 0);
   std::vector<float> sval((size_t)sptr[ns], 0.0f), svalw;
   if (colw) svalw.assign((size_t)sptr[ns], 0.0f);
+#pragma omp parallel for schedule(static) num_threads(cfdh_host_threads()) if (H.n > 4096)
   for (int r = 0; r < H.n; r++) {
     const int sl = r >> 6, lane = r & 63;
     for (int k = H.rowptr[r], j = 0; k < H.rowptr[r + 1]; k++, j++) {
@@ -558,10 +560,26 @@ int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<
 static void csr_axpby_scaled(const CsrHost &A, double alpha, const double *s_row, const double *s_col, const CsrHost &B, CsrHost &C) {
   C.n = A.n; C.m = A.m;
   C.rowptr.assign(A.n + 1, 0);
-  C.col.clear(); C.val.clear();
-  C.col.reserve(A.col.size() + B.col.size() / 4); C.val.reserve(A.col.size() + B.col.size() / 4);
+  const int nt = cfdh_host_threads();
+  // pass 1: size of the union pattern per row; pass 2: fill (rows are independent)
+#pragma omp parallel for schedule(static) num_threads(nt) if (A.n > 4096)
   for (int i = 0; i < A.n; i++) {
-    int ka = A.rowptr[i], kb = B.rowptr[i];
+    int ka = A.rowptr[i], kb = B.rowptr[i], cnt = 0;
+    const int ea = A.rowptr[i + 1], eb = B.rowptr[i + 1];
+    while (ka < ea || kb < eb) {
+      const int ja = ka < ea ? A.col[ka] : 0x7fffffff, jb = kb < eb ? B.col[kb] : 0x7fffffff;
+      const int j = ja < jb ? ja : jb;
+      if (ja == j) ka++;
+      if (jb == j) kb++;
+      cnt++;
+    }
+    C.rowptr[i + 1] = cnt;
+  }
+  for (int i = 0; i < A.n; i++) C.rowptr[i + 1] += C.rowptr[i];
+  C.col.resize(C.rowptr[A.n]); C.val.resize(C.rowptr[A.n]);
+#pragma omp parallel for schedule(static) num_threads(nt) if (A.n > 4096)
+  for (int i = 0; i < A.n; i++) {
+    int ka = A.rowptr[i], kb = B.rowptr[i], p = C.rowptr[i];
     const int ea = A.rowptr[i + 1], eb = B.rowptr[i + 1];
     const double sr = s_row ? s_row[i] : 1.0;
     while (ka < ea || kb < eb) {
@@ -570,9 +588,8 @@ static void csr_axpby_scaled(const CsrHost &A, double alpha, const double *s_row
       double v = 0.0;
       if (ja == j) { v += alpha * sr * A.val[ka] * (s_col ? s_col[j] : 1.0); ka++; }
       if (jb == j) { v += B.val[kb]; kb++; }
-      C.col.push_back(j); C.val.push_back(v);
+      C.col[p] = j; C.val[p] = v; p++;
     }
-    C.rowptr[i + 1] = (int)C.col.size();
   }
 }
 
@@ -664,13 +681,16 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
     const double omega = 4.0 / 3.0 / lm;
     P.n = A.n; P.m = na;
     P.rowptr.assign(A.n + 1, 0);
+#pragma omp parallel for schedule(static) num_threads(cfdh_host_threads()) if (A.n > 4096)
     for (int i = 0; i < A.n; i++) {
-      if (agg[i] < 0) { P.rowptr[i + 1] = P.rowptr[i]; continue; }
+      if (agg[i] < 0) { P.rowptr[i + 1] = 0; continue; }
       bool has = false;
       for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; k++) if (AP0.col[k] == agg[i]) has = true;
-      P.rowptr[i + 1] = P.rowptr[i] + (AP0.rowptr[i + 1] - AP0.rowptr[i]) + (has ? 0 : 1);
+      P.rowptr[i + 1] = (AP0.rowptr[i + 1] - AP0.rowptr[i]) + (has ? 0 : 1);
     }
+    for (int i = 0; i < A.n; i++) P.rowptr[i + 1] += P.rowptr[i];
     P.col.resize(P.rowptr[A.n]); P.val.resize(P.rowptr[A.n]);
+#pragma omp parallel for schedule(static) num_threads(cfdh_host_threads()) if (A.n > 4096)
     for (int i = 0; i < A.n; i++) {
       if (agg[i] < 0) continue;
       int p = P.rowptr[i];
