@@ -1491,8 +1491,14 @@ __global__ __launch_bounds__(TPB) void fused_up_dense_kernel(int n, const int *_
   if (row < n) {
     for (int k = rpB[row] + l, ke = rpB[row + 1]; k < ke; k += 64) a = vfma(vlB[k], b[clB[k]], a);
     const float *Dr = D + (size_t)row * nc;
-#pragma unroll 4
-    for (int j = l; j < nc; j += 64) a = vfma((double)Dr[j], bc[j], a);
+    // the whole row in flight at once when it fits 12 steps (coarsest levels of <= 768 unknowns), remainder in a loop
+    float dv[12];
+    T bv[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) { const int j = l + 64 * q; if (j < nc) { dv[q] = Dr[j]; bv[q] = bc[j]; } }
+#pragma unroll
+    for (int q = 0; q < 12; q++) { const int j = l + 64 * q; if (j < nc) a = vfma((double)dv[q], bv[q], a); }
+    for (int j = l + 768; j < nc; j += 64) a = vfma((double)Dr[j], bc[j], a);
   }
   a = wsum(a);
   if (row < n && l == 0) x[row] = a;
