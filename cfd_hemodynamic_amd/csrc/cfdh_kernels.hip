@@ -1425,9 +1425,31 @@ __global__ __launch_bounds__(TPB) void fused_up_csr_kernel(int n, const int *__r
   const int row = gid >> 3, l = gid & 7;
   T a = vzero((const T *)nullptr);
   if (row < n) {
-    for (int k = rpB[row] + l, ke = rpB[row + 1]; k < ke; k += 8) a = vfma(vlB[k], b[clB[k]], a);
-    if (rpC)
-      for (int k = rpC[row] + l, ke = rpC[row + 1]; k < ke; k += 8) a = vfma(vlC[k], xc[clC[k]], a);
+    // two entries of each matrix per lane requested together, then their gathers (rows of 10-30 entries on the coarse levels:
+    // the plain loops make two to four dependent round trips per matrix)
+    const int kb = rpB[row] + l, keB = rpB[row + 1];
+    int kc = 0, keC = 0;
+    if (rpC) { kc = rpC[row] + l; keC = rpC[row + 1]; }
+    int cb[2], cc[2];
+    double vb[2], vc[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (kb + 8 * q < keB) { cb[q] = clB[kb + 8 * q]; vb[q] = vlB[kb + 8 * q]; }
+      if (kc + 8 * q < keC) { cc[q] = clC[kc + 8 * q]; vc[q] = vlC[kc + 8 * q]; }
+    }
+    T gb[2], gc[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (kb + 8 * q < keB) gb[q] = b[cb[q]];
+      if (kc + 8 * q < keC) gc[q] = xc[cc[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (kb + 8 * q < keB) a = vfma(vb[q], gb[q], a);
+      if (kc + 8 * q < keC) a = vfma(vc[q], gc[q], a);
+    }
+    for (int k = kb + 16; k < keB; k += 8) a = vfma(vlB[k], b[clB[k]], a);
+    for (int k = kc + 16; k < keC; k += 8) a = vfma(vlC[k], xc[clC[k]], a);
   }
   a = g8(a);
   if (row < n && l == 0) x[row] = epbc ? epi_apply(a, row, ea, eb, ezH, er, epbc) : a;
