@@ -1592,7 +1592,9 @@ static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof) 
     const unsigned char *epbc = epi ? c->epi.pbc : nullptr;
     if (epi) { xl = (T *)c->epi.out; c->epi.done = true; }
     if (prof && l == 0) prof_begin(c, prof);
-    if (L->sell && L->Sb.sell_maxw <= (sizeof(T) > 8 ? 8 : 10) && L->Sc.sell_maxw <= (sizeof(T) > 8 ? 8 : 10))
+    // a few longer rows (irregular vertices of a triangle mesh) go through the tail loop of the one-chunk kernel; the chunked
+    // kernel is for meshes whose typical row exceeds a chunk (tetrahedra)
+    if (L->sell && L->Sb.sell_maxw <= 14 && L->Sc.sell_maxw <= 14)
       hipLaunchKernelGGL((fused_up_sell_kernel<T, false>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
                          L->Sb.sptr.p, L->Sb.scol.p, L->Sb.sval.p, bl, L->Sc.sptr.p, L->Sc.scol.p, L->Sc.sval.p, (const T *)N->x.p, xl,
                          ea, eb, ezH, er, epbc);

@@ -652,7 +652,7 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
     TICK(0);
     if (keep0) { H.h_wdinv0 = w; H.h_A0 = A; }
     // short regular rows (finest level of a P1 operator: ~7 entries on triangles, ~15 on tetrahedra): SELL-64 / fp32 kernels
-    L->fine = A.nnz() <= 20ll * A.n && A.n >= 16384;
+    L->fine = A.nnz() <= (c->dim == 3 ? 20ll : 12ll) * A.n && A.n >= 16384;
     L->sell = L->fine && (A.nnz() <= 12ll * A.n || ncol == 1);
     prevW.swap(curW); curW = w;
     const double lm = L->lmax / 1.1;
