@@ -114,9 +114,14 @@ int cfdh_set_options(cfdh_ctx *c, const cfdh_options *o) {
 
 int cfdh_clear_dirichlet(cfdh_ctx *c) {
   ENTER(c);
-  std::fill(c->h_bcflag.begin(), c->h_bcflag.end(), 0);
-  std::fill(c->h_bcval.begin(), c->h_bcval.end(), 0.0);
-  std::fill(c->h_bcmult.begin(), c->h_bcmult.end(), 0.0);
+  // only the entries some object wrote (the arrays start out zero): O(#boundary vertices) per step, not O(nv)
+  const int st = c->dim + 1;
+  for (int v : c->bc_touched) {
+    c->h_bcflag[v] = 0;
+    for (int i = 0; i < st; i++) { c->h_bcval[(size_t)st * v + i] = 0.0; c->h_bcmult[(size_t)st * v + i] = 0.0; }
+  }
+  c->bc_pending.insert(c->bc_pending.end(), c->bc_touched.begin(), c->bc_touched.end());  // must be reset on the device too
+  c->bc_touched.clear();
   c->n_pbc = 0;
   c->bc_dirty = true;
   c->bc_version++;
@@ -130,6 +135,7 @@ int cfdh_add_dirichlet(cfdh_ctx *c, int field, int64_t n, const int32_t *nodes, 
   const int d = c->dim, st = d + 1;  // per vertex: d velocity components, then the pressure
   for (int64_t k = 0; k < n; k++) {
     const int v = c->perm[nodes[k]];
+    c->bc_touched.push_back(v);
     if (field == 0) {
       for (int i = 0; i < d; i++) {
         c->h_bcflag[v] |= (unsigned char)(1u << i);

@@ -201,6 +201,15 @@ struct cfdh_ctx {
   std::vector<double> h_bcval;          // [nv][3]
   std::vector<double> h_bcmult;         // [nv][3]
   bool bc_dirty = true;
+  // vertices written by cfdh_add_dirichlet since the last clear / since the last upload: clearing and uploading touch these
+  // only (a pulsatile inlet re-sends every object every step; the full arrays are 49 B per vertex)
+  std::vector<int> bc_touched, bc_pending;
+  std::vector<int> bc_mark;            // epoch marker per vertex (de-duplication)
+  int bc_epoch = 0;
+  bool bc_full_upload = true;          // device arrays not initialised yet
+  dbuf<int> bc_uidx;                   // staging of the sparse update
+  dbuf<unsigned char> bc_uflag;
+  dbuf<double> bc_uval, bc_umult;
   int n_pbc = 0;
   dbuf<unsigned char> bcflag;
   dbuf<double> bcval, bcmult;
@@ -384,6 +393,7 @@ int k_scatter_global(cfdh_ctx *c, int n, const int *l2g, const double *loc, doub
 int k_gather_global(cfdh_ctx *c, int n, const int *l2g, const double *glob, double *loc);
 int k_cc_combine(cfdh_ctx *c, int n, double alpha, double beta, const double *t, const double *z, const double *r, const unsigned char *pbc, double *out);
 int k_nullspace_test(cfdh_ctx *c, double *nrm, double *absnrm);
+int k_bc_scatter(cfdh_ctx *c, int n, int ncomp, const int *idx, const unsigned char *flag, const double *val, const double *mult);
 
 // vector ops on [0,n)
 int v_copy(cfdh_ctx *c, int n, const double *x, double *y);

@@ -1962,10 +1962,20 @@ __global__ __launch_bounds__(TPB) void multidot_kernel(int n, const double *__re
       ptr[q] = (v < nvec) ? V + (size_t)v * ld : w;  // v == nvec: w.w ; v > nvec: dummy (discarded)
       acc[q] = 0.0;
     }
-    for (int i = lo + threadIdx.x; i < hi; i += TPB) {
-      const double wi = w[i];
+    // two consecutive entries per lane (16-B loads; lo and the leading dimension are even), odd tail by the last lane
+    const int hi2 = lo + ((hi - lo) & ~1);
+    for (int i = lo + 2 * threadIdx.x; i < hi2; i += 2 * TPB) {
+      const double2 wi = *(const double2 *)(w + i);
 #pragma unroll
-      for (int q = 0; q < MD_G; q++) acc[q] += ptr[q][i] * wi;
+      for (int q = 0; q < MD_G; q++) {
+        const double2 vi = *(const double2 *)(ptr[q] + i);
+        acc[q] += vi.x * wi.x + vi.y * wi.y;
+      }
+    }
+    if (hi2 < hi && threadIdx.x == 0) {
+      const double wi = w[hi2];
+#pragma unroll
+      for (int q = 0; q < MD_G; q++) acc[q] += ptr[q][hi2] * wi;
     }
 #pragma unroll
     for (int q = 0; q < MD_G; q++) {
@@ -2036,16 +2046,25 @@ __global__ __launch_bounds__(TPB) void gs_update_normalize_kernel(int n, const d
   const double s = (nrm2 > 0.0 && nrm2 <= ww) ? sqrt(nrm2) : sqrt(ww);  // cancellation: any positive scale, the caller re-orthogonalises
   const double inv = s > 0.0 ? 1.0 / s : 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *s_out = s;
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-    double a0 = w[i], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  // two consecutive entries per lane (16-B loads: ld is even and all vectors are 16-B aligned); same summation order per entry
+  const int n2 = n & ~1;
+  for (int i = 2 * (blockIdx.x * TPB + threadIdx.x); i < n2; i += 2 * gridDim.x * TPB) {
+    const double2 wi = *(const double2 *)(w + i);
+    double a0 = wi.x, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = wi.y, b1 = 0.0, b2 = 0.0, b3 = 0.0;
     int v = 0;
     for (; v + 4 <= nvec; v += 4) {
-      const double x0 = V[(size_t)v * ld + i], x1 = V[(size_t)(v + 1) * ld + i], x2 = V[(size_t)(v + 2) * ld + i],
-                   x3 = V[(size_t)(v + 3) * ld + i];
-      a0 -= h[v] * x0; a1 -= h[v + 1] * x1; a2 -= h[v + 2] * x2; a3 -= h[v + 3] * x3;
+      const double2 x0 = *(const double2 *)(V + (size_t)v * ld + i), x1 = *(const double2 *)(V + (size_t)(v + 1) * ld + i),
+                    x2 = *(const double2 *)(V + (size_t)(v + 2) * ld + i), x3 = *(const double2 *)(V + (size_t)(v + 3) * ld + i);
+      a0 -= h[v] * x0.x; a1 -= h[v + 1] * x1.x; a2 -= h[v + 2] * x2.x; a3 -= h[v + 3] * x3.x;
+      b0 -= h[v] * x0.y; b1 -= h[v + 1] * x1.y; b2 -= h[v + 2] * x2.y; b3 -= h[v + 3] * x3.y;
     }
-    for (; v < nvec; v++) a0 -= h[v] * V[(size_t)v * ld + i];
-    vn[i] = ((a0 + a1) + (a2 + a3)) * inv;
+    for (; v < nvec; v++) { const double2 xv = *(const double2 *)(V + (size_t)v * ld + i); a0 -= h[v] * xv.x; b0 -= h[v] * xv.y; }
+    *(double2 *)(vn + i) = make_double2(((a0 + a1) + (a2 + a3)) * inv, ((b0 + b1) + (b2 + b3)) * inv);
+  }
+  if (n2 < n && blockIdx.x == 0 && threadIdx.x == 0) {
+    double a0 = w[n2];
+    for (int v = 0; v < nvec; v++) a0 -= h[v] * V[(size_t)v * ld + n2];
+    vn[n2] = a0 * inv;
   }
 }
 int v_gs_update_normalize(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, const double *w, double *vn, double *s_dev) {
@@ -2108,6 +2127,24 @@ int k_nullspace_test(cfdh_ctx *c, double *nrm, double *absnrm) {
   CHK(read_scalars(c, c->red_out.p, 2, s));
   *nrm = sqrt(s[0]);
   *absnrm = sqrt(s[1]);
+  return 0;
+}
+
+// sparse update of the Dirichlet arrays (cfdh_solver.cpp::upload_bc): entry k describes vertex idx[k] completely
+__global__ __launch_bounds__(TPB) void bc_scatter_kernel(int n, int ncomp, const int *__restrict__ idx, const unsigned char *__restrict__ flag,
+                                                         const double *__restrict__ val, const double *__restrict__ mult,
+                                                         unsigned char *__restrict__ bcflag, double *__restrict__ bcval,
+                                                         double *__restrict__ bcmult) {
+  const int k = blockIdx.x * TPB + threadIdx.x;
+  if (k >= n) return;
+  const int v = idx[k];
+  bcflag[v] = flag[k];
+  for (int i = 0; i < ncomp; i++) { bcval[(size_t)ncomp * v + i] = val[(size_t)ncomp * k + i]; bcmult[(size_t)ncomp * v + i] = mult[(size_t)ncomp * k + i]; }
+}
+int k_bc_scatter(cfdh_ctx *c, int n, int ncomp, const int *idx, const unsigned char *flag, const double *val, const double *mult) {
+  hipLaunchKernelGGL(bc_scatter_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, ncomp, idx, flag, val, mult, c->bcflag.p,
+                     c->bcval.p, c->bcmult.p);
+  HIPCHK(c, hipGetLastError());
   return 0;
 }
 

@@ -682,10 +682,39 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
 
 static int upload_bc(cfdh_ctx *c) {
   if (!c->bc_dirty) return 0;
-  HIPCHK(c, hipMemcpyAsync(c->bcflag.p, c->h_bcflag.data(), c->h_bcflag.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->bcval.p, c->h_bcval.data(), sizeof(double) * c->h_bcval.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->bcmult.p, c->h_bcmult.data(), sizeof(double) * c->h_bcmult.size(), hipMemcpyHostToDevice, c->stream));
+  const int st = c->dim + 1;
+  // vertices whose device entries may be stale: cleared since the last upload, or (re)written since
+  c->bc_pending.insert(c->bc_pending.end(), c->bc_touched.begin(), c->bc_touched.end());
+  if ((int)c->bc_mark.size() != c->nv) { c->bc_mark.assign(c->nv, -1); c->bc_full_upload = true; }
+  c->bc_epoch++;
+  size_t K = 0;
+  for (int v : c->bc_pending)
+    if (c->bc_mark[v] != c->bc_epoch) { c->bc_mark[v] = c->bc_epoch; c->bc_pending[K++] = v; }
+  c->bc_pending.resize(K);
+  // bc_touched keeps growing with duplicates when objects are re-added without a clear in between: compact it as well
+  if (c->bc_touched.size() > 4 * (size_t)c->nv) { std::sort(c->bc_touched.begin(), c->bc_touched.end()); c->bc_touched.erase(std::unique(c->bc_touched.begin(), c->bc_touched.end()), c->bc_touched.end()); }
+  if (c->bc_full_upload || K > (size_t)c->nv / 8) {
+    HIPCHK(c, hipMemcpyAsync(c->bcflag.p, c->h_bcflag.data(), c->h_bcflag.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->bcval.p, c->h_bcval.data(), sizeof(double) * c->h_bcval.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->bcmult.p, c->h_bcmult.data(), sizeof(double) * c->h_bcmult.size(), hipMemcpyHostToDevice, c->stream));
+    c->bc_full_upload = false;
+  } else if (K > 0) {
+    // sparse update: (vertex, flag, values, multiplicities) of the K vertices, scattered on the device
+    std::vector<unsigned char> fl(K);
+    std::vector<double> va(K * st), mu(K * st);
+    for (size_t k = 0; k < K; k++) {
+      const int v = c->bc_pending[k];
+      fl[k] = c->h_bcflag[v];
+      for (int i = 0; i < st; i++) { va[k * st + i] = c->h_bcval[(size_t)st * v + i]; mu[k * st + i] = c->h_bcmult[(size_t)st * v + i]; }
+    }
+    HIPCHK(c, c->bc_uidx.upload(c->bc_pending, c->stream));
+    HIPCHK(c, c->bc_uflag.upload(fl, c->stream));
+    HIPCHK(c, c->bc_uval.upload(va, c->stream));
+    HIPCHK(c, c->bc_umult.upload(mu, c->stream));
+    CHK(k_bc_scatter(c, (int)K, st, c->bc_uidx.p, c->bc_uflag.p, c->bc_uval.p, c->bc_umult.p));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->bc_pending.clear();
   c->bc_dirty = false;
   return 0;
 }
