@@ -1963,7 +1963,7 @@ __global__ __launch_bounds__(TPB) void multidot_kernel(int n, const double *__re
       acc[q] = 0.0;
     }
     // two consecutive entries per lane (16-B loads; lo and the leading dimension are even), odd tail by the last lane
-    const int hi2 = lo + ((hi - lo) & ~1);
+    const int hi2 = hi > lo ? lo + ((hi - lo) & ~1) : hi;  // blocks past the end of a short vector own nothing
     for (int i = lo + 2 * threadIdx.x; i < hi2; i += 2 * TPB) {
       const double2 wi = *(const double2 *)(w + i);
 #pragma unroll
