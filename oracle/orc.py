@@ -15,8 +15,8 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "libcfdh_oracle.so")
-    src = os.path.join(_HERE, "cfdh_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, n) for n in ("cfdh_oracle.c", "cfdh_oracle3.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(q) for q in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
 

@@ -194,3 +194,29 @@ def test_backflow_term_d2_equals_2d_twin_and_d3_jacobian_is_derivative():
         e = np.zeros(4 * nv); e[k] = eps
         fd = (pb.assemble(xv + e, un, want_jac=False, apply_bc=False)[0] - pb.assemble(xv - e, un, want_jac=False, apply_bc=False)[0]) / (2 * eps)
         assert np.abs(fd - J[:, k].toarray().ravel()).max() <= 1e-7 * max(1.0, abs(J[:, k]).max())
+
+
+def test_c_restatement_of_the_tet_element_tensors_equals_the_twin():
+    """oracle/cfdh_oracle3.c (scalar loops) vs np_twin_nd.element_tensors (einsum): midpoint and BDF2 coefficients, exterior
+    facets with the ds pair, backflow facets; then a whole assembly through Problem with the C element routine."""
+    from oracle import orc3
+    from cfd_hemodynamic_amd.mesh3d import create_unit_cube
+    rng = np.random.default_rng(4)
+    mesh = create_unit_cube(3)
+    x = mesh.x + 0.03 * rng.standard_normal(mesh.x.shape) * (np.abs(mesh.x - 0.5).max(axis=1) < 0.49)[:, None]
+    nv = len(x)
+    top = np.nonzero(mesh.facet_midpoints()[:, 2] > 1.0 - 1e-9)[0]
+    for scheme in (dict(), dict(theta=1.0, a0=1.5, a1=-2.0, a2=0.5)):
+        for ds, beta in ((True, 0.0), (False, 0.6)):
+            prm = TN.Params(0.03, 1.1, 0.02, (0.2, -0.1, 0.3), ds_terms=ds, **scheme)
+            pb = TN.Problem(x, mesh.cells, mesh.facet_cells, mesh.facet_local, prm)
+            pb.set_boundary_terms(ds, top if beta else None, beta)
+            u, un, un2 = (0.4 * rng.standard_normal((nv, 3)) for _ in range(3))
+            p = rng.standard_normal(nv)
+            un[:, 2] -= 0.3
+            Ft, Jt = TN.element_tensors(x, pb.cells, u, un, p, pb.prm, pb.facet_flags, True, un2)
+            Fc, Jc = orc3.element_tensors(x, pb.cells, u, un, p, pb.prm, pb.facet_flags, True, un2)
+            assert np.abs(Ft - Fc).max() <= 1e-13 * np.abs(Ft).max(), (scheme, ds, beta)
+            assert np.abs(Jt - Jc).max() <= 1e-13 * np.abs(Jt).max(), (scheme, ds, beta)
+            Fc2, none = orc3.element_tensors(x, pb.cells, u, un, p, pb.prm, pb.facet_flags, False, un2)
+            assert none is None and np.array_equal(Fc, Fc2)
