@@ -20,7 +20,7 @@ for kv in sys.argv[5:]:
     opts[k] = float(v) if "." in v or "e" in v else int(v)
 for res in [float(v) for v in sys.argv[1].split(",")]:
     t0 = time.time()
-    sc = StenosisWithTreeSimulation("stabilized_schur", dt, 1.0, grade="moderate", res=res, pulse_amplitude=0.5, quiet=True,
+    sc = StenosisWithTreeSimulation(os.environ.get("C5_SOLVER", "stabilized_schur"), dt, 1.0, grade="moderate", res=res, pulse_amplitude=0.5, quiet=True,
                                     inlet_max_velocity=vmax, options=opts, ramp_time=ramp)
     print("res %g: %d vertices, %d DOF, setup %.1fs" % (res, sc.mesh.num_vertices, 3 * sc.mesh.num_vertices, time.time() - t0), flush=True)
     for k in range(nsteps):
