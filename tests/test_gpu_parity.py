@@ -263,6 +263,64 @@ def test_time_dependent_dirichlet_values():
     assert np.allclose(u[inl], (base * (1.0 + 0.5 * np.sin(2 * np.pi * t_used))).reshape(-1, 2)[inl], atol=1e-14)
 
 
+def test_dirichlet_sets_can_be_replaced_sparse_updates_leave_nothing_stale():
+    """cfdh_clear_dirichlet / cfdh_add_dirichlet touch and upload only the vertices involved (a pulsatile inlet re-sends its
+    objects every step).  Replace the whole Dirichlet set by a different one, append to it without a clear, change values only:
+    after each change the device assembly equals a fresh context's (bitwise) and the oracle's."""
+    case = dfg_case(12)
+    m = case.mesh
+    nv = m.num_vertices
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(3 * nv)
+    un = rng.standard_normal(2 * nv)
+    bnd = np.unique(m.facet_vertices)
+    setA = [(0, bnd[: len(bnd) // 2].astype(np.int32), rng.standard_normal((len(bnd) // 2, 2)))]
+    setB = [(0, bnd[len(bnd) // 3:].astype(np.int32), rng.standard_normal((len(bnd) - len(bnd) // 3, 2))),
+            (1, bnd[:7].astype(np.int32), rng.standard_normal(7))]
+    extra = (0, bnd[5:25].astype(np.int32), rng.standard_normal((20, 2)))   # overlaps setB: multiplicity 2 on those dofs
+
+    def assembled(ctx):
+        ctx.set_state(u_prev=un, p_prev=np.zeros(nv), u=x[: 2 * nv], p=x[2 * nv:])
+        ctx.assemble(True)
+        return np.concatenate(ctx.get_residual()), ctx.get_csr()
+
+    def fresh(bcs):
+        ctx2 = make_ctx(type("C", (), dict(mesh=m, bcs=bcs, dt=case.dt, rho=case.rho, mu=case.mu, f=case.f))())
+        out = assembled(ctx2)
+        ctx2.close()
+        return out
+
+    ctx = make_ctx(type("C", (), dict(mesh=m, bcs=setA, dt=case.dt, rho=case.rho, mu=case.mu, f=case.f))())
+    F, J = assembled(ctx)
+    F0, J0 = fresh(setA)
+    assert np.array_equal(F, F0) and np.array_equal(J.data, J0.data)
+    # replace the set
+    ctx.clear_dirichlet()
+    for fld, nodes, vals in setB:
+        ctx.add_dirichlet(fld, nodes, vals)
+    F, J = assembled(ctx)
+    F0, J0 = fresh(setB)
+    assert np.array_equal(F, F0) and np.array_equal(J.data, J0.data)
+    # append an object without clearing
+    ctx.add_dirichlet(*extra)
+    F, J = assembled(ctx)
+    F0, J0 = fresh(setB + [extra])
+    assert np.array_equal(F, F0) and np.array_equal(J.data, J0.data)
+    # values only (same nodes), as a time-dependent inlet does every step
+    setB2 = [(setB[0][0], setB[0][1], 2.0 * setB[0][2]), setB[1]]
+    ctx.clear_dirichlet()
+    for fld, nodes, vals in setB2:
+        ctx.add_dirichlet(fld, nodes, vals)
+    F, J = assembled(ctx)
+    F0, J0 = fresh(setB2)
+    assert np.array_equal(F, F0) and np.array_equal(J.data, J0.data)
+    O = make_oracle(type("C", (), dict(mesh=m, bcs=setB2, dt=case.dt, rho=case.rho, mu=case.mu, f=case.f))())
+    O.set_un(un)
+    Fo = O.assemble(x)
+    assert np.abs(F - Fo).max() <= 1e-13 * np.abs(Fo).max()
+    ctx.close()
+
+
 # ---------------------------------------------------------------- full-size properties
 @pytest.fixture(scope="module")
 def big():
