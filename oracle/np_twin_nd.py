@@ -355,6 +355,25 @@ class Problem:
             x -= dx
         return x, hist
 
+    def wall_shear_stress(self, xvec, mu=None):
+        """assemble_wss of solverBase.py:163-195: (1/|f|) oint w . Tt ds with T = -sigma(u, p) n, Tt = T - (T.n) n, as a P1 vector
+        field: every exterior facet gives Tt / d to each of its d vertices (the pressure part of T is normal and drops out)."""
+        d, n1 = self.d, self.d + 1
+        u, _ = self.split(xvec)
+        mu = self.prm.mu if mu is None else mu
+        g, vol, _ = geometry(self.x, self.cells)
+        out = np.zeros((self.nv, d))
+        for e, fl in zip(self.facet_cells, self.facet_local):
+            gf = g[e, fl]
+            n = -gf / np.linalg.norm(gf)
+            G = np.einsum("ai,aj->ij", g[e], u[self.cells[e]])          # G_ij = d_i u_j
+            T = -mu * (G + G.T) @ n
+            Tt = T - (T @ n) * n
+            for a in range(n1):
+                if a != fl:
+                    out[self.cells[e, a]] += Tt / d
+        return out.ravel()
+
     def l2_norms(self, xvec):
         u, p = self.split(xvec)
         n1 = self.d + 1

@@ -111,6 +111,8 @@ def test_tet_time_steps_match_twin_on_the_bifurcation():
     interior = np.ones(nv, bool)
     interior[np.unique(mesh.facet_vertices)] = False
     assert np.abs(w).max() > 0 and not w[interior].any()
+    wt = pb.wall_shear_stress(x).reshape(-1, 3)      # twin restatement of assemble_wss (solverBase.py:163-195)
+    assert np.abs(w - wt).max() <= 1e-7 * np.abs(wt).max()
     ctx.close()
 
 

@@ -220,3 +220,17 @@ def test_c_restatement_of_the_tet_element_tensors_equals_the_twin():
             assert np.abs(Jt - Jc).max() <= 1e-13 * np.abs(Jt).max(), (scheme, ds, beta)
             Fc2, none = orc3.element_tensors(x, pb.cells, u, un, p, pb.prm, pb.facet_flags, False, un2)
             assert none is None and np.array_equal(Fc, Fc2)
+
+
+def test_wall_shear_stress_d2_equals_the_c_oracle():
+    """np_twin_nd.Problem.wall_shear_stress (d-generic restatement of solverBase.py:163-195) against orc_wss for triangles."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import dfg_case, make_oracle
+    case = dfg_case(8)
+    m, nv = case.mesh, case.mesh.num_vertices
+    x = np.random.default_rng(0).standard_normal(3 * nv)
+    w2 = np.asarray(make_oracle(case).wall_shear_stress(x)).ravel()
+    pb = TN.Problem(m.x, m.cells, m.facet_cells, m.facet_local, TN.Params(case.dt, case.rho, case.mu, np.array([0.0, 0.0])))
+    wn = pb.wall_shear_stress(x)
+    assert np.abs(w2 - wn).max() <= 1e-13 * np.abs(wn).max()
