@@ -83,7 +83,7 @@ typedef struct cfdh_options {
                              * solves), 0: LOWER.  All are right preconditioners of the same FGMRES. */
   int32_t amg_smooth_degree;
   double amg_smooth_ratio;
-  double amg_theta;         /* strength threshold of the aggregation; < 0 (default): 0.08 for gdim 2, 0.02 for gdim 3 */
+  double amg_theta;         /* strength threshold of the aggregation; < 0 (default): 0.07 for gdim 2, 0.02 for gdim 3 */
   int32_t amg_max_coarse;
   int32_t pc_refresh;       /* 0: adaptive lagging of the Sp hierarchy, n>0: every n steps, -1: every Jacobian */
   int32_t remove_p_mean;    /* nullsp.remove(x_n), stabilized_schur.py:319 */

@@ -5,7 +5,9 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from util import dfg_case, make_ctx
 m = int(sys.argv[1]); nsteps = int(sys.argv[2])
 case = dfg_case(m); nv = case.nv
-for extra in [dict(), dict(cheb_degree=2), dict(cheb_degree=1), dict(cheb_degree=2, amg_smooth_ratio=4.0), dict(amg_theta=0.04), dict(amg_theta=0.15)]:
+variants = [eval(a) for a in sys.argv[3:]] or [dict(), dict(amg_smooth_ratio=4.0), dict(amg_smooth_ratio=6.0), dict(amg_smooth_ratio=12.0), dict(amg_theta=0.06),
+            dict(amg_theta=0.1), dict(amg_max_coarse=500), dict(amg_max_coarse=2000), dict(cc_smooth_degree=3), dict(schur_full=1)]
+for extra in variants:
     ctx = make_ctx(case)
     o = ctx.default_options()
     for k, v in extra.items(): setattr(o, k, v)
