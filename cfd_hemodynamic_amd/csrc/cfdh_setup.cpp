@@ -662,7 +662,8 @@ int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A0, bool singular, in
     // aggregates fall apart (3-D bifurcation, 1.0 M DOF: 216 instead of 92 FGMRES iterations per step)
     // triangles: flat between 0.03 and 0.08 on all four 2-D configurations, degrading from 0.09 on (stenosis: 1132 -> 1759
     // iterations over 12 steps; 0.10 on the bench mesh: 467 -> 1459), tools/theta_scan.py -- 0.07 has the lowest counts on three of the four and keeps clear of that edge
-    const double theta = o.amg_theta >= 0 ? o.amg_theta : (c->dim == 3 ? 0.02 : 0.07);
+    static const double theta_env = getenv("CFDH_AMG_THETA") ? atof(getenv("CFDH_AMG_THETA")) : -1.0;  // tuning hook for the default
+    const double theta = o.amg_theta >= 0 ? o.amg_theta : (theta_env >= 0 ? theta_env : (c->dim == 3 ? 0.02 : 0.07));
     int na = aggregate_host(A, theta, agg);
     TICK(1);
     if (na >= A.n || na < 1) break;  // no coarsening possible
