@@ -794,8 +794,13 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
     st->krylov_its += kits;
     st->ms_solve += wall_ms() - t0;
     if (kreason < 0) { reason = CFDH_DIVERGED_LINEAR_SOLVE; cfdh_fail(c, CFDH_E_DIVERGED, "FGMRES failed (reason %d) after %d iterations", kreason, kits); break; }
+    // adaptive lagging: rebuild when a solve needs 1.5x (+5) the iterations the fresh hierarchy needed.  The reference count
+    // is the LARGEST solve of the step the hierarchy was built in and of the step after it: the solves of one step differ
+    // (the first Newton iteration often only repairs boundary rows in a handful of iterations), and a reference taken from
+    // such a solve made every later one trip the rule -- 16 rebuilds in a row during the start-up ramp of config 5.
     if (c->pc_its_ref == 0) c->pc_its_ref = std::max(kits, 1);
-    else if (o.pc_refresh == 0 && kits > (3 * c->pc_its_ref) / 2 + 5) force_refresh = true;  // adaptive lagging
+    else if (c->steps_since_refresh <= 1) c->pc_its_ref = std::max(c->pc_its_ref, kits);
+    else if (o.pc_refresh == 0 && kits > (3 * c->pc_its_ref) / 2 + 5) force_refresh = true;
     // backtracking line search on 1/2 |F|^2 (Dennis-Schnabel, alpha = 1e-4)
     t0 = wall_ms();
     double lam = 1.0, fnew = 0.0;
