@@ -28,19 +28,20 @@ class LidDriven2DSimulation(Scenario):
             self._mesh = create_unit_square(self.nx, self.nx)
         return self._mesh
 
+    def _velocity_condition(self, where, value):
+        """A BoundaryCondition holding the constant velocity `value` on the boundary facets selected by `where`."""
+        g = Function(self.solver.V)
+        g.x.array.reshape(-1, 2)[:] = value
+        facet_dim = self.mesh.topology.dim - 1
+        bc = BoundaryCondition(g)
+        bc.initTopological(facet_dim, locate_entities_boundary(self.mesh, facet_dim, where))
+        return bc
+
     @property
     def bcu(self):
+        # order matters where the sets touch: the lid excludes the two top corners, which stay no-slip (lid_driven2D.py:33-52)
         if not self._bcu:
-            u_noslip = Function(self.solver.V)
-            u_noslip.x.array[:] = 0
-            fdim = self.mesh.topology.dim - 1
-            bc_noslip = BoundaryCondition(u_noslip)
-            bc_noslip.initTopological(fdim, locate_entities_boundary(self.mesh, fdim, self.walls))
-            u_lid = Function(self.solver.V)
-            u_lid.interpolate(lambda x: np.vstack((np.ones(x.shape[1]), np.zeros(x.shape[1]))))
-            bc_lid = BoundaryCondition(u_lid)
-            bc_lid.initTopological(fdim, locate_entities_boundary(self.mesh, fdim, self.lid))
-            self._bcu = [bc_noslip, bc_lid]
+            self._bcu = [self._velocity_condition(self.walls, (0.0, 0.0)), self._velocity_condition(self.lid, (1.0, 0.0))]
         return self._bcu
 
     @property
