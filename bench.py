@@ -42,6 +42,19 @@ def host_cores():
     return n
 
 
+def kernel_source_sha16():
+    """Fingerprint of the kernel sources (csrc/*.hip, *.cpp, *.hpp, quadrature tables): ties a PMC summary to the code it measured
+    (the GPU box has no .git, so a commit id is not available at run time)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cfd_hemodynamic_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cpp")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def kernel_bytes(ctx):
     """Algorithmic HBM bytes per launch of the instrumented kernels (DESIGN.md section 'Kernels')."""
     nvo, nnzv, nc, spnnz = (ctx.info(k) for k in (0, 3, 2, 4))
@@ -114,13 +127,19 @@ def workload_text(args, sc):
     nv = sc.mesh.num_vertices
     head = {"c3": "dfg_1 (DFG 2D-1, Re=20) block-structured mesh m=%d" % args.m,
             "c2": "lid_driven2D (Re=100) unit square nx=%d" % args.nx,
-            "c4": "stenosis grade moderate (L=138, R_in=1.57, R_out=1.2, x_sten=30, severity .5, slope .3), ny=%d, inlet v_max=%g mm/s, p=0 outlet" % (args.ny, args.v_max),
+            "c4": "stenosis \"moderate\" = the reference's effective geometry for every grade (L=138, R_in=1.57, R_out=1.2, x_sten=30, severity .567, slope .4), ny=%d, inlet v_max=%g mm/s, p=0 outlet" % (args.ny, args.v_max),
             "c5": "stenosis_with_tree grade moderate (L=0.03, H=0.003, severity .5, slope .5; 3-generation Murray tree, 8 outlets p=0), "
                   "res=%g, pulsatile inlet v_max (1 + 0.5 sin 2 pi t) with a (1 - cos(pi t / %g)) / 2 start-up ramp, v_max=%g" % (args.res, args.ramp, args.v_max),
             "c5b": "simple_bifurcation (3-D, tetrahedra; Re=%s, inlet u_y = %g (1 - (r/r_in)^2), p = 0 at both outlets; remove_p_mean=0), voxel-tet mesh res=%g" % (
                 ("%.1f" % sc.Re) if args.config == "c5b" else "-", args.v_max, args.res3)}[args.config]
     return "%s: %d vertices, %d P1/P1 DOF, dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)" % (
         head, nv, (sc.mesh.geometry.dim + 1) * nv, args.dt)
+
+
+def run_length(args):
+    """Steps of the config's own run: T = 1.0 at its dt (dfg_1.py / BASELINE configs: 100 steps at dt 0.01, 1000 at 0.001); the
+    lid-driven cavity runs to T = 10."""
+    return int(round((10.0 if args.config == "c2" else 1.0) / args.dt))
 
 
 def step_hook(sc, k, dt):
@@ -138,6 +157,40 @@ def functionals(args, sc):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a child process (one rank per GPU, RCCL inside libcfdh.so), pass rank 0's JSON line through, return its exit code.
+    Nothing in this process has initialised the GPU (device_count() does not, on this image)."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < n and os.environ.get("CFDH_SHARE_GPU") != "1":
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (CFDH_SHARE_GPU=1 rehearses the N-rank path on fewer devices)\n" % (n, ndev))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            sys.stderr.write(ln + "\n")
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit code %d%s)\n" % (n, proc.returncode, "" if line else ", no JSON line"))
+        return proc.returncode or 1
+    if json.loads(line).get("n_gpus") != n:
+        sys.stderr.write("bench.py: the launched job reported n_gpus != %d\n" % n)
+        return 1
+    print(line)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,7 +200,7 @@ def main():
     ap.add_argument("--res3", type=float, default=2.0e-4, help="c5b: voxel size of the 3-D bifurcation (2e-4: 256 k vertices, 1.03 M DOF; 1e-4: 1.95 M vertices, 7.8 M DOF)")
     ap.add_argument("--m", type=int, default=200, help="c3: DFG mesh parameter (m=200: 336,273 vertices, 1,008,819 DOF)")
     ap.add_argument("--nx", type=int, default=288, help="c2: cells per side")
-    ap.add_argument("--ny", type=int, default=115, help="c4: cells across the inlet (115: 678,136 vertices, 2.03 M DOF)")
+    ap.add_argument("--ny", type=int, default=115, help="c4: cells across the inlet (115: 678,832 vertices, 2.04 M DOF)")
     ap.add_argument("--res", type=float, default=7.3e-6, help="c5: cell size (7.3e-6: 2.73 M vertices, 8.18 M DOF)")
     ap.add_argument("--v-max", type=float, default=None, help="inlet peak velocity (c4 default 100 mm/s, c5 default 0.05 m/s: Re = 45)")
     ap.add_argument("--ramp", type=float, default=0.03, help="c5: start-up ramp of the inlet (s); 0 = impulsive start")
@@ -156,6 +209,7 @@ def main():
     ap.add_argument("--parity-steps", type=int, default=None,
                     help="tightly converged steps compared with the oracle (default 2; c5: 0 = skipped, a tight oracle step at 8 M DOF "
                          "takes minutes -- tests/test_gpu_configs.py does that comparison on a coarse mesh of the same domain)")
+    ap.add_argument("--parity-res", type=float, default=2.0e-4, help="c5: cell size of the coarse mesh of the same domain the tight parity leg runs on")
     ap.add_argument("--prof-steps", type=int, default=2, help="extra steps with HIP-event kernel timing (after the timed region)")
     ap.add_argument("--host-loop-steps", type=int, default=10, help="extra steps with the reference's literal state-copy loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,12 +225,15 @@ def main():
     if args.parity_steps is None:
         args.parity_steps = 0 if args.config == "c5" else 2
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the N ranks ourselves (before anything touches the GPU) and relay rank 0's line
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): refusing to report a line for a different rank count" % (world, args.gpus))
 
     import numpy as np
     import torch
@@ -224,11 +281,18 @@ def main():
     its_newton, its_krylov = [], []
     solver.initStressForm()
     kstep = 0
+    # wall-clock and preconditioner set-up time of every step from t = 0 on: the first step carries the build of the AMG
+    # hierarchies (and the hipGraph captures), which the steady-state `value` does not show -- `end_to_end_steps_per_s` does
+    step_wall, step_pc_ms = [], []
     for _ in range(args.warmup):
+        tw = time.perf_counter()
         step_hook(sc, kstep, dt)
         solver.solveStep()
         solver.assemble_wss()
         solver.advance()
+        torch.cuda.synchronize()
+        step_wall.append(time.perf_counter() - tw)
+        step_pc_ms.append(solver.last_stats.ms_pc_setup)
         kstep += 1
     sync_all()
     ctx.profile_reset()  # zero the communication / synchronisation counters
@@ -248,8 +312,11 @@ def main():
         ms_solve += st.ms_solve
         ms_pc += st.ms_pc_setup
         pc_rebuilds += st.pc_refreshes
+        step_pc_ms.append(st.ms_pc_setup)
     sync_all()
     elapsed = time.perf_counter() - t0
+    if not step_wall:  # --warmup 0: the first timed step is the first step of the run
+        step_wall.append(elapsed / args.steps + 1e-3 * step_pc_ms[0])
     counters = {k: ctx.info(i) for k, i in (("allreduce", 13), ("halo", 14), ("host_sync", 15), ("krylov", 16), ("allgather", 17))}
     comm_size = ctx.info(18)
     if dist is not None:
@@ -302,15 +369,23 @@ def main():
         kern.sort(key=lambda k: -k["total_ms"])
         if kern:
             d = kern[0]
-            traffic = None
+            # HBM traffic of the PMC counters: collected by tools/profile_pmc.sh in separate rocprofv3 --pmc passes (it cannot be
+            # measured inside this run) and accepted only if it was taken with EXACTLY the kernel sources of this run
+            traffic, traffic_note = None, "no PMC summary for this workload"
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc) and args.config == "c3" and args.m == 200:
                 try:
-                    traffic = json.load(open(pmc)).get("per_launch_bytes", {}).get(d["kernel"])
-                except Exception:
-                    traffic = None
+                    rec = json.load(open(pmc))
+                    if rec.get("kernel_source_sha16") == kernel_source_sha16():
+                        traffic = rec.get("per_launch_bytes", {}).get(d["kernel"])
+                        traffic_note = "profiles/pmc_traffic.json, kernel sources %s" % rec.get("kernel_source_sha16")
+                    else:
+                        traffic_note = "profiles/pmc_traffic.json is stale (taken with kernel sources %s, this run has %s): not reported" % (
+                            rec.get("kernel_source_sha16"), kernel_source_sha16())
+                except Exception as e:
+                    traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
             roof = {"bound": "hbm", "kernel": d["kernel"], "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "avg_us": d["avg_us"],
+                    "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note, "avg_us": d["avg_us"],
                     "algorithmic_bytes": d["algorithmic_MB"] * 1e6, "empty_event_pair_us": ovh_us}
 
     label = {"c3": "dfg_1 ~1M DOF", "c2": "lid_driven2D ~250k DOF", "c4": "stenosis moderate ~2M DOF",
@@ -342,14 +417,23 @@ def main():
         "per_krylov_iteration": {"allreduce": counters["allreduce"] / kits, "halo_exchange": counters["halo"] / kits,
                                  "allgather": counters["allgather"] / kits, "host_sync": counters["host_sync"] / kits},
         "setup_s": t_setup,
-        # the reference's literal loop `u_prev.x.array[:] = u_sol.x.array[:]` (scenario.py:306-307); since the lazy
-        # array proxy maps that idiom to a device copy no field crosses PCIe any more (key kept for comparability)
-        "pcie_inclusive_steps_per_s": literal_rate,
+        # the reference's literal loop `u_prev.x.array[:] = u_sol.x.array[:]` (scenario.py:306-307): the lazy array proxy maps
+        # that idiom to a device copy, so no field crosses PCIe in it
         "literal_reference_loop_steps_per_s": literal_rate,
         "results": results,
         "roofline": roof,
         "kernels": kern,
     }
+    # The config's own run, end to end: T / dt steps from t = 0 INCLUDING the first step's preconditioner build (measured:
+    # wall-clock of step 1 of this run) -- next to the steady-state `value`.  `hierarchy_build_s` = preconditioner set-up
+    # time of all steps before the timed region (the AMG hierarchies are built in step 1 and lagged after).
+    n_run = run_length(args)
+    t_first = step_wall[0]
+    out["hierarchy_build_s"] = 1e-3 * sum(step_pc_ms[:max(args.warmup, 1)])
+    out["first_step_s"] = t_first
+    out["run_length_steps"] = n_run
+    out["end_to_end_steps_per_s"] = n_run / (t_first + (n_run - 1) * elapsed / args.steps)
+    out["end_to_end_steps_per_s_incl_setup"] = n_run / (t_setup + t_first + (n_run - 1) * elapsed / args.steps)
     if args.config == "c3":
         out["drag_coefficient"], out["lift_coefficient"], out["velocity_l2"] = results["drag"], results["lift"], results["velocity_l2"]
 
@@ -367,7 +451,7 @@ def main():
         mod = types.ModuleType("cfd_hemodynamic_amd.solvers._oracle_double")
         mod.Solver = oracle_solver.Solver
         sys.modules["cfd_hemodynamic_amd.solvers._oracle_double"] = mod
-        cores = min(host_cores(), 16)
+        cores = host_cores()  # all host cores this process may use (stated in the line)
         os.environ["CFDH_ORACLE_THREADS"] = str(cores)
         bdf2 = args.solver == "stabilized_schur_bdf2"
         # same Newton / FGMRES / Cahouet-Chabard + AMG algorithm and tolerances; FULL Schur factorisation, which is
@@ -429,6 +513,23 @@ def main():
                     s_.solver.solveStep()
                     s_.solver.advance()
             out["parity"] = dict(compare(sc3, osc3), step=args.parity_steps,
+                                 tolerances="steps from rest, both sides snes_rtol 1e-12 / ksp_rtol 1e-10 (oracle pc_kind=2)")
+            del sc3, osc3
+        elif args.config == "c5":
+            # a tight oracle step at 8 M DOF takes minutes: the tight comparison of this config runs on a coarse mesh of the
+            # SAME domain, boundary data and dt (same scenario class, res = --parity-res)
+            import copy
+            ca = copy.copy(args)
+            ca.res = args.parity_res
+            sc3 = make_scenario(ca, args.solver, device=local_rank, options=dict(TIGHT))
+            osc3 = make_scenario(ca, "_oracle_double", pc_kind=2, options=dict(TIGHT), bdf2=bdf2)
+            osc3.solver.O.set_threads(cores)
+            for k in range(3):
+                for s_ in (sc3, osc3):
+                    step_hook(s_, k, dt)
+                    s_.solver.solveStep()
+                    s_.solver.advance()
+            out["parity"] = dict(compare(sc3, osc3), step=3, mesh="coarse mesh of the same domain: res=%g, %d vertices" % (ca.res, sc3.mesh.num_vertices),
                                  tolerances="steps from rest, both sides snes_rtol 1e-12 / ksp_rtol 1e-10 (oracle pc_kind=2)")
             del sc3, osc3
 

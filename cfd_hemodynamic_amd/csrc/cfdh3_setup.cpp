@@ -210,10 +210,8 @@ int cfdh_build_mesh3(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, con
   HIPCHK(c, c->a3_inc_cell.upload(inc_cell, s));
   HIPCHK(c, c->a3_inc_row.upload(inc_row, s));
   HIPCHK(c, c->a3_inc_slots.upload(inc_slots, s));
-  {
-    std::vector<unsigned char> cown(nc, 1);
-    HIPCHK(c, c->cell_owned.upload(cown, s));
-  }
+  std::vector<unsigned char> cown(nc, 1);  // lives until the stream synchronisation at the end of this function
+  HIPCHK(c, c->cell_owned.upload(cown, s));
   if (c->nfac) {
     HIPCHK(c, c->d_fac_cell.upload(c->fac_cell, s));
     HIPCHK(c, c->d_fac_local.upload(c->fac_local, s));

@@ -91,7 +91,7 @@ int cfdh_set_params(cfdh_ctx *c, double dt, double rho, double mu, double mu_fac
   if (!(dt > 0) || !(rho > 0) || !(mu > 0)) return cfdh_fail(c, CFDH_E_ARG, "dt, rho, mu must be positive");
   const bool changed = !c->params_set || dt != c->dt || rho != c->rho || mu != c->mu;
   c->dt = dt; c->rho = rho; c->mu = mu; c->muf = mu_facet;
-  c->f[0] = f ? f[0] : 0.0; c->f[1] = f ? f[1] : 0.0; c->f[2] = f ? f[2] : 0.0;
+  c->f[0] = f ? f[0] : 0.0; c->f[1] = f ? f[1] : 0.0; c->f[2] = (f && c->dim == 3) ? f[2] : 0.0;
   c->params_set = true;
   if (changed) { c->mom_valid = false; c->pc_valid = false; }
   return 0;

@@ -65,6 +65,12 @@ struct dbuf {
     return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
   }
   hipError_t zero(hipStream_t s) { return n ? hipMemsetAsync(p, 0, n * sizeof(T), s) : hipSuccess; }
+  void adopt(dbuf &o) {  // take over o's allocation
+    if (&o == this) return;
+    release();
+    p = o.p; n = o.n;
+    o.p = nullptr; o.n = 0;
+  }
 };
 
 struct CsrHost {
@@ -261,6 +267,9 @@ struct cfdh_ctx {
   // kernel of the pressure cycle instead of a kernel of its own
   struct Epilogue { bool on = false, done = false; double alpha = 0, beta = 0; const double *zH = nullptr, *r = nullptr; const unsigned char *pbc = nullptr; double *out = nullptr; } epi;
   std::vector<double> h_Lval, h_Ml;  // P1 stiffness on the vertex graph, lumped mass (geometry only)
+  dbuf<double> d_Lval, d_Ml;         // device copies (device-side preconditioner set-up)
+  dbuf<double> amg_rand;             // start vector of the spectral-bound power iterations (device-side set-up)
+  double ms_pc_build_dev = 0;        // time spent in the last device-side build (verbose / tests)
   long long bc_version = 0;
   // replicated global pressure space (multi-rank pc_type 1)
   int gp_n = 0;                       // global vertex count (0: not set, pressure solve is rank-local)
@@ -351,6 +360,14 @@ int cfdh_build_mesh(cfdh_ctx *c, int64_t nv, int64_t nvo, int64_t nc, const int3
 int cfdh_amg_setup(cfdh_ctx *c, AmgHier &H, const CsrHost &A, bool singular, int ncol);
 int cfdh_level_setup(cfdh_ctx *c, AmgLevel &L, const CsrHost &A, double ratio, int ncol, std::vector<double> *w_out = nullptr);
 int cfdh_upload_csr(cfdh_ctx *c, const CsrHost &H, CsrDev &D, const std::vector<double> *colw = nullptr, int parts = CFDH_UP_CSR | CFDH_UP_SELL);
+int cfdh_aggregate_host_csr(const CsrHost &A, double theta, std::vector<int> &agg);
+
+// ---- device-side hierarchy set-up (cfdh_amg_dev.hip) ---------------------------------
+bool cfdh_amg_dev_enabled(const cfdh_ctx *c);  // fused Jacobi cycle requested and CFDH_AMG_HOST unset
+int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int ncol);   // A0 (device CSR) is consumed
+int cfdh_level_setup_dev(cfdh_ctx *c, AmgLevel &L, CsrDev &A, double ratio, int ncol);  // A is consumed
+int cfdh_proxy_dev(cfdh_ctx *c, CsrDev &out);                       // scalar proxy of A00 on the owned vertices
+int cfdh_cc_h_dev(cfdh_ctx *c, double alpha, double beta, CsrDev &out);  // H = (I + a'T) M_l + b' A11 (rows of ccPbc & 1: identity)
 
 // ---- tetrahedra (cfdh3_setup.cpp, cfdh3_kernels.hip) -------------------------------
 #define CFDH3_MAX_SLOTS 320   // value slots (16 doubles each) accumulated in LDS per assembly workgroup

@@ -432,6 +432,8 @@ static int aggregate_host(const CsrHost &A, double theta, std::vector<int> &agg)
   return na;
 }
 
+int cfdh_aggregate_host_csr(const CsrHost &A, double theta, std::vector<int> &agg) { return aggregate_host(A, theta, agg); }
+
 // C = A * B (Gustavson, sorted output columns)
 static void spgemm_host(const CsrHost &A, const CsrHost &B, CsrHost &C) {
   C.n = A.n; C.m = B.m;

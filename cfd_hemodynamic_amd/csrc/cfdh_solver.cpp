@@ -302,6 +302,97 @@ static int build_cc_host(cfdh_ctx *c) {
   return 0;
 }
 
+// The same preconditioner data built where the Jacobian lives (cfdh_amg_dev.hip): no download of the blocks, sparse
+// products / aggregation / formats by kernels.  Single-rank contexts; a partitioned run keeps the host build (ghost rows and
+// the replicated pressure space are host data structures).
+static int upload_csr_plain(cfdh_ctx *c, const CsrHost &H, CsrDev &D) {
+  D.n = H.n; D.m = H.m; D.nnz = H.nnz();
+  HIPCHK(c, D.rowptr.upload(H.rowptr, c->stream));
+  HIPCHK(c, D.col.upload(H.col, c->stream));
+  HIPCHK(c, D.val.upload(H.val, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+static int build_cc_dev(cfdh_ctx *c) {
+  const int nvo = c->nvo;
+  const std::vector<int> &vp = c->h_vptr, &vc = c->h_vcol;
+  const double t0 = wall_ms();
+  c->ras = false;
+  {
+    CsrDev Ah;
+    CHK(cfdh_proxy_dev(c, Ah));
+    CHK(cfdh_amg_setup_dev(c, c->hA, Ah, false, c->dim));
+  }
+  const double t1 = wall_ms();
+  // pressure Laplacian hierarchy: geometry and Dirichlet set only (see build_cc_host for the pbc bits)
+  std::vector<unsigned char> pbc(nvo);
+  const unsigned pbit = 1u << c->dim, umask = pbit - 1u;
+  for (int i = 0; i < nvo; i++) pbc[i] = (c->h_bcflag[i] & pbit) ? 1 : 0;
+  if (!c->ds_terms)
+    for (int k = 0; k < c->nfac; k++) {
+      const int e = c->fac_cell[k], fl = c->fac_local[k], n1 = c->dim + 1;
+      bool fixed = true;
+      for (int q = 0; q < n1; q++) if (q != fl) fixed = fixed && (c->h_bcflag[c->h_cells[(size_t)n1 * e + q]] & umask) == umask;
+      if (fixed) continue;
+      for (int q = 0; q < n1; q++) {
+        const int v = c->h_cells[(size_t)n1 * e + q];
+        if (q != fl && v < nvo) pbc[v] |= 2;
+      }
+    }
+  if (!c->hL.valid || c->hL_pbc != pbc || c->hL_singular != c->singular) {
+    CsrHost Lh;
+    Lh.n = Lh.m = nvo;
+    Lh.rowptr.assign(nvo + 1, 0);
+    Lh.col.reserve(c->nnzv); Lh.val.reserve(c->nnzv);
+    bool any_pbc = false;
+    for (int i = 0; i < nvo; i++) {
+      any_pbc |= pbc[i] != 0;
+      if (pbc[i]) { Lh.col.push_back(i); Lh.val.push_back(1.0); }
+      else
+        for (int k = vp[i]; k < vp[i + 1]; k++) {
+          const int w = vc[k];
+          if (w >= nvo || pbc[w]) continue;
+          Lh.col.push_back(w); Lh.val.push_back(c->h_Lval[k]);
+        }
+      Lh.rowptr[i + 1] = (int)Lh.col.size();
+    }
+    CsrDev Ld;
+    CHK(upload_csr_plain(c, Lh, Ld));
+    CHK(cfdh_amg_setup_dev(c, c->hL, Ld, c->singular != 0 || !any_pbc, 1));
+    c->hL_pbc = pbc;
+    c->hL_singular = c->singular;
+    std::vector<double> ml(nvo);
+    for (int i = 0; i < nvo; i++) ml[i] = pbc[i] ? 0.0 : c->h_Ml[i];
+    HIPCHK(c, c->ccMl.upload(ml, c->stream));
+    HIPCHK(c, c->ccPbc.upload(pbc, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  const double t2 = wall_ms();
+  c->cc_alpha = c->rho * c->ts_a[0] / (c->ts_theta * c->dt);
+  c->cc_beta = c->mu;
+  {
+    CsrDev Hd;
+    CHK(cfdh_cc_h_dev(c, c->cc_alpha, c->cc_beta, Hd));
+    CHK(cfdh_level_setup_dev(c, c->Hlev, Hd, 8.0, 1));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->ms_pc_build_dev = wall_ms() - t0;
+  if (c->opt.verbose)
+    fprintf(stderr, "[cfdh] preconditioner built on the device: velocity hierarchy %.1f ms, pressure Laplacian %.1f ms, H %.1f ms\n", t1 - t0, t2 - t1,
+            wall_ms() - t2);
+  return 0;
+}
+static int build_cc(cfdh_ctx *c) {
+  if (c->nranks == 1 && cfdh_amg_dev_enabled(c)) {
+    const int rc = build_cc_dev(c);
+    if (rc == 0) return 0;
+    // the device build gave up (a product row beyond its tables, a zero pivot): keep the message, build on the host
+    if (c->opt.verbose) fprintf(stderr, "[cfdh] device-side hierarchy set-up failed (%s): host build\n", c->err.c_str());
+    c->hL.clear(); c->hA.clear();
+  }
+  return build_cc_host(c);
+}
+
 // refresh the parts of the preconditioner that follow the current Jacobian:
 // always the Jacobi diagonal and the spectral bound of D^-1 A00; the Sp
 // hierarchy only when asked (lagged preconditioner)
@@ -311,7 +402,7 @@ int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
   if (c->opt.pc_type == 1) {
     if (refresh_amg || !c->pc_valid) {
       c->pc_graph_valid = false;
-      CHK(build_cc_host(c));
+      CHK(build_cc(c));
       c->pc_valid = true;
       c->pc_its_ref = 0;
       c->steps_since_refresh = 0;
@@ -693,6 +784,9 @@ static int upload_bc(cfdh_ctx *c) {
   c->bc_pending.resize(K);
   // bc_touched keeps growing with duplicates when objects are re-added without a clear in between: compact it as well
   if (c->bc_touched.size() > 4 * (size_t)c->nv) { std::sort(c->bc_touched.begin(), c->bc_touched.end()); c->bc_touched.erase(std::unique(c->bc_touched.begin(), c->bc_touched.end()), c->bc_touched.end()); }
+  // staging of the sparse update: declared here so that they outlive the stream synchronisation below
+  std::vector<unsigned char> fl;
+  std::vector<double> va, mu;
   if (c->bc_full_upload || K > (size_t)c->nv / 8) {
     HIPCHK(c, hipMemcpyAsync(c->bcflag.p, c->h_bcflag.data(), c->h_bcflag.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->bcval.p, c->h_bcval.data(), sizeof(double) * c->h_bcval.size(), hipMemcpyHostToDevice, c->stream));
@@ -700,8 +794,7 @@ static int upload_bc(cfdh_ctx *c) {
     c->bc_full_upload = false;
   } else if (K > 0) {
     // sparse update: (vertex, flag, values, multiplicities) of the K vertices, scattered on the device
-    std::vector<unsigned char> fl(K);
-    std::vector<double> va(K * st), mu(K * st);
+    fl.resize(K); va.resize(K * st); mu.resize(K * st);
     for (size_t k = 0; k < K; k++) {
       const int v = c->bc_pending[k];
       fl[k] = c->h_bcflag[v];

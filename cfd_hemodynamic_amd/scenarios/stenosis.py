@@ -40,16 +40,19 @@ class StenosisSimulation(Scenario):
     def __init__(self, solver_name, dt, T, f: tuple[float, float] = (0, 0), grade="severe", *, rho=1.06e-3, mu=3.5e-3,
                  ny=None, res=0.15, L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, x_position_stenosis=None, severity=None,
                  slope=None, tension=0.5, v_max=None, outlet_pressure=0.0, **solver_kwargs):
-        """Geometry defaults of stenosis.py:60-69 (L 138, R_in 1.57, R_out 1.2, stenosis at x = 30, res 0.15); `grade`
-        selects severity / slope unless they are given (:71-74).  `ny` (cells across the inlet) replaces `res` as the
-        resolution parameter of the structured mesh: ny = round(2 R_in / res) when not given."""
+        """Geometry defaults of stenosis.py:60-69 (L 138, R_in 1.57, R_out 1.2, stenosis at x = 30, res 0.15,
+        severity 0.567, slope 0.4).  The reference writes those defaults into its mesh options BEFORE the grade
+        table is consulted (:70-77: `if k not in self.mesh_options`), so `grade` never takes effect there: every
+        grade builds the 0.567 / 0.4 throat unless severity / slope are passed explicitly.  That effective behaviour
+        is reproduced (the table is kept as data, as in the reference).  `ny` (cells across the inlet) replaces `res`
+        as the resolution parameter of the structured mesh: ny = round(2 R_in / res) when not given."""
         self._mesh = None
         self._ft = None
         self._bcu = None
         self._bcp = None
-        g = self.stenosis_grades.get(grade, self.stenosis_grades["severe"])
-        self.severity = g["severity"] if severity is None else severity
-        self.slope = g["slope"] if slope is None else slope
+        self.grade = grade  # accepted and, like in the reference, without effect on the geometry (see above)
+        self.severity = 0.567 if severity is None else severity
+        self.slope = 0.4 if slope is None else slope
         self.tension = tension
         self.ny = int(ny) if ny is not None else max(4, int(round(2.0 * R_in / res)))
         self.L, self.R_in, self.R_out = L, R_in, R_out

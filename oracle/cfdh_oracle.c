@@ -1430,10 +1430,20 @@ int orc_solve_step(orc_ctx *c, double *xv, const orc_opts *o, orc_stats *st) {
   {
     /* nullsp.test(A): |J n| < 1e-7 for the normalised constant-pressure vector n.  An open outlet
      * (free velocity + the ds terms of :79) makes the system regular even without a pressure condition. */
+    /* One criterion in the product (csrc/cfdh_solver.cpp), here and in np_twin_nd.py: PETSc's absolute bound AND
+     * |J n| <= 1e-6 | |J| n | -- the absolute bound alone is passed by ANY matrix on a mesh in metres with millimetre
+     * cells (a deviation from MatNullSpaceTest where the two disagree). */
     double *nvec = (double *)calloc(n, sizeof(double)), *yv = (double *)malloc(sizeof(double) * n);
     for (int i = 0; i < nv; i++) nvec[nu + i] = 1.0 / sqrt((double)nv);
     blk_mult(c, 0, nvec, yv);
-    singular = vnorm(n, yv) < 1e-7;
+    double an2 = 0.0;
+    for (int r = 0; r < n; r++) {
+      double a = 0.0;
+      for (int k = c->rowptr[r]; k < c->rowptr[r + 1]; k++) a += fabs(c->val[k]) * nvec[c->col[k]];
+      an2 += a * a;
+    }
+    const double jn = vnorm(n, yv);
+    singular = jn < 1e-7 && jn <= 1e-6 * sqrt(an2);
     free(nvec); free(yv);
     if (singular != c->singular) { c->singular = singular; c->amg_valid = 0; }
   }

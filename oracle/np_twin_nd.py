@@ -336,9 +336,11 @@ class Problem:
             if singular is None:
                 # constant-pressure null vector?  Not with a pressure condition, and not with a do-nothing outlet either (the
                 # weak form without the ds pair fixes the pressure level): decided on the matrix, relative to |J| e
+                # (the product's criterion, csrc/cfdh_solver.cpp: PETSc's absolute bound on the normalised vector AND a relative one)
                 e = np.zeros(self.ndof)
-                e[self.nu:] = 1.0
-                singular = (not self.isbc[self.nu:].any()) and np.linalg.norm(J @ e) <= 1e-9 * np.linalg.norm(abs(J) @ e)
+                e[self.nu:] = 1.0 / np.sqrt(self.ndof - self.nu)
+                jn = np.linalg.norm(J @ e)
+                singular = bool(jn < 1e-7 and jn <= 1e-6 * np.linalg.norm(abs(J) @ e))
             fn = np.linalg.norm(F)
             hist.append(fn)
             if fn <= atol or (it > 0 and fn <= rtol * hist[0]):

@@ -254,7 +254,7 @@ def test_config4_stenosis_partitioned_over_4_ranks_at_full_size(tmp_path):
         subprocess.check_call(["make", "-C", os.path.join(HERE, "fake_rccl"), "-s"])
     tight = dict(snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-9)
     ref = StenosisSimulation("stabilized_schur", 0.01, 0.015, grade="moderate", ny=115, v_max=100.0, quiet=True, options=tight)
-    assert 3 * ref.mesh.num_vertices == 2034408
+    assert 3 * ref.mesh.num_vertices == 2036496
     ref.solve(None)
     ref_krylov = sum(st.krylov_its for _, st in ref.step_stats)
     u0, p0 = np.asarray(ref.solver.u_sol.x.array).copy(), np.asarray(ref.solver.p_sol.x.array).copy()
