@@ -127,8 +127,9 @@ struct AOpImwDA {
   MatV A;
   const double *dinv;
   double omega;
+  const int *agg;  // rows of unknowns outside every aggregate stay empty (no coarse correction), as in the host build
   __device__ int begin(int i) const { return A.rp[i]; }
-  __device__ int end(int i) const { return A.rp[i + 1]; }
+  __device__ int end(int i) const { return agg[i] >= 0 ? A.rp[i + 1] : A.rp[i]; }
   __device__ int col(int k) const { return A.col[k]; }
   __device__ double val(int i, int k, int j) const { return (i == j ? 1.0 : 0.0) - omega * dinv[i] * A.val[k]; }
 };
@@ -174,13 +175,20 @@ constexpr int NBIN = 6;
 __global__ __launch_bounds__(TPB) void bin_rows_kernel(int n, const int *__restrict__ size, int merge45, int *__restrict__ lists,
                                                        int *__restrict__ cnt) {
   const int i = blockIdx.x * TPB + threadIdx.x;
-  if (i >= n) return;
-  const int s = size[i];
-  if (s <= 0) return;  // empty row: nothing to compute
-  int b = s <= 24 ? 0 : (s <= 96 ? 1 : (s <= 384 ? 2 : (s <= 1536 ? 3 : (s <= 6144 ? 4 : 5))));
+  const int s = i < n ? size[i] : 0;
+  int b = s <= 0 ? -1 : (s <= 24 ? 0 : (s <= 96 ? 1 : (s <= 384 ? 2 : (s <= 1536 ? 3 : (s <= 6144 ? 4 : 5)))));  // -1: empty row, nothing to compute
   if (merge45 && b == 4) b = 5;
-  const int pos = atomicAdd(&cnt[b], 1);
-  lists[(size_t)b * n + pos] = i;
+  // one atomic per wavefront and class (a counter per class is a single hot address: per-row atomics serialise at the L2,
+  // 4 ms for the 336 k short rows of a finest-level product)
+  const int lane = threadIdx.x & 63;
+  for (int q = 0; q < NBIN; q++) {
+    const unsigned long long m = __ballot(b == q);
+    if (m == 0) continue;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&cnt[q], __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (b == q) lists[(size_t)q * n + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+  }
 }
 __global__ __launch_bounds__(TPB) void rowlen_kernel(int n, const int *__restrict__ rp, int *__restrict__ len) {
   const int i = blockIdx.x * TPB + threadIdx.x;
@@ -251,6 +259,64 @@ __global__ __launch_bounds__(64) void spgemm_hash_kernel(const int *__restrict__
   bitonic_sort<TS, true>(keys, vals, lane);
   const int base = Crp[i], cnt = Crp[i + 1] - base;
   for (int t = lane; t < cnt; t += 64) { Ccol[base + t] = keys[t]; Cval[base + t] = vals[t]; }
+}
+
+// Short rows (at most 24 products: the prolongator and A P on the finest level, hundreds of thousands of rows): eight lanes
+// per row, 32 rows per workgroup, 32-slot tables -- a wavefront per row would be all launch overhead there.
+template <bool NUM, class AOp, class BOp>
+__global__ __launch_bounds__(256) void spgemm_small_kernel(const int *__restrict__ rows, const int *__restrict__ nrows, AOp A, BOp B,
+                                                           int *__restrict__ Crp, int *__restrict__ Ccol, double *__restrict__ Cval) {
+  constexpr int TS = 32;
+  __shared__ int keys[32][TS];
+  __shared__ double vals[NUM ? 32 : 1][NUM ? TS : 1];
+  const int g = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+  const int idx = blockIdx.x * 32 + g;
+  const bool live = idx < *nrows;
+  const int i = live ? rows[idx] : 0;
+  int *kk = keys[g];
+  double *vv = NUM ? vals[g] : nullptr;
+  for (int t = l8; t < TS; t += 8) { kk[t] = -1; if (NUM) vv[t] = 0.0; }
+  __syncthreads();
+  if (live)
+    for (int ka = A.begin(i), ae = A.end(i); ka < ae; ka++) {
+      const int k = A.col(ka);
+      const double av = NUM ? A.val(i, ka, k) : 0.0;
+      for (int q = B.begin(k) + l8, qe = B.end(k); q < qe; q += 8) {
+        const int j = B.col(q);
+        unsigned h = ((unsigned)j * 2654435761u) >> 7;
+        for (;;) {  // at most 24 distinct keys in 32 slots: a free slot always exists
+          h &= (unsigned)(TS - 1);
+          const int old = atomicCAS(&kk[h], -1, j);
+          if (old == -1 || old == j) break;
+          h++;
+        }
+        if (NUM) atomicAdd(&vv[h], av * B.val(k, q, j));
+      }
+    }
+  __syncthreads();
+  if (!NUM) {
+    int cnt = 0;
+    for (int t = l8; t < TS; t += 8) cnt += kk[t] >= 0 ? 1 : 0;
+    cnt += __shfl_xor(cnt, 1); cnt += __shfl_xor(cnt, 2); cnt += __shfl_xor(cnt, 4);
+    if (live && l8 == 0) Crp[i + 1] = cnt;
+    return;
+  }
+  for (int t = l8; t < TS; t += 8) if (kk[t] < 0) kk[t] = 0x7fffffff;
+  __syncthreads();
+  for (int k = 2; k <= TS; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = l8; t < TS / 2; t += 8) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const int a = kk[lo], b = kk[hi];
+        if ((a > b) == up) { kk[lo] = b; kk[hi] = a; const double x = vv[lo]; vv[lo] = vv[hi]; vv[hi] = x; }
+      }
+      __syncthreads();
+    }
+  if (live) {
+    const int base = Crp[i], cnt = Crp[i + 1] - base;
+    for (int t = l8; t < cnt; t += 8) { Ccol[base + t] = kk[t]; Cval[base + t] = vv[t]; }
+  }
 }
 
 // Long rows (coarse levels: few columns in total): dense accumulator per wavefront in global memory.  marker holds the
@@ -403,6 +469,21 @@ __global__ __launch_bounds__(TPB) void spmv_dinv_kernel(int n, const int *__rest
   if (i < n && l == 0) y[i] = dinv[i] * a;
 }
 
+// v[i] = element i of the sequence st <- a st + c (mod 2^64), st_0 = seed, mapped to [-0.5, 0.5): the (i+1)-fold
+// composition of the affine map by binary powering
+__global__ __launch_bounds__(TPB) void lcg_vector_kernel(int n, double *__restrict__ v) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long ra = 1ull, rc = 0ull;                                            // identity map
+  unsigned long long pa = 6364136223846793005ull, pc = 1442695040888963407ull;        // one step
+  for (unsigned k = (unsigned)i + 1u; k; k >>= 1) {
+    if (k & 1u) { rc = pa * rc + pc; ra = pa * ra; }
+    pc = pa * pc + pc; pa = pa * pa;
+  }
+  const unsigned long long st = ra * 0x9E3779B97F4A7C15ull + rc;
+  v[i] = ((st >> 11) * (1.0 / 9007199254740992.0)) - 0.5;
+}
+
 // ---- SELL-64 (fp32) from sorted CSR
 __global__ __launch_bounds__(64) void sell_width_kernel(int n, const int *__restrict__ rp, int *__restrict__ sptr1, int *__restrict__ maxw) {
   const int sl = blockIdx.x, r = sl * 64 + threadIdx.x;
@@ -488,13 +569,23 @@ __global__ __launch_bounds__(TPB) void absdiag_kernel(int n, const int *__restri
   for (int k = rp[i], e = rp[i + 1]; k < e; k++) if (col[k] == i) v = fabs(val[k]);
   d[i] = v;
 }
+// Connection strength for "strongest neighbour" choices, coarsened to 16 mantissa bits: on structured meshes many connections
+// are equal up to rounding, and the tetrahedral assembly is reproducible to 1e-12 only (LDS-arrival order) -- comparing raw
+// values would let that noise pick different aggregates from run to run.  Ties go to the lower aggregate id.
+__device__ __forceinline__ unsigned qstrength(double a) { return __float_as_uint((float)a) >> 8; }
 __device__ __forceinline__ unsigned hash32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-// state: 0 out (not a root), 1 undecided, 2 root.  key = state << 62 | hash << 30 | (index & 0x3fffffff)
-__device__ __forceinline__ unsigned long long mis_key(int state, int i) {
-  return ((unsigned long long)state << 62) | ((unsigned long long)(hash32((unsigned)i) >> 2) << 30) | (unsigned long long)(unsigned)i;
+// state: 0 out (not a root), 1 undecided, 2 root.  key = state << 62 | priority (32 bits) << 30 | index (30 bits).
+// Priority modes (the packing density of the roots decides the coarsening ratio, and with it the iteration count):
+//   0 hash       : random -- a jammed random packing, ~15 % fewer aggregates than an ordered sweep
+//   1 index      : lowest index first = the roots of the sequential greedy pass (long dependency chains: many rounds)
+//   2 front      : number of strong neighbours already decided "out", then hash: new roots are placed right next to the
+//                  finished region (distance 3 from its roots), i.e. the packing grows as tight fronts
+//   3 front+seed : as 2, with one vertex in 64 eligible in the first round (fewer, larger fronts)
+__device__ __forceinline__ unsigned long long mis_pack(int state, unsigned prio, int i) {
+  return ((unsigned long long)state << 62) | ((unsigned long long)prio << 30) | (unsigned long long)(unsigned)i;
 }
 __global__ __launch_bounds__(TPB) void mis_init_kernel(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
                                                        const double *__restrict__ d, double theta, int *__restrict__ state) {
@@ -508,31 +599,57 @@ __global__ __launch_bounds__(TPB) void mis_init_kernel(int n, const int *__restr
   }
   state[i] = any ? 1 : 0;
 }
-// t1[i] = max key over the strong closed neighbourhood (pass 1: from the vertex keys, pass 2: from t1)
-template <int PASS>
-__global__ __launch_bounds__(TPB) void mis_propagate_kernel(int n, const int *__restrict__ rp, const int *__restrict__ col,
-                                                            const double *__restrict__ val, const double *__restrict__ d, double theta,
-                                                            const int *__restrict__ state, const unsigned long long *__restrict__ in,
-                                                            unsigned long long *__restrict__ out) {
+__global__ __launch_bounds__(TPB) void mis_key_kernel(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+                                                      const double *__restrict__ d, double theta, const int *__restrict__ state, int mode, int round,
+                                                      unsigned long long *__restrict__ key) {
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
-  unsigned long long m = PASS == 1 ? mis_key(state[i], i) : in[i];
+  const int st = state[i];
+  unsigned prio;
+  if (mode == 1) prio = (unsigned)(n - 1 - i);
+  else if (mode >= 4) {
+    // tiles of 2^(mode) consecutive (Morton-ordered) vertices: random order of the tiles, ascending index inside a tile -- the
+    // sequential greedy sweep, run in all tiles at once; a tile adapts to its finished neighbours like the sweep to earlier rows
+    const int tb = mode > 16 ? 16 : mode;
+    prio = ((hash32((unsigned)(i >> tb)) >> 16) << 16) | (0xffffu - (unsigned)(i & ((1 << tb) - 1)));
+  } else {
+    prio = hash32((unsigned)i) >> 8;  // 24 bits
+    if (mode >= 2 && st == 1) {
+      int cnt = 0;
+      for (int k = rp[i], e = rp[i + 1]; k < e; k++) {
+        const int j = col[k];
+        if (j != i && state[j] == 0 && fabs(val[k]) >= theta * sqrt(d[i] * d[j])) cnt++;
+      }
+      prio |= (unsigned)(cnt > 127 ? 127 : cnt) << 24;
+      // seeding: in the first round only one vertex in 64 may win (state 0-like key); the others wait
+      if (mode == 3 && round == 0 && (hash32((unsigned)i ^ 0x9e3779b9u) & 63u) != 0) { key[i] = mis_pack(0, prio, i); return; }
+    }
+  }
+  key[i] = mis_pack(st, prio, i);
+}
+// out[i] = max of in[] over the strong closed neighbourhood
+__global__ __launch_bounds__(TPB) void mis_propagate_kernel(int n, const int *__restrict__ rp, const int *__restrict__ col,
+                                                            const double *__restrict__ val, const double *__restrict__ d, double theta,
+                                                            const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long m = in[i];
   for (int k = rp[i], e = rp[i + 1]; k < e; k++) {
     const int j = col[k];
     if (j == i || !(fabs(val[k]) >= theta * sqrt(d[i] * d[j]))) continue;
-    const unsigned long long kj = PASS == 1 ? mis_key(state[j], j) : in[j];
+    const unsigned long long kj = in[j];
     m = kj > m ? kj : m;
   }
   out[i] = m;
 }
-__global__ __launch_bounds__(TPB) void mis_decide_kernel(int n, const unsigned long long *__restrict__ t2, int *__restrict__ state,
-                                                         int *__restrict__ undecided) {
+__global__ __launch_bounds__(TPB) void mis_decide_kernel(int n, const unsigned long long *__restrict__ key, const unsigned long long *__restrict__ t2,
+                                                         int *__restrict__ state, int *__restrict__ undecided) {
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i >= n || state[i] != 1) return;
   const unsigned long long m = t2[i];
-  if ((int)(m >> 62) == 2) state[i] = 0;                                // a root within distance two
-  else if ((unsigned)(m & 0x3fffffffu) == (unsigned)i) state[i] = 2;    // largest undecided key within distance two
-  else atomicAdd(undecided, 1);
+  if ((int)(m >> 62) == 2) state[i] = 0;              // a root within distance two
+  else if (m == key[i]) state[i] = 2;                 // largest undecided key within distance two (a waiting vertex carries a state-0 key: never equal)
+  else *undecided = 1;                                // a flag, not a count: no atomic
 }
 __global__ __launch_bounds__(TPB) void agg_number_roots_kernel(int n, const int *__restrict__ state, int *__restrict__ flag1) {
   const int i = blockIdx.x * TPB + threadIdx.x;
@@ -547,17 +664,72 @@ __global__ __launch_bounds__(TPB) void agg_phase1_kernel(int n, const int *__res
   if (i >= n) return;
   if (state[i] == 2) { agg[i] = rootid[i + 1] - 1; return; }
   int best = -1;
-  double bv = -1.0;
+  unsigned bq = 0;
   for (int k = rp[i], e = rp[i + 1]; k < e; k++) {
     const int j = col[k];
     if (j == i || state[j] != 2) continue;
     const double a = fabs(val[k]);
-    // the root claims i when ITS row rates the connection strong (the root's view, as in the sequential greedy pass); on the
-    // pattern-symmetric matrices of this code a_ij and a_ji share the threshold sqrt(d_i d_j)
     if (!(a >= theta * sqrt(d[i] * d[j]))) continue;
-    if (a > bv) { bv = a; best = rootid[j + 1] - 1; }
+    const unsigned q = qstrength(a);
+    const int id = rootid[j + 1] - 1;
+    if (best < 0 || q > bq || (q == bq && id < best)) { bq = q; best = id; }
   }
   agg[i] = best;
+}
+// Secondary aggregates in the gaps of the root packing: a vertex left over by phase 1 (no root next to it) whose strong
+// neighbourhood holds at least two more leftovers becomes a secondary root when it beats all its leftover neighbours
+// (priority: number of leftover neighbours, then hash); it claims those neighbours.
+__global__ __launch_bounds__(TPB) void agg_gap_key_kernel(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+                                                          const double *__restrict__ d, double theta, const int *__restrict__ agg, int minleft,
+                                                          unsigned long long *__restrict__ key) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long kk = 0;
+  if (agg[i] < 0) {
+    int cnt = 0;
+    for (int k = rp[i], e = rp[i + 1]; k < e; k++) {
+      const int j = col[k];
+      if (j != i && agg[j] < 0 && fabs(val[k]) >= theta * sqrt(d[i] * d[j])) cnt++;
+    }
+    if (cnt >= minleft) kk = mis_pack(1, ((unsigned)(cnt > 127 ? 127 : cnt) << 24) | (hash32((unsigned)i) >> 8), i);
+  }
+  key[i] = kk;
+}
+__global__ __launch_bounds__(TPB) void agg_gap_root_kernel(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+                                                           const double *__restrict__ d, double theta, const unsigned long long *__restrict__ key,
+                                                           int *__restrict__ flag1) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long ki = key[i];
+  bool root = ki != 0;
+  for (int k = rp[i], e = rp[i + 1]; k < e && root; k++) {
+    const int j = col[k];
+    if (j != i && fabs(val[k]) >= theta * sqrt(d[i] * d[j]) && key[j] > ki) root = false;
+  }
+  flag1[i + 1] = root ? 1 : 0;
+}
+__global__ __launch_bounds__(TPB) void agg_gap_claim_kernel(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+                                                            const double *__restrict__ d, double theta, const int *__restrict__ flagscan /*inclusive*/,
+                                                            int na0, const int *__restrict__ in, int *__restrict__ out) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  int a0 = in[i];
+  if (a0 < 0) {
+    if (flagscan[i + 1] != flagscan[i]) a0 = na0 + flagscan[i + 1] - 1;
+    else {
+      unsigned bq = 0;
+      for (int k = rp[i], e = rp[i + 1]; k < e; k++) {
+        const int j = col[k];
+        if (j == i || in[j] >= 0 || flagscan[j + 1] == flagscan[j]) continue;  // j is a secondary root?
+        const double a = fabs(val[k]);
+        if (!(a >= theta * sqrt(d[i] * d[j]))) continue;
+        const unsigned q = qstrength(a);
+        const int id = na0 + flagscan[j + 1] - 1;
+        if (a0 < 0 || q > bq || (q == bq && id < a0)) { bq = q; a0 = id; }
+      }
+    }
+  }
+  out[i] = a0;
 }
 // phase 2: an unaggregated vertex joins the aggregate of its strongest aggregated strong neighbour (reads `in`, writes `out`)
 __global__ __launch_bounds__(TPB) void agg_phase2_kernel(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
@@ -567,13 +739,14 @@ __global__ __launch_bounds__(TPB) void agg_phase2_kernel(int n, const int *__res
   if (i >= n) return;
   int a0 = in[i];
   if (a0 < 0) {
-    double bv = -1.0;
+    unsigned bq = 0;
     for (int k = rp[i], e = rp[i + 1]; k < e; k++) {
       const int j = col[k];
       if (j == i || in[j] < 0) continue;
       const double a = fabs(val[k]);
       if (!(a >= theta * sqrt(d[i] * d[j]))) continue;
-      if (a > bv) { bv = a; a0 = in[j]; }
+      const unsigned q = qstrength(a);
+      if (a0 < 0 || q > bq || (q == bq && in[j] < a0)) { bq = q; a0 = in[j]; }
     }
   }
   out[i] = a0;
@@ -606,6 +779,11 @@ struct Spgemm {
   if (hc[b] > 0)                                                                                                                 \
     hipLaunchKernelGGL((spgemm_hash_kernel<TS, NUM, AOp, BOp>), dim3(hc[b]), dim3(64), 0, s, lists.p + (size_t)(b) * n, cnt + (b), A, B, \
                        C.rowptr.p, C.col.p, C.val.p, fail)
+      if (hc[0] > 0) {
+        if (pass == 0) hipLaunchKernelGGL((spgemm_small_kernel<false, AOp, BOp>), dim3((hc[0] + 31) / 32), dim3(256), 0, s, lists.p, cnt, A, B, C.rowptr.p, C.col.p, C.val.p);
+        else hipLaunchKernelGGL((spgemm_small_kernel<true, AOp, BOp>), dim3((hc[0] + 31) / 32), dim3(256), 0, s, lists.p, cnt, A, B, C.rowptr.p, C.col.p, C.val.p);
+        hc[0] = 0;
+      }
       if (pass == 0) { HASH_LAUNCH(32, false, 0); HASH_LAUNCH(128, false, 1); HASH_LAUNCH(512, false, 2); HASH_LAUNCH(2048, false, 3); HASH_LAUNCH(8192, false, 4); }
       else { HASH_LAUNCH(32, true, 0); HASH_LAUNCH(128, true, 1); HASH_LAUNCH(512, true, 2); HASH_LAUNCH(2048, true, 3); }
 #undef HASH_LAUNCH
@@ -722,17 +900,10 @@ struct Builder {
     if ((size_t)n > offd.n) HIPCHK(c, offd.alloc((size_t)n + 64));
     const dim3 gr((n + TPB - 1) / TPB), bl(TPB), gr8((unsigned)((8ll * n + TPB - 1) / TPB));
     hipLaunchKernelGGL(level_diag_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, L.dinv.p, offd.p);
-    // start vector: the host build's LCG sequence (a prefix of it for every n), kept on the device
-    if ((size_t)n > c->amg_rand.n) {
-      std::vector<double> v(n);
-      uint64_t st = 0x9E3779B97F4A7C15ull;
-      for (int i = 0; i < n; i++) { st = st * 6364136223846793005ull + 1442695040888963407ull; v[i] = ((st >> 11) * (1.0 / 9007199254740992.0)) - 0.5; }
-      HIPCHK(c, c->amg_rand.upload(v, s));
-      HIPCHK(c, hipStreamSynchronize(s));
-    }
+    // start vector: the host build's LCG sequence, element i by jump-ahead (the same numbers, no host loop)
     dbuf<double> v, w;
     HIPCHK(c, v.alloc(n)); HIPCHK(c, w.alloc(n));
-    HIPCHK(c, hipMemcpyAsync(v.p, c->amg_rand.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(lcg_vector_kernel, gr, bl, 0, s, n, v.p);
     double *nrm = c->red_out.p + 30;
     for (int it = 0; it < 15; it++) {
       hipLaunchKernelGGL(spmv_dinv_kernel, gr8, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, L.dinv.p, v.p, w.p);
@@ -770,23 +941,51 @@ struct Builder {
     if (cnts.n < 16) HIPCHK(c, cnts.alloc(16));
     hipLaunchKernelGGL(absdiag_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p);
     hipLaunchKernelGGL(mis_init_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, state.p);
-    for (int round = 0; round < 64; round++) {
+    // defaults measured on the four 2-D / 3-D bench configurations against the sequential greedy pass of the host build
+    // (DESIGN.md section 6): front priority + secondary roots with >= 4 leftover neighbours reproduce its iteration counts
+    // within +-1 or better; 2 or 3 leftover neighbours are better still on three of them and 50 % worse on the stenosis
+    static const int mode = getenv("CFDH_AGG_PRIO") ? atoi(getenv("CFDH_AGG_PRIO")) : 2;
+    dbuf<unsigned long long> key;
+    HIPCHK(c, key.alloc(n));
+    int rounds = 0;
+    for (int round = 0; round < 4096; round++) {
       HIPCHK(c, hipMemsetAsync(cnts.p + 13, 0, sizeof(int), s));
-      hipLaunchKernelGGL((mis_propagate_kernel<1>), gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, state.p, (const unsigned long long *)nullptr, t1.p);
-      hipLaunchKernelGGL((mis_propagate_kernel<2>), gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, state.p, t1.p, t2.p);
-      hipLaunchKernelGGL(mis_decide_kernel, gr, bl, 0, s, n, t2.p, state.p, cnts.p + 13);
-      int und = 0;
-      CHK(dv.read_int(cnts.p + 13, &und));
-      if (und == 0) break;
+      hipLaunchKernelGGL(mis_key_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, state.p, mode, round, key.p);
+      hipLaunchKernelGGL(mis_propagate_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, key.p, t1.p);
+      hipLaunchKernelGGL(mis_propagate_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, t1.p, t2.p);
+      hipLaunchKernelGGL(mis_decide_kernel, gr, bl, 0, s, n, key.p, t2.p, state.p, cnts.p + 13);
+      rounds++;
+      // the count of still-undecided vertices is read every fourth round (a round after the fixed point changes nothing)
+      if ((round & 3) == 3 || mode == 0) {
+        int und = 0;
+        CHK(dv.read_int(cnts.p + 13, &und));
+        if (und == 0) break;
+      }
     }
+    if (c->opt.verbose > 1) fprintf(stderr, "[cfdh]   aggregation: n %d, %d MIS-2 rounds (priority mode %d)\n", n, rounds, mode);
     HIPCHK(c, hipMemsetAsync(flag.p, 0, sizeof(int), s));
     hipLaunchKernelGGL(agg_number_roots_kernel, gr, bl, 0, s, n, state.p, flag.p);
     CHK(dv.scan(flag.p + 1, n));
     hipLaunchKernelGGL(agg_phase1_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, state.p, flag.p, agg.p);
+    int na = 0;
+    CHK(dv.read_int(flag.p + n, &na));
+    static const int gap = getenv("CFDH_AGG_GAP") ? atoi(getenv("CFDH_AGG_GAP")) : 4;  // 0: off, k: secondary roots with >= k leftover neighbours
+    if (gap > 0) {
+      hipLaunchKernelGGL(agg_gap_key_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, agg.p, gap, key.p);
+      HIPCHK(c, hipMemsetAsync(flag.p, 0, sizeof(int), s));
+      hipLaunchKernelGGL(agg_gap_root_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, key.p, flag.p);
+      CHK(dv.scan(flag.p + 1, n));
+      hipLaunchKernelGGL(agg_gap_claim_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, flag.p, na, agg.p, agg2.p);
+      int na2 = 0;
+      CHK(dv.read_int(flag.p + n, &na2));
+      na += na2;
+      HIPCHK(c, hipMemcpyAsync(agg.p, agg2.p, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
+    }
     hipLaunchKernelGGL(agg_phase2_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, agg.p, agg2.p);
     hipLaunchKernelGGL(agg_phase2_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, agg2.p, agg.p);
     HIPCHK(c, hipGetLastError());
-    CHK(dv.read_int(flag.p + n, na_out));  // synchronises: the temporaries above may go out of scope
+    HIPCHK(c, hipStreamSynchronize(s));  // the temporaries above may go out of scope
+    *na_out = na;
     return 0;
   }
 };
@@ -889,17 +1088,22 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
   const int maxlev = 16;
   static const double theta_env = getenv("CFDH_AMG_THETA") ? atof(getenv("CFDH_AMG_THETA")) : -1.0;
   const double theta = o.amg_theta >= 0 ? o.amg_theta : (theta_env >= 0 ? theta_env : (c->dim == 3 ? 0.02 : 0.07));
-  static const bool host_agg = getenv("CFDH_AMG_AGG") && !strcmp(getenv("CFDH_AMG_AGG"), "host");
+  const bool host_agg = getenv("CFDH_AMG_AGG") && !strcmp(getenv("CFDH_AMG_AGG"), "host");
   CsrDev A;
   move_csr(A, A0);
-  CsrDev lastSc;  // Sc (CSR, fp64) of the level above the coarsest one, for the folded dense correction
   AmgLevel *lastL = nullptr;
+  // phase timings (verbose): the stream is synchronised at every tick, so they are only taken when asked for
+  double tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = now_ms();
+  const bool timing = c->opt.verbose > 0;
+#define TICK(i) do { if (timing) { (void)hipStreamSynchronize(s); const double n_ = now_ms(); tm[i] += n_ - tq; tq = n_; } } while (0)
   for (;;) {
     AmgLevel *L = new AmgLevel();
     H.lev.push_back(L);
     double lm = 1.0;
+    TICK(9);
     CHK(B.level_quantities(*L, A, o.amg_smooth_ratio, &lm));
     CHK(B.work_vectors(*L, ncol));
+    TICK(0);
     L->fine = A.nnz <= (c->dim == 3 ? 20ll : 12ll) * A.n && A.n >= 16384;
     L->sell = L->fine && (A.nnz <= 12ll * A.n || ncol == 1);
     const bool last = A.n <= o.amg_max_coarse || (int)H.lev.size() >= maxlev;
@@ -922,6 +1126,7 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
         CHK(B.aggregate(A, theta, agg, &na));
       }
     }
+    TICK(1);
     if (last || na >= A.n || na < 1) {
       // coarsest level: keep the operator (CSR) for the closing step
       move_csr(L->A, A);
@@ -930,12 +1135,16 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
     // P = (I - omega D^-1 A) P0
     const MatV Am{A.rowptr.p, A.col.p, A.val.p};
     CsrDev P, R, AP, Ac;
-    CHK((Spgemm<AOpImwDA, BOpAgg>::run(B.dv, A.n, na, AOpImwDA{Am, L->dinv.p, 4.0 / 3.0 / lm}, BOpAgg{agg.p}, P, B.lists, B.tmp, B.cnts)));
+    CHK((Spgemm<AOpImwDA, BOpAgg>::run(B.dv, A.n, na, AOpImwDA{Am, L->dinv.p, 4.0 / 3.0 / lm, agg.p}, BOpAgg{agg.p}, P, B.lists, B.tmp, B.cnts)));
+    TICK(2);
     CHK(B.transpose(P, R));
+    TICK(3);
     const MatV Pm{P.rowptr.p, P.col.p, P.val.p}, Rm{R.rowptr.p, R.col.p, R.val.p};
     CHK((Spgemm<AOpPlain, BOpPlain>::run(B.dv, A.n, na, AOpPlain{Am}, BOpPlain{Pm}, AP, B.lists, B.tmp, B.cnts)));
+    TICK(4);
     // G = R (I - A W)
     CHK((Spgemm<AOpPlain, BOpImAW>::run(B.dv, na, A.n, AOpPlain{Rm}, BOpImAW{Am, L->wdinv.p}, L->G, B.lists, B.tmp, B.cnts)));
+    TICK(5);
     // Sb = 2W - W A W (pattern of A)
     L->Sb.n = A.n; L->Sb.m = A.n; L->Sb.nnz = A.nnz;
     HIPCHK(c, L->Sb.rowptr.alloc((size_t)A.n + 1)); HIPCHK(c, L->Sb.col.alloc(A.nnz)); HIPCHK(c, L->Sb.val.alloc(A.nnz));
@@ -950,9 +1159,11 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
     hipLaunchKernelGGL(sc_kernel, dim3((A.n + TPB - 1) / TPB), dim3(TPB), 0, s, A.n, AP.rowptr.p, AP.col.p, AP.val.p, P.rowptr.p, P.col.p, P.val.p,
                        L->wdinv.p, L->Sc.val.p);
     HIPCHK(c, hipGetLastError());
+    TICK(6);
     // A_c = R (A P)
     const MatV APm{AP.rowptr.p, AP.col.p, AP.val.p};
     CHK((Spgemm<AOpPlain, BOpPlain>::run(B.dv, na, na, AOpPlain{Rm}, BOpPlain{APm}, Ac, B.lists, B.tmp, B.cnts)));
+    TICK(7);
     // formats of the cycle kernels
     if (L->fine) CHK(B.formats(L->G, CFDH_UP_CSRF));
     if (L->sell) { CHK(B.formats(L->Sb, CFDH_UP_SELL)); CHK(B.formats(L->Sc, CFDH_UP_SELL)); }
@@ -961,7 +1172,9 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
     lastL = L;
     move_csr(A, Ac);
     HIPCHK(c, hipStreamSynchronize(s));  // P, R, AP are released here
+    TICK(8);
   }
+  tq = now_ms();
   // ---- closing step
   AmgLevel *Lc = H.lev.back();
   const int n = Lc->n;
@@ -1012,8 +1225,10 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
   if (c->opt.verbose) {
     fprintf(stderr, "[cfdh] AMG hierarchy built on the device in %.1f ms (ncol %d%s):", now_ms() - t_begin, ncol, H.fused ? ", fused" : "");
     for (AmgLevel *l : H.lev) fprintf(stderr, " (%d, nnz %d; G %d Sb %d Sc %d D %d)", l->n, l->A.nnz, l->G.nnz, l->Sb.nnz, l->Sc.nnz, l->Dn);
-    fprintf(stderr, "\n");
+    fprintf(stderr, "\n[cfdh]   ms: level quantities %.1f, aggregation %.1f, P %.1f, R = P^T %.1f, A P %.1f, G %.1f, Sb + Sc %.1f, A_c %.1f, formats %.1f, releases %.1f, "
+            "coarsest level %.1f\n", tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7], tm[8], tm[9], now_ms() - tq);
   }
+#undef TICK
   return 0;
 }
 
@@ -1031,7 +1246,7 @@ int cfdh_level_setup_dev(cfdh_ctx *c, AmgLevel &L, CsrDev &A, double ratio, int 
 }
 
 bool cfdh_amg_dev_enabled(const cfdh_ctx *c) {
-  static const bool host_only = getenv("CFDH_AMG_HOST") && getenv("CFDH_AMG_HOST")[0] == '1';
+  const bool host_only = getenv("CFDH_AMG_HOST") && getenv("CFDH_AMG_HOST")[0] == '1';
   const char *nf = getenv("CFDH_NO_FUSED_AMG");
   return !host_only && c->opt.amg_smooth_degree == 1 && !(nf && nf[0] == '1');
 }

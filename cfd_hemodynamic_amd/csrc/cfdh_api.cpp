@@ -632,6 +632,16 @@ int64_t cfdh_info(const cfdh_ctx *c, int what) {
     case 17: return c->n_allgather;
     case 18: return c->nranks;
     case 26: return c->dim;
+    case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
+    case 40: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49:
+    case 50: case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59:
+    case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: {
+      const AmgHier &h = what < 50 ? c->hA : (c->opt.pc_type == 1 ? c->hL : c->hS);
+      const size_t l = (size_t)(what % 10);
+      if (l >= h.lev.size()) return 0;
+      return ((what / 10) & 1) ? (int64_t)h.lev[l]->n : (int64_t)h.lev[l]->A.nnz;
+    }
+    case 27: return (int64_t)(1000.0 * c->ms_pc_build_dev);  // microseconds of the last device-side preconditioner build (0: host build)
     case 19: return c->opt.pc_type == 1 ? c->hL.nnz_S0 : c->hS.nnz_S0;
     case 20: return c->hA.nnz_S0;
     case 21: return c->opt.pc_type == 1 ? c->hL.nnz_G0 : c->hS.nnz_G0;

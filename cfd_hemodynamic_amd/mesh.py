@@ -364,7 +364,7 @@ def create_dfg_channel(m, comm=None):
     return mesh, ft
 
 
-def create_stenosis_channel(ny, L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, severity=0.5, slope=0.3, tension=0.5,
+def create_stenosis_channel(ny, L=138.0, R_in=1.57, R_out=1.2, x_sten=30.0, severity=0.567, slope=0.4, tension=0.5,
                             comm=None):
     """2-D stenosed channel of /root/reference/src/scenarios/stenosis.py:262-374: 0 <= x <= L, walls
     y = R_in +- R(x) with R the linear taper R_in -> R_out and, around x_sten, the narrowing to

@@ -265,7 +265,9 @@ int cfdh_profile_reset(cfdh_ctx *ctx);
  * counters since cfdh_create / cfdh_profile_reset: 13 all-reduce calls, 14 halo exchanges, 15 host synchronisations
  * (stream/event waits for scalars), 16 FGMRES iterations, 17 all-gathers; 18: communicator size;
  * fused AMG cycle: 19 / 20 entries of Sb + Sc on level 0 (pressure / velocity hierarchy), 21 / 22 entries of G on
- * level 0, 23 / 24 size of level 1, 25: fused cycle in use; 26: gdim */
+ * level 0, 23 / 24 size of level 1, 25: fused cycle in use; 26: gdim;
+ * 27: microseconds the last preconditioner build took on the device (0: it was built on the host);
+ * 30 + l / 40 + l: rows / entries of level l of the velocity hierarchy, 50 + l / 60 + l: of the pressure hierarchy (l < 10, 0 past the end) */
 int64_t cfdh_info(const cfdh_ctx *ctx, int what);
 
 #ifdef __cplusplus

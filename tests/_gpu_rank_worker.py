@@ -39,6 +39,11 @@ def main():
         from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
         sc = StenosisSimulation("stabilized_schur", 0.01, float(os.environ.get("CFDH_TEST_T", "0.015")), grade="moderate",
                                 ny=int(os.environ.get("CFDH_TEST_NY", "115")), v_max=100.0, quiet=True, device=0, comm=comm, options=tight)
+    elif case == "tree_c5":  # BASELINE config 5: stenosis + vascular tree (cut-cell mesh, eight p = 0 outlets), pulsatile inlet, dt = 0.001
+        from cfd_hemodynamic_amd.scenarios.stenosis_with_tree import StenosisWithTreeSimulation
+        sc = StenosisWithTreeSimulation("stabilized_schur", 0.001, float(os.environ.get("CFDH_TEST_T", "0.0035")), grade="moderate",
+                                        res=float(os.environ.get("CFDH_TEST_RES", "5e-5")), pulse_amplitude=0.5, ramp_time=0.005,
+                                        inlet_max_velocity=0.05, quiet=True, device=0, comm=comm, options=tight)
     elif case == "stenosis_backflow":  # do-nothing outlet, backflow facet term, no pressure Dirichlet set
         from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
         sc = StenosisSimulation("stabilized_schur_backflow", 0.01, 0.035, ny=12, L=30.0, x_sten=10.0, v_max=60.0, quiet=True,
@@ -56,8 +61,12 @@ def main():
     nfac_local = len(sc.solver._part.facet_cells)
     u = sc.solver.u_sol.x.array.copy()   # gathers the owned slices of every rank
     p = sc.solver.p_sol.x.array.copy()
+    extra = {}
+    if case == "tree_c5":
+        extra["outlet_flows"] = sc.outlet_flow_rates()
+        extra["inlet_peak"] = float(np.abs(np.asarray(sc._u_inlet.x.array)).max())
     if rank == 0:
-        np.savez(out, u=u, p=p, drag=getattr(sc, "drag", 0.0), lift=getattr(sc, "lift", 0.0), norm_v=sc.norm_v, norm_p=sc.norm_p, steps=sc.num_steps,
+        np.savez(out, u=u, p=p, **extra, drag=getattr(sc, "drag", 0.0), lift=getattr(sc, "lift", 0.0), norm_v=sc.norm_v, norm_p=sc.norm_p, steps=sc.num_steps,
                  krylov=sum(s.krylov_its for _, s in sc.step_stats), backend=comm.backend,
                  allgather=sc.solver.ctx.info(9), rccl_attached=sc.solver.ctx.info(10),
                  dist_coarse=sc.solver.ctx.info(11), ras=sc.solver.ctx.info(12),

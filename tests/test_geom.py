@@ -39,10 +39,10 @@ def test_murray_law_and_flow_split():
 
 
 def test_stenosis_outline_is_the_references():
-    """stenosis.py:262-374 with the defaults of :60-69 and grade "moderate" (:27-31)."""
-    ch = StenosedChannel(138.0, 1.57, 1.2, 30.0, 0.5, 0.3, 0.5, yc=1.57, clamp_frac=None)
+    """stenosis.py:262-374 with the defaults of :60-69 (severity 0.567, slope 0.4: the values every grade ends up with, :70-77)."""
+    ch = StenosedChannel(138.0, 1.57, 1.2, 30.0, 0.567, 0.4, 0.5, yc=1.57, clamp_frac=None)
     r_mid = 1.57 + (1.2 - 1.57) * 30.0 / 138.0
-    assert abs(ch.R_min - 0.5 * r_mid) < 1e-15 and abs(ch.dist_x - 0.5 * r_mid / 0.3) < 1e-14
+    assert abs(ch.R_min - (1.0 - 0.567) * r_mid) < 1e-15 and abs(ch.dist_x - 0.567 * r_mid / 0.4) < 1e-14
     x = np.array([0.0, ch.x1, 30.0, ch.x2, 138.0])
     R = ch.radius(x)
     taper = 1.57 + (1.2 - 1.57) * x / 138.0

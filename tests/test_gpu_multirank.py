@@ -170,16 +170,17 @@ def test_part_without_exterior_facets_takes_part_in_facet_functionals(tmp_path):
     fake = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
     if not os.path.exists(fake):
         subprocess.check_call(["make", "-C", os.path.join(HERE, "fake_rccl"), "-s"])
-    # singular system (no pressure condition): a Krylov target below ~1e-18 absolute cannot be met (round-off leaves a
-    # component of F outside the range of J), so the tolerances stay a decade above the other partition tests
-    tight = dict(snes_rtol=1e-10, snes_stol=0.0, ksp_rtol=1e-8)
+    # singular system (no pressure condition): the tolerances of the other singular-cavity partition test.  (Round 2 ran this
+    # case at 1e-10 / 1e-8 after a 1000-iteration stall at 1e-11 / 1e-9 on an earlier commit; at HEAD the stall does not
+    # reproduce -- tools/mr_island.sh 1e-11 1e-9: 17 FGMRES iterations per Newton step on both ranks.)
+    tight = dict(snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-9)
     ref = LidDriven2DSimulation("stabilized_schur", 0.01, 0.035, nx=48, mu=0.01, quiet=True, options=tight)
     ref.solve(None)
     fd, fl = ref.solver.functional(0, 0), ref.solver.functional(1, 0)
     for backend, extra in (("host", {}), ("rccl", {"CFDH_RCCL_LIB": fake})):
         out = str(tmp_path / ("island_%s.npz" % backend))
         r = _run(2, out, timeout=300, CFDH_TEST_BACKEND=backend, CFDH_TEST_CASE="lid", CFDH_TEST_PARTITION="interior_island",
-                 CFDH_TEST_SNES_RTOL="1e-10", CFDH_TEST_KSP_RTOL="1e-8", **extra)
+                 CFDH_TEST_SNES_RTOL="1e-11", CFDH_TEST_KSP_RTOL="1e-9", **extra)
         assert int(np.load(out + ".nfac1.npy")[0]) == 0 and int(np.load(out + ".nfac0.npy")[0]) > 0
         assert abs(float(r["fd_all"]) - fd) <= 1e-7 * abs(fd) + 1e-12
         assert abs(float(r["fl_all"]) - fl) <= 1e-7 * abs(fl) + 1e-12
@@ -264,5 +265,33 @@ def test_config4_stenosis_partitioned_over_4_ranks_at_full_size(tmp_path):
     assert int(r["steps"]) == 2 and str(r["backend"]) == "rccl"
     assert np.linalg.norm(r["u"] - u0) <= 1e-8 * np.linalg.norm(u0)
     assert np.linalg.norm(r["p"] - p0) <= 1e-7 * np.linalg.norm(p0)
+    assert int(r["ras"]) == 1 and int(r["dist_coarse"]) > 0
+    assert int(r["krylov"]) <= 1.5 * ref_krylov, (int(r["krylov"]), ref_krylov)
+
+
+def test_config5_tree_partitioned_over_4_ranks(tmp_path):
+    """BASELINE configs[4] partitioned: stenosis + 3-generation vascular tree (cut-cell mesh, eight `p = 0` outlets;
+    stenosis_with_tree.py:114-142), pulsatile inlet re-sent through `bc.update()` every step, dt = 0.001 -- four ranks through the
+    RCCL stand-in on a 60 k-vertex mesh of the domain.  The partition cuts through the tree (a rank may hold several outlets or none);
+    solution, outlet flow rates and the inlet data of the last step equal the single-rank run's."""
+    from cfd_hemodynamic_amd.scenarios.stenosis_with_tree import StenosisWithTreeSimulation
+    fake = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "fake_rccl"), "-s"])
+    tight = dict(snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-9)
+    ref = StenosisWithTreeSimulation("stabilized_schur", 0.001, 0.0035, grade="moderate", res=5e-5, pulse_amplitude=0.5, ramp_time=0.005,
+                                     inlet_max_velocity=0.05, quiet=True, options=tight)
+    assert ref.mesh.num_vertices > 60000 and len(ref.mesh.outlet_caps) == 8
+    ref.solve(None)
+    ref_krylov = sum(st.krylov_its for _, st in ref.step_stats)
+    u0, p0 = np.asarray(ref.solver.u_sol.x.array).copy(), np.asarray(ref.solver.p_sol.x.array).copy()
+    q0 = ref.outlet_flow_rates()
+    r = _run(4, str(tmp_path / "c5.npz"), timeout=600, CFDH_TEST_BACKEND="rccl", CFDH_RCCL_LIB=fake, CFDH_TEST_CASE="tree_c5",
+             CFDH_TEST_SNES_RTOL="1e-11", CFDH_TEST_KSP_RTOL="1e-9")
+    assert int(r["steps"]) == ref.num_steps == 4 and str(r["backend"]) == "rccl" and int(r["rccl_attached"]) == 1
+    assert np.linalg.norm(r["u"] - u0) <= 1e-8 * np.linalg.norm(u0)
+    assert np.linalg.norm(r["p"] - p0) <= 1e-7 * np.linalg.norm(p0)
+    assert np.abs(r["outlet_flows"] - q0).max() <= 1e-6 * np.abs(q0).max() and (q0 > 0).all()
+    assert abs(float(r["inlet_peak"]) - float(np.abs(np.asarray(ref._u_inlet.x.array)).max())) <= 1e-14
     assert int(r["ras"]) == 1 and int(r["dist_coarse"]) > 0
     assert int(r["krylov"]) <= 1.5 * ref_krylov, (int(r["krylov"]), ref_krylov)

@@ -515,6 +515,7 @@ def test_fused_amg_cycle_is_the_same_preconditioner(monkeypatch):
     case = dfg_case(64)   # four-level hierarchies, fine level in SELL format
     nv = case.nv
     runs = []
+    monkeypatch.setenv("CFDH_AMG_HOST", "1")  # both cycles on the SAME (host-built) hierarchy; the device build makes the composites only
     for nofuse in ("1", "0"):
         monkeypatch.setenv("CFDH_NO_FUSED_AMG", nofuse)
         ctx = make_ctx(case)
@@ -535,3 +536,47 @@ def test_fused_amg_cycle_is_the_same_preconditioner(monkeypatch):
     assert [n for n, _ in its0] == [n for n, _ in its1]
     assert all(abs(a - b) <= 1 for (_, a), (_, b) in zip(its0, its1)), (its0, its1)
     assert np.linalg.norm(x0 - x1) <= 1e-9 * np.linalg.norm(x0)
+
+
+def _run_steps(case, nsteps=3, tight=True):
+    nv = case.nv
+    ctx = make_ctx(case)
+    o = ctx.default_options()
+    if tight:
+        o.snes_rtol, o.ksp_rtol, o.snes_stol = 1e-11, 1e-9, 0.0
+    ctx.set_options(o)
+    z2, z1 = np.zeros(2 * nv), np.zeros(nv)
+    ctx.set_state(u_prev=z2, p_prev=z1, u=z2, p=z1)
+    its = []
+    for _ in range(nsteps):
+        st = ctx.solve_step()
+        its.append((st.newton_its, st.krylov_its))
+        ctx.advance()
+    shape = [[ctx.info(b + l) for l in range(8)] for b in (30, 40, 50, 60)]
+    out = (its, np.concatenate(ctx.get_solution()), shape, ctx.info(27), ctx.info(25))
+    ctx.close()
+    return out
+
+
+def test_device_built_hierarchies_match_the_host_build(monkeypatch):
+    """The AMG hierarchies are built on the GPU (csrc/cfdh_amg_dev.hip: hash SpGEMM per wavefront, transposition, composite
+    operators, dense coarse inverse, SELL/fp32 formats).  With the host's aggregates handed in (CFDH_AMG_AGG=host) every
+    level has the same size and entry count as the host-built hierarchy and FGMRES takes the same iterations; with the
+    device aggregation (distance-2 independent set, front priority) the counts stay within 10 %.  Solutions agree to
+    solver tolerance in all three."""
+    case = dfg_case(64)
+    monkeypatch.setenv("CFDH_AMG_HOST", "1")
+    its_h, x_h, shape_h, us_h, fused_h = _run_steps(case)
+    monkeypatch.setenv("CFDH_AMG_HOST", "0")
+    monkeypatch.setenv("CFDH_AMG_AGG", "host")
+    its_a, x_a, shape_a, us_a, fused_a = _run_steps(case)
+    monkeypatch.delenv("CFDH_AMG_AGG")
+    its_d, x_d, shape_d, us_d, fused_d = _run_steps(case)
+    assert us_h == 0 and us_a > 0 and us_d > 0 and fused_h == fused_a == fused_d == 1
+    assert shape_h[0] == shape_a[0] and shape_h[2] == shape_a[2], (shape_h, shape_a)       # rows per level, both hierarchies
+    assert shape_h[1] == shape_a[1] and shape_h[3] == shape_a[3], (shape_h, shape_a)       # entries per level
+    assert its_h == its_a, (its_h, its_a)
+    assert [n for n, _ in its_h] == [n for n, _ in its_d]
+    assert sum(k for _, k in its_d) <= 1.1 * sum(k for _, k in its_h), (its_h, its_d)
+    for x in (x_a, x_d):
+        assert np.linalg.norm(x - x_h) <= 1e-8 * np.linalg.norm(x_h)
