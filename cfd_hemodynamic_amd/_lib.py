@@ -41,7 +41,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp)
 
 # every symbol include/cfdh.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "cfdh_create", "cfdh_set_facet_markers", "cfdh_destroy", "cfdh_last_error", "cfdh_abi_version", "cfdh_set_params", "cfdh_default_options",
+    "cfdh_create", "cfdh_create_elem", "cfdh_set_facet_markers", "cfdh_destroy", "cfdh_last_error", "cfdh_abi_version", "cfdh_set_params", "cfdh_default_options",
     "cfdh_set_options", "cfdh_clear_dirichlet", "cfdh_add_dirichlet", "cfdh_set_state", "cfdh_get_solution",
     "cfdh_get_previous", "cfdh_get_residual", "cfdh_advance", "cfdh_advance_field", "cfdh_set_time_scheme", "cfdh_set_previous2", "cfdh_get_previous2",
     "cfdh_shift_history", "cfdh_set_boundary_terms", "cfdh_assemble", "cfdh_get_csr", "cfdh_spmv", "cfdh_solve_step",
@@ -76,6 +76,7 @@ def lib():
     L = C.CDLL(_SO)
     vp = C.c_void_p
     L.cfdh_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, ip, dp, C.c_int64, ip, ip, ip]
+    L.cfdh_create_elem.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, ip, dp, C.c_int64, ip, ip, ip]
     L.cfdh_set_facet_markers.argtypes = [vp, C.c_int64, ip]
     L.cfdh_destroy.argtypes = [vp]
     L.cfdh_destroy.restype = None
@@ -144,14 +145,19 @@ def _raise(code, msg):
 class Context:
     """Thin owner of a cfdh_ctx: arrays in, arrays out, exceptions for error codes."""
 
-    def __init__(self, x, cells, facet_cells, facet_local, facet_marker, nv_owned=None, device=0):
+    def __init__(self, x, cells, facet_cells, facet_local, facet_marker, nv_owned=None, device=0, etype=0):
+        """etype 0: P1 triangles / tetrahedra (cfdh_create); 1 P2 triangles, 2 Q1 quadrilaterals, 3 P1 triangles through the
+        generic kernels (cfdh_create_elem: `x` are node coordinates, `cells` list nloc nodes)."""
         L = lib()
         self.L = L
         x = np.asarray(x, dtype=np.float64)
         cells = np.asarray(cells)
-        self.dim = cells.shape[1] - 1  # triangles -> 2, tetrahedra -> 3
+        self.etype = int(etype)
+        self.dim = 2 if self.etype else cells.shape[1] - 1  # triangles -> 2, tetrahedra -> 3
         if self.dim not in (2, 3) or x.shape[1] < self.dim:
             raise ValueError("cells must be triangles [nc,3] or tetrahedra [nc,4] with matching coordinates")
+        if self.etype and cells.shape[1] != {1: 6, 2: 4, 3: 3}[self.etype]:
+            raise ValueError("element type %d needs %d nodes per cell" % (self.etype, {1: 6, 2: 4, 3: 3}[self.etype]))
         self.x = np.ascontiguousarray(x[:, : self.dim]).copy()
         self.cells = np.ascontiguousarray(cells, dtype=np.int32)
         self.nv = len(self.x)
@@ -160,8 +166,12 @@ class Context:
         fl = np.ascontiguousarray(facet_local, dtype=np.int32)
         fm = np.ascontiguousarray(facet_marker, dtype=np.int32)
         h = C.c_void_p()
-        rc = L.cfdh_create(C.byref(h), int(device), self.dim, self.nv, self.nvo, len(self.cells), _ip(self.cells), _dp(self.x),
-                           len(fc), _ip(fc), _ip(fl), _ip(fm))
+        if self.etype:
+            rc = L.cfdh_create_elem(C.byref(h), int(device), self.dim, self.etype, self.nv, len(self.cells), _ip(self.cells), _dp(self.x),
+                                    len(fc), _ip(fc), _ip(fl), _ip(fm))
+        else:
+            rc = L.cfdh_create(C.byref(h), int(device), self.dim, self.nv, self.nvo, len(self.cells), _ip(self.cells), _dp(self.x),
+                               len(fc), _ip(fc), _ip(fl), _ip(fm))
         if rc != 0:
             _raise(rc, "cfdh_create failed: " + L.cfdh_last_error(None).decode())
         self.h = h

@@ -16,7 +16,7 @@
 #include <cmath>
 
 #include "cfdh_internal.hpp"
-#include "quad_tet.h"
+#include "cfdh_quad_tet.h"
 
 #define TPB 256
 

@@ -28,7 +28,7 @@ int cfdh_build_mesh3(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, con
     if (cells[k] < 0 || cells[k] >= nv) return cfdh_fail(c, CFDH_E_ARG, "cell vertex index out of range");
   for (int k = 0; k < nfac; k++)
     if (fcell[k] < 0 || fcell[k] >= ncu || flocal[k] < 0 || flocal[k] > 3) return cfdh_fail(c, CFDH_E_ARG, "facet (cell, local) out of range");
-  c->dim = 3;
+  c->dim = 3; c->nloc = 4;
   c->nv = nv; c->nvo = nvo; c->ng = 0;
   c->NO = 4 * nvo; c->NL = 4 * nvo;
   // ---- Morton numbering

@@ -33,12 +33,15 @@ int cfdh_default_options(cfdh_options *o) {
   return 0;
 }
 
-int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_owned, int64_t nc, const int32_t *cells,
-                const double *coords, int64_t nfacets, const int32_t *facet_cells, const int32_t *facet_local,
-                const int32_t *facet_marker) {
+static int create_ctx(cfdh_ctx **out, int device, int gdim, int etype, int64_t nv, int64_t nv_owned, int64_t nc, const int32_t *cells,
+                      const double *coords, int64_t nfacets, const int32_t *facet_cells, const int32_t *facet_local,
+                      const int32_t *facet_marker) {
   if (!out) return cfdh_fail(nullptr, CFDH_E_ARG, "null output pointer");
   *out = nullptr;
   if (gdim != 2 && gdim != 3) return cfdh_fail(nullptr, CFDH_E_ARG, "gdim must be 2 (P1 triangles) or 3 (P1 tetrahedra)");
+  if (etype < 0 || etype > 3) return cfdh_fail(nullptr, CFDH_E_ARG, "unknown element type %d", etype);
+  if (etype != 0 && gdim != 2) return cfdh_fail(nullptr, CFDH_E_ARG, "P2 / Q1 elements are implemented for gdim 2");
+  if (etype != 0 && nv_owned != nv) return cfdh_fail(nullptr, CFDH_E_ARG, "P2 / Q1 contexts are single-GPU: nv_owned must equal nv");
   if (!cells || !coords || (nfacets > 0 && (!facet_cells || !facet_local)))
     return cfdh_fail(nullptr, CFDH_E_ARG, "null mesh array");
   int ndev = 0;
@@ -57,6 +60,12 @@ int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_own
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = cfdh_fail(nullptr, CFDH_E_HIP, "hipStreamCreate failed"); break; }
     rc = gdim == 3 ? k3_upload_quadrature(c) : k_upload_quadrature(c);
     if (rc) break;
+    if (etype != 0) {
+      rc = kg_upload_tables(c);
+      if (rc) break;
+      rc = cfdh_build_mesh_gen(c, etype, nv, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker);
+      break;
+    }
     rc = gdim == 3 ? cfdh_build_mesh3(c, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker)
                    : cfdh_build_mesh(c, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker);
   } while (0);
@@ -67,6 +76,17 @@ int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_own
   }
   *out = c;
   return 0;
+}
+
+int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_owned, int64_t nc, const int32_t *cells,
+                const double *coords, int64_t nfacets, const int32_t *facet_cells, const int32_t *facet_local,
+                const int32_t *facet_marker) {
+  return create_ctx(out, device, gdim, CFDH_ELEM_P1, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker);
+}
+
+int cfdh_create_elem(cfdh_ctx **out, int device, int gdim, int elem, int64_t nn, int64_t nc, const int32_t *cells, const double *node_coords,
+                     int64_t nfacets, const int32_t *facet_cells, const int32_t *facet_local, const int32_t *facet_marker) {
+  return create_ctx(out, device, gdim, elem, nn, nn, nc, cells, node_coords, nfacets, facet_cells, facet_local, facet_marker);
 }
 
 void cfdh_destroy(cfdh_ctx *c) {
@@ -281,6 +301,18 @@ int cfdh_set_time_scheme(cfdh_ctx *c, double theta, double a0, double a1, double
 
 // per-cell facet bits of the assembly kernel: bits 0..d exterior facet, bits d+1..2d+1 backflow facet (marker == bf_marker)
 static int upload_cell_facet_flags(cfdh_ctx *c) {
+  if (c->gen) {
+    std::vector<unsigned short> gf((size_t)c->nc, 0);
+    for (int k = 0; k < c->nfac; k++) {
+      gf[c->fac_cell[k]] |= (unsigned short)(1u << c->fac_local[k]);
+      if (c->bf_marker >= 0 && c->fac_marker[k] == c->bf_marker) gf[c->fac_cell[k]] |= (unsigned short)(256u << c->fac_local[k]);
+    }
+    HIPCHK(c, c->gflag.upload(gf, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->jac_valid = false;
+    c->pc_valid = false;
+    return 0;
+  }
   std::vector<unsigned char> cflag((size_t)c->nc, 0);
   for (int k = 0; k < c->nfac; k++) {
     cflag[c->fac_cell[k]] |= (unsigned char)(1u << c->fac_local[k]);
@@ -641,6 +673,8 @@ int64_t cfdh_info(const cfdh_ctx *c, int what) {
       if (l >= h.lev.size()) return 0;
       return ((what / 10) & 1) ? (int64_t)h.lev[l]->n : (int64_t)h.lev[l]->A.nnz;
     }
+    case 28: return c->etype;
+    case 29: return c->nloc;
     case 27: return (int64_t)(1000.0 * c->ms_pc_build_dev);  // microseconds of the last device-side preconditioner build (0: host build)
     case 19: return c->opt.pc_type == 1 ? c->hL.nnz_S0 : c->hS.nnz_S0;
     case 20: return c->hA.nnz_S0;

@@ -150,6 +150,12 @@ struct cfdh_ctx {
 
   // geometric dimension: 2 (triangles, 3x3 vertex blocks) or 3 (tetrahedra, 4x4 vertex blocks; single GPU)
   int dim = 2;
+  // element: 0 P1 simplices (closed-form kernels), 1 P2 triangles, 2 Q1 parallelograms -- `gen`: the quadrature kernels of
+  // cfdh_gen.hip assemble (also for etype 0 when created as CFDH_ELEM_P1_GENERIC); "vertex" then means node everywhere below
+  int etype = 0, nloc = 3;
+  bool gen = false;
+  dbuf<int> gslot;             // [nc][nloc * nloc] value slot of the local node pair (a, b) in the vertex-graph arrays
+  dbuf<unsigned short> gflag;  // [nc] bit f: exterior facet f, bit 8 + f: backflow facet f
   // sizes (local part): nv = nvo owned + ng ghosts
   int nv = 0, nvo = 0, ng = 0, nc = 0, nfac = 0;
   int NL = 0;   // vector length incl. ghost tail = 3*nvo + 3*ng
@@ -381,6 +387,15 @@ int k3_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double
 int k3_nullspace_test(cfdh_ctx *c, double *nrm, double *absnrm);
 int k3_functional(cfdh_ctx *c, int kind, int marker, double *out);
 int k3_wss(cfdh_ctx *c, double *out);
+
+// ---- nodal elements beyond P1 (cfdh_gen.hip) ------------------------------------------
+int kg_upload_tables(cfdh_ctx *c);
+int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv, int64_t nc, const int32_t *cells, const double *coords, int64_t nfac,
+                        const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker);
+int cfdh_facet_nodes(const cfdh_ctx *c, int f, int out[3]);  // local nodes of local facet f; returns their number
+int kg_assemble(cfdh_ctx *c, const double *xstate, int mode);
+int kg_functional_partials(cfdh_ctx *c, int kind, int marker, int nb);  // per-block partial sums into red_partial
+int kg_wss(cfdh_ctx *c, double *out);
 
 // ---- kernels (cfdh_kernels.hip) ----------------------------------------------------
 void prof_begin(cfdh_ctx *c, int kind);

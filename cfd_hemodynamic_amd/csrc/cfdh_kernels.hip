@@ -22,7 +22,7 @@
 #include <cmath>
 
 #include "cfdh_internal.hpp"
-#include "quad_tri.h"
+#include "cfdh_quad_tri.h"
 
 #define TPB 256
 // streamed-once operands (matrix values / columns of the AMG sweeps): non-temporal loads keep them from evicting the
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(TPB) void moments_kernel(int nc, int nvo, const int
 }
 
 int k_moments(cfdh_ctx *c) {
+  if (c->gen) { c->mom_valid = true; return 0; }  // tau is evaluated inside the quadrature loop of the generic kernels
   if (c->dim == 3) return k3_moments(c);
   prof_begin(c, 2);
   hipLaunchKernelGGL(moments_kernel, dim3((c->nc + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nc, c->nvo, c->cells.p,
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
 }
 
 int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
+  if (c->gen) return kg_assemble(c, xstate, mode);
   if (c->dim == 3) return k3_assemble(c, xstate, mode);
   AsmArgs a;
   a.coords = c->coords.p; a.mom = c->mom.p; a.x = xstate; a.un = c->xprev.p; a.un2 = c->xprev2.p; a.bcval = c->bcval.p; a.bcmult = c->bcmult.p;
@@ -2289,6 +2291,7 @@ __global__ __launch_bounds__(TPB) void wss_kernel(int nfac, int nvo, const int *
   atomicAdd(out + 2 * (size_t)v2, Tt[0]); atomicAdd(out + 2 * (size_t)v2 + 1, Tt[1]);
 }
 int k_wss(cfdh_ctx *c, double *out) {
+  if (c->gen) return kg_wss(c, out);
   if (c->dim == 3) return k3_wss(c, out);
   HIPCHK(c, hipMemsetAsync(out, 0, sizeof(double) * 2 * (size_t)c->nv, c->stream));
   if (c->nfac > 0)
@@ -2301,7 +2304,9 @@ int k_wss(cfdh_ctx *c, double *out) {
 int k_functional(cfdh_ctx *c, int kind, int marker, double *out) {
   if (c->dim == 3) return k3_functional(c, kind, marker, out);
   const int nb = 256;
-  if (kind == 0 || kind == 1) {
+  if (c->gen && (kind <= 3 || kind == 7)) {
+    CHK(kg_functional_partials(c, kind, marker, nb));
+  } else if (kind == 0 || kind == 1) {
     // a part without exterior facets (nfac == 0) still launches: the kernel then only writes zero partials, and the
     // rank takes part in the reduction below like every other one (skipping it would desynchronise the collectives)
     hipLaunchKernelGGL(draglift_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nfac, marker, c->nvo, c->d_fac_cell.p,

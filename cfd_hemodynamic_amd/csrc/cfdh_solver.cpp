@@ -88,6 +88,26 @@ static int build_schur_host(cfdh_ctx *c, CsrHost &S) {
   return 0;
 }
 
+// Do-nothing boundary (ds_terms off): the nodes of every exterior facet that is not a no-slip / inflow facet (all velocity
+// components of all its nodes constrained) form the outflow boundary of the preconditioner's pressure Poisson problem: bit 1.
+static void mark_outflow_nodes(const cfdh_ctx *c, std::vector<unsigned char> &pbc) {
+  const unsigned umask = (1u << c->dim) - 1u;
+  const int nvo = c->nvo;
+  for (int k = 0; k < c->nfac; k++) {
+    const int e = c->fac_cell[k], fl = c->fac_local[k];
+    int loc[4], nn = 0;
+    if (c->gen) nn = cfdh_facet_nodes(c, fl, loc);
+    else for (int q = 0; q <= c->dim; q++) if (q != fl) loc[nn++] = q;
+    bool fixed = true;
+    for (int q = 0; q < nn; q++) fixed = fixed && (c->h_bcflag[c->h_cells[(size_t)c->nloc * e + loc[q]]] & umask) == umask;
+    if (fixed) continue;
+    for (int q = 0; q < nn; q++) {
+      const int v = c->h_cells[(size_t)c->nloc * e + loc[q]];
+      if (v < nvo) pbc[v] |= 2;
+    }
+  }
+}
+
 // pc_type 1 -- host side of the Cahouet-Chabard-type preconditioner (all rank-local, owned x owned):
 //   * hA : SA hierarchy of the scalar proxy (A00_xx + A00_yy)/2 of the velocity block, applied to both
 //          components at once (the xy coupling of the symmetric-gradient term is dropped: Korn-equivalent);
@@ -175,19 +195,9 @@ static int build_cc_host(cfdh_ctx *c) {
   // with a do-nothing boundary (ds_terms off) the vertices of every exterior facet that is not a
   // no-slip/inflow facet form the outflow boundary of the pressure Poisson problem.
   std::vector<unsigned char> pbc(nvo);
-  const unsigned pbit = 1u << c->dim, umask = pbit - 1u;  // bits 0..dim-1: velocity components, bit dim: pressure
+  const unsigned pbit = 1u << c->dim;  // bits 0..dim-1: velocity components, bit dim: pressure
   for (int i = 0; i < nvo; i++) pbc[i] = (c->h_bcflag[i] & pbit) ? 1 : 0;
-  if (!c->ds_terms)
-    for (int k = 0; k < c->nfac; k++) {
-      const int e = c->fac_cell[k], fl = c->fac_local[k], n1 = c->dim + 1;
-      bool fixed = true;
-      for (int q = 0; q < n1; q++) if (q != fl) fixed = fixed && (c->h_bcflag[c->h_cells[(size_t)n1 * e + q]] & umask) == umask;
-      if (fixed) continue;
-      for (int q = 0; q < n1; q++) {
-        const int v = c->h_cells[(size_t)n1 * e + q];
-        if (q != fl && v < nvo) pbc[v] |= 2;
-      }
-    }
+  if (!c->ds_terms) mark_outflow_nodes(c, pbc);
   if (!c->hL.valid || c->hL_pbc != pbc || c->hL_singular != c->singular) {
     CsrHost Lh;
     Lh.n = Lh.m = nvo;
@@ -326,19 +336,9 @@ static int build_cc_dev(cfdh_ctx *c) {
   const double t1 = wall_ms();
   // pressure Laplacian hierarchy: geometry and Dirichlet set only (see build_cc_host for the pbc bits)
   std::vector<unsigned char> pbc(nvo);
-  const unsigned pbit = 1u << c->dim, umask = pbit - 1u;
+  const unsigned pbit = 1u << c->dim;
   for (int i = 0; i < nvo; i++) pbc[i] = (c->h_bcflag[i] & pbit) ? 1 : 0;
-  if (!c->ds_terms)
-    for (int k = 0; k < c->nfac; k++) {
-      const int e = c->fac_cell[k], fl = c->fac_local[k], n1 = c->dim + 1;
-      bool fixed = true;
-      for (int q = 0; q < n1; q++) if (q != fl) fixed = fixed && (c->h_bcflag[c->h_cells[(size_t)n1 * e + q]] & umask) == umask;
-      if (fixed) continue;
-      for (int q = 0; q < n1; q++) {
-        const int v = c->h_cells[(size_t)n1 * e + q];
-        if (q != fl && v < nvo) pbc[v] |= 2;
-      }
-    }
+  if (!c->ds_terms) mark_outflow_nodes(c, pbc);
   if (!c->hL.valid || c->hL_pbc != pbc || c->hL_singular != c->singular) {
     CsrHost Lh;
     Lh.n = Lh.m = nvo;

@@ -38,9 +38,14 @@ class VTUWriter:
         data = vals.reshape(nv, bs)
         if bs == 2:  # ParaView wants 3-component vectors
             data = np.concatenate([data, np.zeros((nv, 1))], axis=1)
-        npc = m.cells.shape[1]  # 3: VTK_TRIANGLE (5), 4: VTK_TETRA (10)
-        arrays = [pts.ravel(), np.ascontiguousarray(m.cells, dtype=np.int32).ravel(),
-                  (npc * np.arange(1, nc + 1)).astype(np.int32), np.full(nc, 5 if npc == 3 else 10, dtype=np.uint8), data.ravel()]
+        npc = m.cells.shape[1]  # 3: VTK_TRIANGLE (5), 4: VTK_TETRA (10) / VTK_QUAD (9) in 2-D, 6: VTK_QUADRATIC_TRIANGLE (22)
+        conn, ctype = np.ascontiguousarray(m.cells, dtype=np.int32), (5 if npc == 3 else 10)
+        if npc == 4 and m.x.shape[1] == 2:
+            conn, ctype = conn[:, [0, 1, 3, 2]], 9          # DOLFINx tensor-product order -> VTK's cyclic order
+        elif npc == 6:
+            conn, ctype = conn[:, [0, 1, 2, 5, 3, 4]], 22   # edge nodes: VTK wants (0-1), (1-2), (2-0); ours are opposite vertex 0, 1, 2
+        arrays = [pts.ravel(), np.ascontiguousarray(conn).ravel(),
+                  (npc * np.arange(1, nc + 1)).astype(np.int32), np.full(nc, ctype, dtype=np.uint8), data.ravel()]
         offs, blob = [], bytearray()
         for a in arrays:
             offs.append(len(blob))

@@ -46,18 +46,29 @@ class SolverBase(ABC):
     def solveStep(self) -> None:
         pass
 
+    def _dof_mesh(self, degree):
+        """The node set of Lagrange elements of `degree` on the mesh: the mesh itself for P1 / Q1, vertices + edge midpoints
+        for P2 triangles (`p_grade = 2`, stabilized_schur_backflow.py:84-87)."""
+        from .elements import dof_mesh
+        dm = dof_mesh(self.mesh, degree)
+        if getattr(self, "_dm", None) not in (None, dm):
+            raise ValueError("velocity and pressure must use the same Lagrange degree (equal-order elements)")
+        self._dm = dm
+        return dm
+
     def initVelocitySpace(self, family, cell, degree, shape=None) -> None:
-        if int(degree) != 1:
-            raise ValueError("only P1 velocity is implemented")
-        self._V = FunctionSpace(self.mesh, self.mesh.geometry.dim if shape is None else int(shape[0]))
+        if str(family) not in ("Lagrange", "CG", "P"):
+            raise ValueError("only Lagrange spaces are implemented")
+        dm = self._dof_mesh(degree)
+        self._V = FunctionSpace(dm, self.mesh.geometry.dim if shape is None else int(shape[0]))
         self._u_sol = Function(self.V, name="velocity")
         self._u_prev = Function(self.V)
         self.u_residual = Function(self.V, name="u_residual")
 
     def initPressureSpace(self, family, cell, degree, shape=None) -> None:
-        if int(degree) != 1:
-            raise ValueError("only P1 pressure is implemented")
-        self._Q = FunctionSpace(self.mesh, 1)
+        if str(family) not in ("Lagrange", "CG", "P"):
+            raise ValueError("only Lagrange spaces are implemented")
+        self._Q = FunctionSpace(self._dof_mesh(degree), 1)
         self._p_sol = Function(self.Q, name="pressure")
         self._p_prev = Function(self.Q)
         self.p_residual = Function(self.Q, name="p_residual")
@@ -65,8 +76,9 @@ class SolverBase(ABC):
     def initStressForm(self):
         """Allocates the stress fields the Scenario writes
         (/root/reference/src/solverBase.py:144-173)."""
-        self.normal_stress = Function(FunctionSpace(self.mesh, 1), name="normal_stress")
-        self.shear_stress = Function(FunctionSpace(self.mesh, self.mesh.geometry.dim), name="shear_stress")
+        dm = getattr(self, "_dm", None) or self.mesh
+        self.normal_stress = Function(FunctionSpace(dm, 1), name="normal_stress")
+        self.shear_stress = Function(FunctionSpace(dm, self.mesh.geometry.dim), name="shear_stress")
 
     def assemble_wss(self):
         """Wall shear stress  (1/|e|) oint w . (T - (T.n) n),  T = -sigma(u,p) n
@@ -75,8 +87,8 @@ class SolverBase(ABC):
         if not hasattr(self, "shear_stress"):
             return
         mesh = self.mesh
-        if mesh.geometry.dim != 2:
-            raise NotImplementedError("host restatement of the wall shear stress: triangles only (the device path covers tetrahedra)")
+        if mesh.geometry.dim != 2 or getattr(getattr(self, "_dm", mesh), "etype", 0) != 0:
+            raise NotImplementedError("host restatement of the wall shear stress: P1 triangles only (the device path covers the other elements)")
         u = self.u_sol.x.array.reshape(-1, 2)
         mu = float(self.mu.value)
         fc, fl, fv = mesh.facet_cells, mesh.facet_local, mesh.facet_vertices

@@ -31,8 +31,15 @@ class Solver(SolverBase):
     def __init__(self, mesh, dt: float, rho: float, mu: float, f: list,
                  initial_velocity: Callable[[np.ndarray], np.ndarray] = None, **kwargs):
         super().__init__(mesh, dt, rho, mu, f)
-        super().initVelocitySpace("Lagrange", mesh.topology.cell_name(), 1, shape=(mesh.geometry.dim,))
-        super().initPressureSpace("Lagrange", mesh.topology.cell_name(), 1)
+        # Lagrange degree of both spaces: 1 as in stabilized_schur.py:55-57 (on quadrilateral cells that is Q1); the backflow
+        # variant passes its p_grade (stabilized_schur_backflow.py:84-87)
+        degree = int(kwargs.pop("_degree", 1))
+        super().initVelocitySpace("Lagrange", mesh.topology.cell_name(), degree, shape=(mesh.geometry.dim,))
+        super().initPressureSpace("Lagrange", mesh.topology.cell_name(), degree)
+        dm = self._dm
+        etype = int(getattr(dm, "etype", 0))
+        if kwargs.get("generic_kernels") and etype == 0 and mesh.geometry.dim == 2:
+            etype = 3  # P1 triangles through the quadrature kernels of the P2 / Q1 path (cross-check)
         if initial_velocity:
             self.u_prev.interpolate(initial_velocity)
         self._mu_float = float(mu)  # raw python float of the ds term (stabilized_schur.py:79)
@@ -41,7 +48,11 @@ class Solver(SolverBase):
         self._comm = kwargs.get("comm", None)
         device = int(kwargs.get("device", 0))
         self._part = None
-        if self._comm is not None and self._comm.size > 1:
+        if etype != 0:
+            if self._comm is not None and self._comm.size > 1:
+                raise NotImplementedError("P2 / Q1 elements run on one GPU")
+            self.ctx = _lib.Context(dm.x, dm.cells, dm.facet_cells, dm.facet_local, dm.facet_marker, device=device, etype=etype)
+        elif self._comm is not None and self._comm.size > 1:
             from ..mesh import PartCommView
             mesh.comm = PartCommView(self._comm)  # rank-0 guards of the harness (printing, file output) see the real rank
             part = self._comm.make_part(mesh)

@@ -9,7 +9,7 @@
 
 Same gfx950 kernels; `cfdh_set_boundary_terms(ds_terms=0, outlet marker, beta)` selects the
 facet terms.  Constructor as in the reference: `v_max` is required (ValueError otherwise, :66-70),
-`p_grade` must be 1 here (P2/P2 is SURVEY.md section 8f rank 4), `beta_backflow` defaults to 0.2.
+`p_grade` 1 or 2 (P2/P2 on the node set of `elements.NodeMesh`, quadrature kernels of csrc/cfdh_gen.hip), `beta_backflow` defaults to 0.2.
 """
 from __future__ import annotations
 
@@ -29,8 +29,10 @@ class Solver(_MidpointSolver):
                  v_max: float = None, p_grade: int = 1, beta_backflow: float = 0.2, **kwargs):
         if v_max is None:
             raise ValueError("v_max is required for stabilized_schur_backflow. Pass it via CLI: --v_max <value>")
-        if int(p_grade) != 1:
-            raise NotImplementedError("p_grade=%r: only P1/P1 runs on the gfx950 kernels" % (p_grade,))
+        if int(p_grade) not in (1, 2):
+            raise NotImplementedError("p_grade=%r: P1/P1 and P2/P2 run on the gfx950 kernels" % (p_grade,))
+        self.p_grade = int(p_grade)
+        kwargs["_degree"] = self.p_grade
         self.v_max = float(v_max)
         self.beta_backflow = float(beta_backflow)
         for k in ("p_inlet", "p_outlet", "beta_nitsche", "R_resistance", "initial_ffr"):

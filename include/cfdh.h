@@ -112,6 +112,18 @@ typedef struct cfdh_stats {
 int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_owned, int64_t nc,
                 const int32_t *cells, const double *coords, int64_t nfacets, const int32_t *facet_cells,
                 const int32_t *facet_local, const int32_t *facet_marker);
+/* The same for nodal equal-order elements beyond P1 simplices: `p_grade = 2` of
+ * stabilized_schur_backflow.py:84-87 (P2/P2 triangles on a straight-sided triangulation) and quadrilateral cells as
+ * unit_square_pipe.py:101-105 builds them (Q1/Q1; parallelograms only: the geometry map must be affine).
+ * cells [nc][nloc] list NODE ids in the DOLFINx/Basix local order -- P2 triangle: vertices 0,1,2 then the edge nodes opposite
+ * to them (nloc 6); Q1 quadrilateral: (0,0),(1,0),(0,1),(1,1) (nloc 4); node_coords [nn][2].  Local facets: triangle f =
+ * opposite vertex f; quadrilateral 0:(0,1) 1:(0,2) 2:(1,3) 3:(2,3).  Every node carries (u_x, u_y, p): all other calls take
+ * node ids / per-node arrays where they say vertex.  Single GPU.  CFDH_ELEM_P1_GENERIC runs P1 triangles through the
+ * quadrature kernels of the P2/Q1 path (a cross-check of the closed-form P1 kernels). */
+enum { CFDH_ELEM_P1 = 0, CFDH_ELEM_P2_TRIANGLE = 1, CFDH_ELEM_Q1_QUADRILATERAL = 2, CFDH_ELEM_P1_GENERIC = 3 };
+int cfdh_create_elem(cfdh_ctx **out, int device, int gdim, int elem, int64_t nn, int64_t nc, const int32_t *cells,
+                     const double *node_coords, int64_t nfacets, const int32_t *facet_cells, const int32_t *facet_local,
+                     const int32_t *facet_marker);
 /* (Re)assign the markers of the exterior facets after cfdh_create: the reference hands `facet_tags` / `tags` to
  * Solver.setup(), not to the constructor (/root/reference/src/scenario.py:137-149;
  * stabilized_schur_backflow.py:158-163 builds ds_out from them there).  markers[nfacets] in the facet order of
@@ -266,7 +278,8 @@ int cfdh_profile_reset(cfdh_ctx *ctx);
  * (stream/event waits for scalars), 16 FGMRES iterations, 17 all-gathers; 18: communicator size;
  * fused AMG cycle: 19 / 20 entries of Sb + Sc on level 0 (pressure / velocity hierarchy), 21 / 22 entries of G on
  * level 0, 23 / 24 size of level 1, 25: fused cycle in use; 26: gdim;
- * 27: microseconds the last preconditioner build took on the device (0: it was built on the host);
+ * 27: microseconds the last preconditioner build took on the device (0: it was built on the host); 28: element type (CFDH_ELEM_*),
+ * 29: nodes per cell;
  * 30 + l / 40 + l: rows / entries of level l of the velocity hierarchy, 50 + l / 60 + l: of the pressure hierarchy (l < 10, 0 past the end) */
 int64_t cfdh_info(const cfdh_ctx *ctx, int what);
 

@@ -41,7 +41,7 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
-#include "quad_tri.h"
+#include "cfdh_quad_tri.h"
 
 #define EPS_VNORM 1e-15 /* np.finfo(float64).resolution, stabilized_schur.py:100 */
 

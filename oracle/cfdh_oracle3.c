@@ -23,7 +23,7 @@
 #include <stddef.h>
 #include <string.h>
 
-#include "quad_tet.h"
+#include "cfdh_quad_tet.h"
 
 #define EPS_VNORM2 1e-30 /* (1e-15)^2: max(2|u|, eps)^2 with eps = 1e-15 as 4 s vs eps^2 */
 

@@ -15,7 +15,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "libcfdh_oracle.so")
-    srcs = [os.path.join(_HERE, n) for n in ("cfdh_oracle.c", "cfdh_oracle3.c")]
+    srcs = [os.path.join(_HERE, n) for n in ("cfdh_oracle.c", "cfdh_oracle3.c", "cfdh_oracle_gen.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(q) for q in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
