@@ -414,6 +414,7 @@ int k_extract_diag(cfdh_ctx *c);
 int k_cheb_a00(cfdh_ctx *c, const double *b, double *x);
 int k_cheb_a00_coeffs(cfdh_ctx *c);  // x = Cheb_k(A00) b, zero initial guess
 int k_csr_spmv(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mode, const double *b);  // mode 0: y=Ax, 1: y=b-Ax, 2: y+=Ax
+int k_csr_spmv_ncol(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mode, const double *b, int ncol);
 int k_amg_vcycle(cfdh_ctx *c, AmgHier &H, const double *b, double *x);
 int k_level_smooth(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, int degree);
 bool k_cc_cheb2_scale(cfdh_ctx *c, AmgLevel *L, const double *b, double *x, const double *ml, double *y);

@@ -1072,6 +1072,12 @@ static int csr_spmv_t(cfdh_ctx *c, const CsrDev &A, const T *x, T *y, int mode, 
 int k_csr_spmv(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mode, const double *b) {
   return csr_spmv_t<double>(c, A, x, y, mode, b);
 }
+// the same scalar matrix applied to ncol interleaved right-hand sides (velocity components through the scalar proxy)
+int k_csr_spmv_ncol(cfdh_ctx *c, const CsrDev &A, const double *x, double *y, int mode, const double *b, int ncol) {
+  if (ncol == 2) return csr_spmv_t<double2>(c, A, (const double2 *)x, (double2 *)y, mode, (const double2 *)b);
+  if (ncol == 3) return csr_spmv_t<d3>(c, A, (const d3 *)x, (d3 *)y, mode, (const d3 *)b);
+  return csr_spmv_t<double>(c, A, x, y, mode, b);
+}
 
 // One Chebyshev step on a scalar CSR level (single right-hand side):
 //   r_out = r_in - A d_old ; d_new = c1 d_old + c2 D^-1 r_out ; x (+)= ...

@@ -495,6 +495,20 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
           CHK(k_gather_global(c, nvo, c->gp_l2g.p, c->gp_sol.p, c->pu2.p));
         } else {
           // rank-local cycle: the combination below runs in the epilogue of its last kernel when the fused cycle is used
+          static const int lcycles = getenv("CFDH_L_CYCLES") ? atoi(getenv("CFDH_L_CYCLES")) : 1;
+          if (lcycles > 1 && c->hL.lev.size() >= 1 && c->hL.lev[0]->A.val.p) {
+            // experiment: k V-cycles on the pressure Laplacian (stationary iteration x += V(b - L x))
+            AmgLevel *L0 = c->hL.lev[0];
+            CHK(k_amg_vcycle(c, c->hL, c->pu1.p, c->pu2.p));
+            for (int cyc = 1; cyc < lcycles; cyc++) {
+              CHK(k_csr_spmv(c, L0->A, c->pu2.p, L0->r.p, 1, c->pu1.p));   // r = y - L t
+              CHK(k_amg_vcycle(c, c->hL, L0->r.p, L0->d0.p));
+              CHK(v_axpy(c, nvo, 1.0, L0->d0.p, c->pu2.p));
+            }
+            CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, upper ? rp : c->pp0.p, c->ccPbc.p, zp));
+            if (multi && c->opt.schur_full) CHK(v_copy(c, nvo, zp, c->pcw.p + nu));
+            return 0;
+          }
           c->epi.on = true; c->epi.done = false;
           c->epi.alpha = c->cc_alpha; c->epi.beta = c->cc_beta; c->epi.zH = c->pp1.p; c->epi.r = upper ? rp : c->pp0.p;
           c->epi.pbc = c->ccPbc.p; c->epi.out = zp;
@@ -511,7 +525,19 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
           if (multi) CHK(k_spmv_block_ghost(c, 2, c->pcw.p, c->pu0.p, ru));  // t_u = r_u - A01 z_p (with ghosts)
           else CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));
           if (multi && c->ras) CHK(v_copy(c, nu, c->pu0.p, c->pcw.p));       // t_u into the halo scratch vector; cycle in stage 4
-          else CHK(k_amg_vcycle(c, c->hA, c->pu0.p, zu));
+          else {
+            CHK(k_amg_vcycle(c, c->hA, c->pu0.p, zu));
+            static const int acycles = getenv("CFDH_A_CYCLES") ? atoi(getenv("CFDH_A_CYCLES")) : 1;
+            if (acycles > 1 && !multi && c->hA.lev[0]->A.val.p) {
+              // experiment: further V-cycles on the velocity proxy (stationary iteration)
+              AmgLevel *L0 = c->hA.lev[0];
+              for (int cyc = 1; cyc < acycles; cyc++) {
+                CHK(k_csr_spmv_ncol(c, L0->A, zu, L0->r.p, 1, c->pu0.p, c->dim));
+                CHK(k_amg_vcycle(c, c->hA, L0->r.p, L0->d0.p));
+                CHK(v_axpy(c, nu, 1.0, L0->d0.p, zu));
+              }
+            }
+          }
         } else {
           CHK(v_copy(c, nu, multi ? c->pcw.p : c->pu0.p, zu));              // block lower-triangular variant
         }

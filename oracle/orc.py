@@ -89,7 +89,7 @@ def default_opts(**kw):
 
 
 class Oracle:
-    """Plain-array problem: x [nv,2], cells [nc,3], exterior facets (cell, local)."""
+    """Plain-array problem: x [nv,2], cells [nc,3] (or x [nv,3], cells [nc,4]: tetrahedra), exterior facets (cell, local)."""
 
     def __init__(self, x, cells, facet_cells, facet_local, dt, rho, mu, f=(0.0, 0.0), mu_facet=None):
         L = lib()
@@ -98,9 +98,14 @@ class Oracle:
         self.fc = np.ascontiguousarray(facet_cells, dtype=np.int32)
         self.fl = np.ascontiguousarray(facet_local, dtype=np.int32)
         self.nv, self.nc = len(self.x), len(self.cells)
-        self.ndof = 3 * self.nv
-        self.h = L.orc_create(self.nv, self.nc, _ip(self.cells), _dp(self.x), len(self.fc), _ip(self.fc), _ip(self.fl))
-        ff = np.asarray(f, dtype=np.float64)
+        self.dim = self.cells.shape[1] - 1   # triangles: 2; tetrahedra: 3 (element tensors from cfdh_oracle3.c, pc_kind 2 only)
+        assert self.x.shape[1] == self.dim
+        self.ndof = (self.dim + 1) * self.nv
+        L.orc_create_d.restype = C.c_void_p
+        L.orc_create_d.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self.h = L.orc_create_d(self.dim, self.nv, self.nc, _ip(self.cells), _dp(self.x), len(self.fc), _ip(self.fc), _ip(self.fl))
+        ff = np.zeros(3)
+        ff[: len(np.atleast_1d(f))] = np.asarray(f, dtype=np.float64)
         L.orc_set_params(self.h, dt, rho, mu, mu if mu_facet is None else mu_facet, _dp(ff))
         self.mu = mu
 
@@ -121,7 +126,7 @@ class Oracle:
 
     def add_bc_u(self, nodes, values):
         nodes = np.ascontiguousarray(nodes, dtype=np.int32)
-        values = np.ascontiguousarray(values, dtype=np.float64).reshape(-1, 2)
+        values = np.ascontiguousarray(values, dtype=np.float64).reshape(-1, self.dim)
         lib().orc_add_bc(self.h, 0, len(nodes), _ip(nodes), _dp(values))
 
     def add_bc_p(self, nodes, values):

@@ -10,12 +10,13 @@ from oracle import orc
 class Solver(SolverBase):
     def __init__(self, mesh, dt, rho, mu, f, initial_velocity=None, **kwargs):
         super().__init__(mesh, dt, rho, mu, f)
-        self.initVelocitySpace("Lagrange", "triangle", 1, shape=(2,))
-        self.initPressureSpace("Lagrange", "triangle", 1)
+        self.gdim = mesh.geometry.dim  # 2: triangles; 3: tetrahedra (C driver with the element tensors of cfdh_oracle3.c, pc_kind 2)
+        self.initVelocitySpace("Lagrange", mesh.topology.cell_name(), 1, shape=(self.gdim,))
+        self.initPressureSpace("Lagrange", mesh.topology.cell_name(), 1)
         if initial_velocity:
             self.u_prev.interpolate(initial_velocity)
         self.O = orc.Oracle(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, dt, rho, mu, f)
-        self.opts = orc.default_opts(pc_kind=int(kwargs.get("pc_kind", 1)))
+        self.opts = orc.default_opts(pc_kind=int(kwargs.get("pc_kind", 2 if self.gdim == 3 else 1)))
         for k, v in dict(kwargs.get("options", {})).items():
             setattr(self.opts, k, v)
         self.nv = mesh.num_vertices
@@ -23,7 +24,7 @@ class Solver(SolverBase):
         self.calls = 0
         # bdf2=True: the time discretisation of stabilized_schur_bdf2.py (BDF1 on the first step, BDF2 afterwards)
         self.bdf2 = bool(kwargs.get("bdf2", False))
-        self._un2 = np.zeros(2 * self.nv)
+        self._un2 = np.zeros(self.gdim * self.nv)
 
     def setup(self, bcu, bcp, facet_tags=None, tags=None):
         self._bcs = [(0, bc.getBC(self.V)) for bc in bcu] + [(1, bc.getBC(self.Q)) for bc in bcp]
@@ -34,7 +35,7 @@ class Solver(SolverBase):
         for fld, bc in self._bcs:
             bc.update()
             if fld == 0:
-                self.O.add_bc_u(bc.dofs, bc.g.x.array.reshape(-1, 2)[bc.dofs])
+                self.O.add_bc_u(bc.dofs, bc.g.x.array.reshape(-1, self.gdim)[bc.dofs])
             else:
                 self.O.add_bc_p(bc.dofs, bc.g.x.array[bc.dofs])
         self.O.set_un(self.u_prev.x.array)
@@ -43,8 +44,8 @@ class Solver(SolverBase):
             self.O.set_un2(self._un2)
             self._un2 = np.array(self.u_prev.x.array, copy=True)  # u_prev2 of the next step
         self.x_n, st = self.O.solve_step(self.x_n, self.opts)
-        self.u_sol.x.array[:] = self.x_n[: 2 * self.nv]
-        self.p_sol.x.array[:] = self.x_n[2 * self.nv:]
+        self.u_sol.x.array[:] = self.x_n[: self.gdim * self.nv]
+        self.p_sol.x.array[:] = self.x_n[self.gdim * self.nv:]
         self.last_stats = st
         self.calls += 1
 
@@ -55,5 +56,19 @@ class Solver(SolverBase):
 
     def functional(self, kind, marker=0):
         """Same contract as the product Solver.functional (cfdh_functional kinds 0-3)."""
+        if self.gdim == 3:
+            if kind not in (2, 3):
+                raise NotImplementedError("tetrahedral test double: L2 norms only")
+            # int_K l_a l_b = |K| (1 + d_ab) / 20 (scenario.py:315-324 on P1 tetrahedra)
+            m = self.mesh
+            X = m.x[m.cells]
+            vol = np.abs(np.linalg.det(X[:, 1:] - X[:, :1])) / 6.0
+            mab = vol[:, None, None] * (1.0 + np.eye(4))[None] / 20.0
+            nv = self.nv
+            if kind == 2:
+                ue = self.x_n[: 3 * nv].reshape(-1, 3)[m.cells]
+                return float(np.sqrt(np.einsum("cab,cai,cbi->", mab, ue, ue)))
+            pe = self.x_n[3 * nv:][m.cells]
+            return float(np.sqrt(np.einsum("cab,ca,cb->", mab, pe, pe)))
         facets = np.nonzero(self.mesh.facet_marker == marker)[0] if kind in (0, 1) else None
         return self.O.functional(self.x_n, kind, facets)

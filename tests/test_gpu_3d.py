@@ -305,3 +305,38 @@ def test_tet_assembly_matches_the_c_oracle(monkeypatch):
         v = rng.standard_normal(4 * nv)
         assert np.abs(ctx.spmv(v) - J @ v).max() <= 1e-12 * np.abs(J @ v).max()
         ctx.close()
+
+
+def test_tet_time_steps_match_the_c_oracle_solver_at_138k_dof():
+    """Step parity at size: the bifurcation at res 4e-4 (138 k DOF) against the C oracle's own Newton / FGMRES / Cahouet-Chabard +
+    AMG driver on tetrahedra (oracle/cfdh_oracle.c with the element tensors of cfdh_oracle3.c) -- the twin's direct solve stops
+    at ~10^4 DOF.  Both sides converged tightly; two steps from rest."""
+    from oracle import orc
+    mesh, ft = create_bifurcation(4e-4)
+    nv = mesh.num_vertices
+    assert 4 * nv > 100000
+    Re = 1055.0 * 0.01 * ((100 / 0.003918604) / 1e6) / 3.5e-3
+    bcs = _bifurcation_bcs(mesh, ft)
+    ctx = _lib.Context(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, mesh.facet_marker)
+    ctx.set_params(0.01, 1.0, 1.0 / Re, f=(0.0, 0.0, 0.0))
+    O = orc.Oracle(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, 0.01, 1.0, 1.0 / Re, (0.0, 0.0, 0.0))
+    for fld, nodes, vals in bcs:
+        ctx.add_dirichlet(fld, nodes, vals)
+        (O.add_bc_u if fld == 0 else O.add_bc_p)(nodes, vals)
+    o = ctx.default_options()
+    o.snes_rtol, o.snes_stol, o.ksp_rtol, o.remove_p_mean = 1e-11, 0.0, 1e-9, 0
+    ctx.set_options(o)
+    oo = orc.default_opts(pc_kind=2, snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-9, remove_p_mean=0)
+    z3, z1 = np.zeros(3 * nv), np.zeros(nv)
+    ctx.set_state(u_prev=z3, p_prev=z1, u=z3, p=z1)
+    x = np.zeros(4 * nv)
+    for step in range(2):
+        st = ctx.solve_step()
+        assert st.reason > 0
+        xg = np.concatenate(ctx.get_solution())
+        ctx.advance()
+        O.set_un(x[: 3 * nv].copy())
+        x, so = O.solve_step(x, oo)
+        assert np.linalg.norm(xg[: 3 * nv] - x[: 3 * nv]) <= 1e-7 * np.linalg.norm(x[: 3 * nv]), step
+        assert np.linalg.norm(xg[3 * nv:] - x[3 * nv:]) <= 1e-6 * np.linalg.norm(x[3 * nv:]), step
+    ctx.close()

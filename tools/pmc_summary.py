@@ -59,7 +59,9 @@ def main(dirs):
             e["hbm_bytes"] = e["fetch_bytes"] + e["write_bytes"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     flat = {k: v.get("hbm_bytes") for k, v in out.items()}
-    json.dump({"per_launch_bytes": flat, "detail": out,
+    sys.path.insert(0, root)
+    import bench  # the fingerprint of the kernel sources these counters were taken with: bench.py refuses a stale summary
+    json.dump({"kernel_source_sha16": bench.kernel_source_sha16(), "per_launch_bytes": flat, "detail": out,
                "note": "FETCH_SIZE x2 (gfx950 correction), KiB->bytes; level-0 dispatches only"},
               open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(flat, indent=1))
