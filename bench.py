@@ -72,6 +72,16 @@ def kernel_bytes(ctx):
             kb[8] = ("amg_down0_pressure", 8.0 * ctx.info(21) + 12.0 * ctx.info(23) + 8.0 * nvo)
             kb[9] = ("amg_down0_velocity_3rhs", 8.0 * ctx.info(22) + 28.0 * ctx.info(24) + 24.0 * nvo)
         return kb
+    if ctx.info(28) in (1, 2):
+        # P2 / Q1 nodal elements (csrc/cfdh_gen.hip): block values out (72 B per graph entry), per node coordinates, iterate,
+        # u_prev, Dirichlet data in (~80 B) and the residual out (24 B), connectivity and value slots per cell
+        nl = ctx.info(29)
+        kb = {0: ("gen_asm_residual_jacobian", 72.0 * nnzv + 104.0 * nvo + 4.0 * (nl + nl * nl) * nc),
+              1: ("spmv_full_block3x3", 76.0 * nnzv + 52.0 * nvo)}
+        if ctx.info(25):
+            kb[4] = ("amg_up0_pressure", 8.0 * ctx.info(19) + 16.0 * nvo + 8.0 * ctx.info(23))
+            kb[5] = ("amg_up0_velocity_2rhs", 8.0 * ctx.info(20) + 32.0 * nvo + 16.0 * ctx.info(24))
+        return kb
     kb = {
         # fused residual+Jacobian: SURVEY.md 8d figure, 624 B per vertex
         0: ("asm_residual_jacobian", 624.0 * nvo),
@@ -119,21 +129,31 @@ def make_scenario(args, solver_name, **kw):
         kw = dict(kw)
         kw["options"] = dict(kw.get("options", {}), remove_p_mean=0)
         return MicrovasculatureSimulation(solver_name, args.dt, 1.0, v_inlet=args.v_max, res=args.res3, quiet=True, **kw)
+    if cfg == "p2":
+        # `--simulation stenosis --solver stabilized_schur_backflow --p_grade 2` (P2/P2, do-nothing outlet)
+        from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
+        return StenosisSimulation("stabilized_schur_backflow", args.dt, 1.0, ny=args.ny, v_max=args.v_max, p_grade=2, beta_backflow=0.2, quiet=True, **kw)
+    if cfg == "q1":
+        # unit_square_pipe on quadrilateral cells (Q1/Q1), refined to --nx x --ny cells
+        from cfd_hemodynamic_amd.scenarios.unit_square_pipe import UnitSquarePipeSimulation
+        return UnitSquarePipeSimulation(solver_name, args.dt, 1.0, p_inlet=7.47, p_outlet=0.0, nx=args.nx, ny=args.ny, quiet=True, **kw)
     from cfd_hemodynamic_amd.scenarios.stenosis_with_tree import StenosisWithTreeSimulation
     return StenosisWithTreeSimulation(solver_name, args.dt, 1.0, grade="moderate", res=args.res, pulse_amplitude=0.5,
                                       ramp_time=args.ramp, inlet_max_velocity=args.v_max, quiet=True, **kw)
 
 
 def workload_text(args, sc):
-    nv = sc.mesh.num_vertices
+    nv = sc.solver.V.mesh.num_vertices  # nodes of the function space (= mesh vertices for P1 / Q1)
     head = {"c3": "dfg_1 (DFG 2D-1, Re=20) block-structured mesh m=%d" % args.m,
             "c2": "lid_driven2D (Re=100) unit square nx=%d" % args.nx,
             "c4": "stenosis \"moderate\" = the reference's effective geometry for every grade (L=138, R_in=1.57, R_out=1.2, x_sten=30, severity .567, slope .4), ny=%d, inlet v_max=%g mm/s, p=0 outlet" % (args.ny, args.v_max),
             "c5": "stenosis_with_tree grade moderate (L=0.03, H=0.003, severity .5, slope .5; 3-generation Murray tree, 8 outlets p=0), "
                   "res=%g, pulsatile inlet v_max (1 + 0.5 sin 2 pi t) with a (1 - cos(pi t / %g)) / 2 start-up ramp, v_max=%g" % (args.res, args.ramp, args.v_max),
+            "p2": "stenosis (reference geometry) with stabilized_schur_backflow --p_grade 2: P2/P2 triangles on ny=%d cells across, inlet v_max=%g mm/s, do-nothing outlet + backflow stabilisation" % (args.ny, args.v_max),
+            "q1": "unit_square_pipe (80 x 1.5 mm channel, p_inlet 7.47 / p_outlet 0, no-slip walls) on %d x %d quadrilateral cells, Q1/Q1" % (args.nx, args.ny),
             "c5b": "simple_bifurcation (3-D, tetrahedra; Re=%s, inlet u_y = %g (1 - (r/r_in)^2), p = 0 at both outlets; remove_p_mean=0), voxel-tet mesh res=%g" % (
                 ("%.1f" % sc.Re) if args.config == "c5b" else "-", args.v_max, args.res3)}[args.config]
-    return "%s: %d vertices, %d P1/P1 DOF, dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)" % (
+    return "%s: %d nodes, %d DOF (equal-order), dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)" % (
         head, nv, (sc.mesh.geometry.dim + 1) * nv, args.dt)
 
 
@@ -197,7 +217,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5", "c5b"])
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5", "c5b", "p2", "q1"],
+                    help="c3 (default) = the headline config; p2 / q1: the SURVEY 8f-4 element types (P2/P2 stenosis with the backflow plugin, "
+                         "Q1/Q1 unit_square_pipe), no CPU leg")
     ap.add_argument("--res3", type=float, default=2.0e-4, help="c5b: voxel size of the 3-D bifurcation (2e-4: 256 k vertices, 1.03 M DOF; 1e-4: 1.95 M vertices, 7.8 M DOF)")
     ap.add_argument("--m", type=int, default=200, help="c3: DFG mesh parameter (m=200: 336,273 vertices, 1,008,819 DOF)")
     ap.add_argument("--nx", type=int, default=288, help="c2: cells per side")
@@ -222,7 +244,13 @@ def main():
     if args.dt is None:
         args.dt = 0.001 if args.config == "c5" else 0.01
     if args.v_max is None:
-        args.v_max = {"c5": 0.05, "c5b": 1.5}.get(args.config, 100.0)
+        args.v_max = {"c5": 0.05, "c5b": 1.5, "p2": 20.0}.get(args.config, 100.0)
+    if args.config == "p2" and args.ny == 115:
+        args.ny = 40      # 82 k vertices -> 330 k P2 nodes, ~1 M DOF
+    if args.config == "q1" and (args.nx, args.ny) == (288, 115):
+        args.nx, args.ny = 5870 // 2, 110 // 2   # the reference's 587 x 11 cells refined 5 x: 2935 x 55 -> 164 k nodes, 0.49 M DOF
+    if args.config in ("p2", "q1"):
+        args.no_cpu_baseline = True
     if args.parity_steps is None:
         args.parity_steps = {"c5": 0, "c5b": 1}.get(args.config, 2)
 
@@ -390,7 +418,8 @@ def main():
                     "algorithmic_bytes": d["algorithmic_MB"] * 1e6, "empty_event_pair_us": ovh_us}
 
     label = {"c3": "dfg_1 ~1M DOF", "c2": "lid_driven2D ~250k DOF", "c4": "stenosis moderate ~2M DOF",
-             "c5": "stenosis_with_tree ~8M DOF pulsatile", "c5b": "simple_bifurcation 3-D tets"}[args.config]
+             "c5": "stenosis_with_tree ~8M DOF pulsatile", "c5b": "simple_bifurcation 3-D tets", "p2": "stenosis P2/P2 ~1M DOF (backflow plugin)",
+             "q1": "unit_square_pipe Q1/Q1 quadrilaterals"}[args.config]
     kits = max(sum(its_krylov), 1)
     out = {
         "metric": "time-steps/sec, %s (%s)" % (label, args.solver),

@@ -321,7 +321,7 @@ class Context:
         self._chk(self.L.cfdh_set_halo(self.h, len(a), _ip(a), _lp(sp_), _ip(si), _lp(rp), _ip(ri)))
 
     def set_global_pressure_space(self, x_global, cells_global, owned_global, pbc_nodes_global):
-        xg = np.ascontiguousarray(x_global, dtype=np.float64)[:, :2].copy()
+        xg = np.ascontiguousarray(x_global, dtype=np.float64)[:, : self.dim].copy()
         cg = np.ascontiguousarray(cells_global, dtype=np.int32)
         og = np.ascontiguousarray(owned_global, dtype=np.int32)
         pb = np.ascontiguousarray(pbc_nodes_global, dtype=np.int32)

@@ -102,6 +102,11 @@ __device__ __forceinline__ void tet_geom(const double X[4][3], double g[4][3], d
   h = sqrt(h2);
 }
 
+// offsets into a vector in the partitioned layout [u owned 3 nvo | p owned nvo | ghosts (ux, uy, uz, p) ng]; a vertex id
+// w >= nvo is a ghost (4 w = 4 nvo + 4 (w - nvo)).  On one rank (ng = 0) these are 3 w and 3 nv + w.
+__device__ __forceinline__ size_t uo3(int w, int nvo) { return w < nvo ? 3 * (size_t)w : 4 * (size_t)w; }
+__device__ __forceinline__ size_t po3(int w, int nvo) { return w < nvo ? 3 * (size_t)nvo + w : 4 * (size_t)w + 3; }
+
 // ---------------------------------------------------------------- tau moments
 // record per cell (12 doubles): M00 M01 M02 M03 M11 M12 M13 M22 M23 M33 L pad
 __global__ __launch_bounds__(TPB) void moments3_kernel(int nc, int nv, const int *__restrict__ cells, const double *__restrict__ coords,
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(TPB) void moments3_kernel(int nc, int nv, const int
   for (int a = 0; a < 4; a++) {
     vs[a] = cells[4 * (size_t)e + a];
 #pragma unroll
-    for (int i = 0; i < 3; i++) { X[a][i] = coords[3 * (size_t)vs[a] + i]; U[a][i] = un[3 * (size_t)vs[a] + i]; }
+    for (int i = 0; i < 3; i++) { X[a][i] = coords[3 * (size_t)vs[a] + i]; U[a][i] = un[uo3(vs[a], nv) + i]; }
   }
   double g[4][3], vol, h;
   tet_geom(X, g, vol, h);
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(TPB) void moments3_kernel(int nc, int nv, const int
 
 int k3_moments(cfdh_ctx *c) {
   prof_begin(c, 2);
-  hipLaunchKernelGGL(moments3_kernel, dim3((c->nc + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nc, c->nv, c->cells.p, c->coords.p,
+  hipLaunchKernelGGL(moments3_kernel, dim3((c->nc + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nc, c->nvo, c->cells.p, c->coords.p,
                      c->xprev.p, c->mom.p, c->dt, c->mu / c->rho);
   prof_end(c, 2);
   HIPCHK(c, hipGetLastError());
@@ -221,15 +226,16 @@ __global__ __launch_bounds__(TPB, CFDH3_ASMQ_OCC) void asm3q_kernel(Asm3Args p) 
     const unsigned slot = (unsigned)((p.inc_slots[inc] >> (16 * q)) & 0xffffull);
     const int vq = p.cells[4 * (size_t)e + q];
     const unsigned flq = p.bcflag[vq];
-    const double pq = p.x[3 * (size_t)nv + vq];
+    const double pq = p.x[po3(vq, nv)];
+    const size_t uq0 = uo3(vq, nv);
     double Xq[3], ubq[3], wq[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       Xq[i] = p.coords[3 * (size_t)vq + i];
-      const double u = p.x[3 * (size_t)vq + i], un = p.un[3 * (size_t)vq + i];
+      const double u = p.x[uq0 + i], un = p.un[uq0 + i];
       ubq[i] = th * u + (1.0 - th) * un;
       double wt = p.a0 * u + p.a1 * un;
-      if (p.hist2) wt += p.a2 * p.un2[3 * (size_t)vq + i];
+      if (p.hist2) wt += p.a2 * p.un2[uq0 + i];
       wq[i] = wt * idt;
     }
     const double *mo = p.mom + 12 * (size_t)e;
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(TPB, CFDH3_ASMQ_OCC) void asm3q_kernel(Asm3Args p) 
     if (cb) {
       double unq[3];
 #pragma unroll
-      for (int i = 0; i < 3; i++) unq[i] = p.un[3 * (size_t)vq + i];
+      for (int i = 0; i < 3; i++) unq[i] = p.un[uq0 + i];
 #pragma unroll
       for (int f = 0; f < 4; f++) {
         if (!((cb >> f) & 1u) || f == a) continue;  // uniform in the quad
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(TPB, CFDH3_ASMQ_OCC) void asm3q_kernel(Asm3Args p) 
         double gx[4] = {0, 0, 0, 0};  // g - x on the Dirichlet columns of vertex q, zero elsewhere
 #pragma unroll
         for (int jc = 0; jc < 3; jc++)
-          if ((flq >> jc) & 1u) gx[jc] = p.bcval[4 * (size_t)vq + jc] - p.x[3 * (size_t)vq + jc];
+          if ((flq >> jc) & 1u) gx[jc] = p.bcval[4 * (size_t)vq + jc] - p.x[uq0 + jc];
         if (flq & 8u) gx[3] = p.bcval[4 * (size_t)vq + 3] - pq;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
@@ -503,7 +509,8 @@ int k3_assemble(cfdh_ctx *c, const double *xstate, int mode) {
   a.inc_cell = c->a3_inc_cell.p; a.inc_row = c->a3_inc_row.p; a.inc_slots = c->a3_inc_slots.p;
   a.cflag = c->cflag.p; a.bcflag = c->bcflag.p;
   a.A00 = c->A00.p; a.A01 = c->A01.p; a.A10 = c->A10.p; a.A11 = c->A11.p; a.F = c->F.p;
-  a.nv = c->nv; a.dt = c->dt; a.rho = c->rho; a.mu = c->mu; a.muf = c->muf; a.f[0] = c->f[0]; a.f[1] = c->f[1]; a.f[2] = c->f[2];
+  a.nv = c->nvo;  // owned vertices: rows, and the split point of the partitioned vector layout
+  a.dt = c->dt; a.rho = c->rho; a.mu = c->mu; a.muf = c->muf; a.f[0] = c->f[0]; a.f[1] = c->f[1]; a.f[2] = c->f[2];
   a.theta = c->ts_theta; a.a0 = c->ts_a[0]; a.a1 = c->ts_a[1]; a.a2 = c->ts_a[2];
   a.ds_terms = c->ds_terms ? 1 : 0; a.hist2 = c->ts_a[2] != 0.0 ? 1 : 0;
   a.beta_bf = (c->bf_beta > 0.0 && c->bf_marker >= 0) ? c->bf_beta * c->rho : 0.0;
@@ -531,7 +538,8 @@ __global__ __launch_bounds__(TPB) void spmv3_full_kernel(int nv, const int *__re
     // (requesting the two blocks of a lane together -- 60 doubles in flight -- was measured: 159 us instead of 107)
     for (int k = vptr[row] + l, ke = vptr[row + 1]; k < ke; k += 8) {
       const int w = vcol[k];
-      const double x0 = x[3 * (size_t)w], x1 = x[3 * (size_t)w + 1], x2 = x[3 * (size_t)w + 2], xp = x[3 * (size_t)nv + w];
+      const size_t uo = uo3(w, nv);
+      const double x0 = x[uo], x1 = x[uo + 1], x2 = x[uo + 2], xp = x[po3(w, nv)];
       const double *b = A00 + 9 * (size_t)k, *c01 = A01 + 3 * (size_t)k, *c10 = A10 + 3 * (size_t)k;
       a0 += b[0] * x0 + b[1] * x1 + b[2] * x2 + c01[0] * xp;
       a1 += b[3] * x0 + b[4] * x1 + b[5] * x2 + c01[1] * xp;
@@ -555,7 +563,9 @@ int k3_spmv_full(cfdh_ctx *c, const double *x, double *y) {
 }
 
 // BLK 2: y_u = b_u - A01 x_p ; BLK 3: y_p = b_p - A10 x_u  (b null: y = A x)
-template <int BLK>
+// GHOST false: x is a compact block vector of the owned vertices (ghost columns are skipped: rank-local product);
+// GHOST true: x is a full vector in the partitioned layout whose ghost tail was refreshed by comm_halo.
+template <int BLK, bool GHOST = false>
 __global__ __launch_bounds__(TPB) void spmv3_blk_kernel(int nv, const int *__restrict__ vptr, const int *__restrict__ vcol,
                                                         const double *__restrict__ A, const double *__restrict__ x,
                                                         double *__restrict__ y, const double *__restrict__ bvec) {
@@ -565,12 +575,14 @@ __global__ __launch_bounds__(TPB) void spmv3_blk_kernel(int nv, const int *__res
   if (row < nv) {
     for (int k = vptr[row] + l, ke = vptr[row + 1]; k < ke; k += 8) {
       const int w = vcol[k];
+      if (!GHOST && w >= nv) continue;
       const double *cc = A + 3 * (size_t)k;
       if (BLK == 2) {
-        const double xp = x[w];
+        const double xp = GHOST ? x[po3(w, nv)] : x[w];
         a0 += cc[0] * xp; a1 += cc[1] * xp; a2 += cc[2] * xp;
       } else {
-        a0 += cc[0] * x[3 * (size_t)w] + cc[1] * x[3 * (size_t)w + 1] + cc[2] * x[3 * (size_t)w + 2];
+        const size_t uo = GHOST ? uo3(w, nv) : 3 * (size_t)w;
+        a0 += cc[0] * x[uo] + cc[1] * x[uo + 1] + cc[2] * x[uo + 2];
       }
     }
   }
@@ -603,7 +615,7 @@ __global__ __launch_bounds__(TPB) void spmv3_a01_resid_kernel(int nv, const int 
     for (int q = 0; q < 4; q++) {
       const double *cc = A + 3 * (size_t)kq[q];
       cq[q][0] = cc[0]; cq[q][1] = cc[1]; cq[q][2] = cc[2];
-      xq[q] = x[wq[q]];
+      xq[q] = wq[q] < nv ? x[wq[q]] : 0.0;  // compact operand: ghost columns are skipped
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -611,6 +623,7 @@ __global__ __launch_bounds__(TPB) void spmv3_a01_resid_kernel(int nv, const int 
       a0 += cq[q][0] * xp; a1 += cq[q][1] * xp; a2 += cq[q][2] * xp;
     }
     for (int k = ks + l + 16; k < ke; k += 4) {
+      if (vcol[k] >= nv) continue;
       const double xp = x[vcol[k]];
       const double *cc = A + 3 * (size_t)k;
       a0 += cc[0] * xp; a1 += cc[1] * xp; a2 += cc[2] * xp;
@@ -623,6 +636,13 @@ __global__ __launch_bounds__(TPB) void spmv3_a01_resid_kernel(int nv, const int 
     const size_t o = 3 * (size_t)row;
     y[o] = bvec[o] - a0; y[o + 1] = bvec[o + 1] - a1; y[o + 2] = bvec[o + 2] - a2;
   }
+}
+int k3_spmv_block_ghost(cfdh_ctx *c, int blk, const double *xv, double *y, const double *b) {
+  dim3 grid((unsigned)((8ll * c->nvo + TPB - 1) / TPB)), block(TPB);
+  if (blk == 2) hipLaunchKernelGGL((spmv3_blk_kernel<2, true>), grid, block, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A01.p, xv, y, b);
+  else hipLaunchKernelGGL((spmv3_blk_kernel<3, true>), grid, block, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A10.p, xv, y, b);
+  HIPCHK(c, hipGetLastError());
+  return 0;
 }
 int k3_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b) {
   dim3 grid((unsigned)((8ll * c->nvo + TPB - 1) / TPB)), block(TPB);
@@ -663,6 +683,7 @@ __global__ __launch_bounds__(TPB) void final3_kernel(int nb, int stride, const d
   if (threadIdx.x == 0) out[blockIdx.x] = a;
 }
 static int read2(cfdh_ctx *c, double *v, int n) {
+  if (c->nranks > 1) CHK(comm_allreduce_dev(c, c->red_out.p, n, 0));  // sums over the parts of a partitioned mesh
   HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->red_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < n; i++) v[i] = c->h_pinned[i];
@@ -683,11 +704,12 @@ int k3_nullspace_test(cfdh_ctx *c, double *nrm, double *absnrm) {
 
 // ---------------------------------------------------------------- functionals
 // kind 2/3: ||u||_L2, ||p||_L2 (scenario.py:315-324); kind 7: outward volume flux through the facets of `marker`
-__global__ __launch_bounds__(TPB) void l2_3_kernel(int nc, int nv, const int *__restrict__ cells, const double *__restrict__ coords,
-                                                   const double *__restrict__ x, double *__restrict__ partial) {
+__global__ __launch_bounds__(TPB) void l2_3_kernel(int nc, int nv, const int *__restrict__ cells, const unsigned char *__restrict__ cown,
+                                                   const double *__restrict__ coords, const double *__restrict__ x, double *__restrict__ partial) {
   __shared__ double sh[4];
   double au = 0, ap = 0;
   for (int e = blockIdx.x * TPB + threadIdx.x; e < nc; e += gridDim.x * TPB) {
+    if (!cown[e]) continue;  // overlapping parts: a cell is integrated by the rank that owns its first vertex
     int vs[4];
     double X[4][3];
     for (int a = 0; a < 4; a++) { vs[a] = cells[4 * (size_t)e + a]; for (int i = 0; i < 3; i++) X[a][i] = coords[3 * (size_t)vs[a] + i]; }
@@ -697,9 +719,9 @@ __global__ __launch_bounds__(TPB) void l2_3_kernel(int nc, int nv, const int *__
     for (int a = 0; a < 4; a++)
       for (int b = 0; b < 4; b++) {
         const double m = (a == b ? 2.0 : 1.0);
-        su += m * (x[3 * (size_t)vs[a]] * x[3 * (size_t)vs[b]] + x[3 * (size_t)vs[a] + 1] * x[3 * (size_t)vs[b] + 1] +
-                   x[3 * (size_t)vs[a] + 2] * x[3 * (size_t)vs[b] + 2]);
-        sp += m * x[3 * (size_t)nv + vs[a]] * x[3 * (size_t)nv + vs[b]];
+        const size_t ua = uo3(vs[a], nv), ub = uo3(vs[b], nv);
+        su += m * (x[ua] * x[ub] + x[ua + 1] * x[ub + 1] + x[ua + 2] * x[ub + 2]);
+        sp += m * x[po3(vs[a], nv)] * x[po3(vs[b], nv)];
       }
     au += vol * su * (1.0 / 20.0);
     ap += vol * sp * (1.0 / 20.0);
@@ -709,13 +731,14 @@ __global__ __launch_bounds__(TPB) void l2_3_kernel(int nc, int nv, const int *__
   if (threadIdx.x == 0) { partial[blockIdx.x] = au; partial[gridDim.x + blockIdx.x] = ap; }
 }
 __global__ __launch_bounds__(TPB) void flux3_kernel(int nfac, int marker, int nv, const int *__restrict__ fcell, const int *__restrict__ flocal,
-                                                    const int *__restrict__ fmarker, const int *__restrict__ cells,
+                                                    const int *__restrict__ fmarker, const int *__restrict__ cells, const unsigned char *__restrict__ cown,
                                                     const double *__restrict__ coords, const double *__restrict__ x, double *__restrict__ partial) {
   __shared__ double sh[4];
   double q = 0;
   for (int k = blockIdx.x * TPB + threadIdx.x; k < nfac; k += gridDim.x * TPB) {
     if (fmarker[k] != marker) continue;
     const int e = fcell[k], fl = flocal[k];
+    if (!cown[e]) continue;
     int vs[4];
     double X[4][3];
     for (int a = 0; a < 4; a++) { vs[a] = cells[4 * (size_t)e + a]; for (int i = 0; i < 3; i++) X[a][i] = coords[3 * (size_t)vs[a] + i]; }
@@ -723,7 +746,7 @@ __global__ __launch_bounds__(TPB) void flux3_kernel(int nfac, int marker, int nv
     tet_geom(X, g, vol, h);
     // |f| n = -3 vol grad l_f ; flux = |f| n . mean of the three facet vertices' velocities
     double um[3] = {0, 0, 0};
-    for (int a = 0; a < 4; a++) if (a != fl) for (int i = 0; i < 3; i++) um[i] += x[3 * (size_t)vs[a] + i] * (1.0 / 3.0);
+    for (int a = 0; a < 4; a++) if (a != fl) for (int i = 0; i < 3; i++) um[i] += x[uo3(vs[a], nv) + i] * (1.0 / 3.0);
     q += -3.0 * vol * (g[fl][0] * um[0] + g[fl][1] * um[1] + g[fl][2] * um[2]);
   }
   q = bsum3(q, sh);
@@ -733,7 +756,7 @@ int k3_functional(cfdh_ctx *c, int kind, int marker, double *out) {
   const int nb = 256;
   c->mirror_src = nullptr;
   if (kind == 2 || kind == 3) {
-    hipLaunchKernelGGL(l2_3_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nc, c->nv, c->cells.p, c->coords.p, c->x.p, c->red_partial.p);
+    hipLaunchKernelGGL(l2_3_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nc, c->nvo, c->cells.p, c->cell_owned.p, c->coords.p, c->x.p, c->red_partial.p);
     hipLaunchKernelGGL(final3_kernel, dim3(2), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p);
     HIPCHK(c, hipGetLastError());
     double v[2];
@@ -742,8 +765,8 @@ int k3_functional(cfdh_ctx *c, int kind, int marker, double *out) {
     return 0;
   }
   if (kind == 7) {
-    hipLaunchKernelGGL(flux3_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nfac, marker, c->nv, c->d_fac_cell.p, c->d_fac_local.p,
-                       c->d_fac_marker.p, c->cells.p, c->coords.p, c->x.p, c->red_partial.p);
+    hipLaunchKernelGGL(flux3_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nfac, marker, c->nvo, c->d_fac_cell.p, c->d_fac_local.p,
+                       c->d_fac_marker.p, c->cells.p, c->cell_owned.p, c->coords.p, c->x.p, c->red_partial.p);
     hipLaunchKernelGGL(final3_kernel, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p);
     HIPCHK(c, hipGetLastError());
     return read2(c, out, 1);
@@ -774,7 +797,7 @@ __global__ __launch_bounds__(TPB) void wss3_kernel(int nfac, int nv, const int *
   double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   for (int a = 0; a < 4; a++)
     for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) G[i][j] += g[a][i] * x[3 * (size_t)vs[a] + j];
+      for (int j = 0; j < 3; j++) G[i][j] += g[a][i] * x[uo3(vs[a], nv) + j];
   double T[3];
   for (int i = 0; i < 3; i++) {
     T[i] = 0.0;
@@ -789,7 +812,7 @@ __global__ __launch_bounds__(TPB) void wss3_kernel(int nfac, int nv, const int *
 int k3_wss(cfdh_ctx *c, double *out) {
   HIPCHK(c, hipMemsetAsync(out, 0, sizeof(double) * 3 * (size_t)c->nv, c->stream));
   if (c->nfac > 0)
-    hipLaunchKernelGGL(wss3_kernel, dim3((c->nfac + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nfac, c->nv, c->d_fac_cell.p, c->d_fac_local.p,
+    hipLaunchKernelGGL(wss3_kernel, dim3((c->nfac + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nfac, c->nvo, c->d_fac_cell.p, c->d_fac_local.p,
                        c->cells.p, c->coords.p, c->x.p, c->mu, out);
   HIPCHK(c, hipGetLastError());
   return 0;

@@ -21,17 +21,18 @@ static inline uint64_t spread3(uint64_t x) {  // 21 bits -> every third bit
 int cfdh_build_mesh3(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, const int32_t *cells, const double *coords,
                      int64_t nfac64, const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker) {
   const int nv = (int)nv64, nvo = (int)nvo64, ncu = (int)nc64, nfac = (int)nfac64;
-  if (nv <= 0 || ncu <= 0) return cfdh_fail(c, CFDH_E_ARG, "bad mesh sizes");
-  if (nvo != nv) return cfdh_fail(c, CFDH_E_ARG, "tetrahedral contexts are single-GPU in this version: nv_owned must equal nv");
+  if (nv <= 0 || nvo <= 0 || nvo > nv || ncu <= 0) return cfdh_fail(c, CFDH_E_ARG, "bad mesh sizes");
   if (nv64 > (1ll << 28) || nc64 > (1ll << 29)) return cfdh_fail(c, CFDH_E_ARG, "mesh too large for int32 indexing");
   for (int64_t k = 0; k < 4 * nc64; k++)
     if (cells[k] < 0 || cells[k] >= nv) return cfdh_fail(c, CFDH_E_ARG, "cell vertex index out of range");
   for (int k = 0; k < nfac; k++)
     if (fcell[k] < 0 || fcell[k] >= ncu || flocal[k] < 0 || flocal[k] > 3) return cfdh_fail(c, CFDH_E_ARG, "facet (cell, local) out of range");
   c->dim = 3; c->nloc = 4;
-  c->nv = nv; c->nvo = nvo; c->ng = 0;
-  c->NO = 4 * nvo; c->NL = 4 * nvo;
-  // ---- Morton numbering
+  // a part of a partitioned mesh: owned vertices first, ghosts after (as in 2-D); vectors [u owned 3 nvo | p owned nvo |
+  // ghosts (ux, uy, uz, p) ng]
+  c->nv = nv; c->nvo = nvo; c->ng = nv - nvo;
+  c->NO = 4 * nvo; c->NL = 4 * nvo + 4 * c->ng;
+  // ---- Morton numbering of the owned vertices (ghosts keep their order: grouped by owner)
   c->perm.resize(nv); c->iperm.resize(nv);
   {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -39,37 +40,40 @@ int cfdh_build_mesh3(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, con
       for (int i = 0; i < 3; i++) { lo[i] = std::min(lo[i], coords[3 * v + i]); hi[i] = std::max(hi[i], coords[3 * v + i]); }
     const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
     if (!(ext > 0)) return cfdh_fail(c, CFDH_E_ARG, "degenerate coordinates");
-    std::vector<uint64_t> key(nv);
-    for (int v = 0; v < nv; v++) {
+    std::vector<uint64_t> key(nvo);
+    for (int v = 0; v < nvo; v++) {
       uint64_t q[3];
       for (int i = 0; i < 3; i++) q[i] = (uint64_t)std::min(2097151.0, (coords[3 * v + i] - lo[i]) / ext * 2097151.0);
       key[v] = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
     }
-    std::vector<int> order(nv);
+    std::vector<int> order(nvo);
     std::iota(order.begin(), order.end(), 0);
     const char *nr = getenv("CFDH_NO_RENUMBER");
     if (!(nr && nr[0] == '1')) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
-    for (int k = 0; k < nv; k++) { c->iperm[k] = order[k]; c->perm[order[k]] = k; }
+    for (int k = 0; k < nvo; k++) { c->iperm[k] = order[k]; c->perm[order[k]] = k; }
+    for (int v = nvo; v < nv; v++) { c->iperm[v] = v; c->perm[v] = v; }
   }
   c->h_coords.resize(3 * (size_t)nv);
   for (int k = 0; k < nv; k++)
     for (int i = 0; i < 3; i++) c->h_coords[3 * (size_t)k + i] = coords[3 * (size_t)c->iperm[k] + i];
   // ---- cells in internal ids, sorted by smallest vertex, positively oriented
   {
-    std::vector<std::pair<int, int>> keyed(ncu);
+    std::vector<std::pair<int, int>> keyed;
+    keyed.reserve(ncu);
     for (int e = 0; e < ncu; e++) {
       int mn = nv;
       for (int a = 0; a < 4; a++) mn = std::min(mn, c->perm[cells[4 * e + a]]);
-      keyed[e] = {mn, e};
+      if (mn < nvo) keyed.push_back({mn, e});  // cells touching an owned vertex
     }
     std::stable_sort(keyed.begin(), keyed.end());
-    c->nc = ncu;
-    c->h_cells.resize(4 * (size_t)ncu);
-    c->cell_user.resize(ncu);
-    std::vector<int> cmap(ncu);
-    std::vector<unsigned char> flipped(ncu, 0);
+    const int nck = (int)keyed.size();
+    c->nc = nck;
+    c->h_cells.resize(4 * (size_t)nck);
+    c->cell_user.resize(nck);
+    std::vector<int> cmap(ncu, -1);
+    std::vector<unsigned char> flipped(nck, 0);
     const double *X = c->h_coords.data();
-    for (int k = 0; k < ncu; k++) {
+    for (int k = 0; k < nck; k++) {
       const int e = keyed[k].second;
       cmap[e] = k; c->cell_user[k] = e;
       int *v = &c->h_cells[4 * (size_t)k];
@@ -89,25 +93,26 @@ int cfdh_build_mesh3(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, con
     c->nfac_user = nfac;
     for (int k = 0; k < nfac; k++) {
       const int e = cmap[fcell[k]];
+      if (e < 0) continue;
       int fl = flocal[k];
       if (flipped[e] && fl >= 2) fl = 5 - fl;  // local vertices 2 and 3 were swapped
       c->fac_cell.push_back(e); c->fac_local.push_back(fl);
       c->fac_marker.push_back(fmarker ? fmarker[k] : 0);
       c->fac_user.push_back(k);
     }
-    c->nfac = nfac;
+    c->nfac = (int)c->fac_cell.size();
   }
   const int nc = c->nc;
   // ---- vertex -> incident (cell, local); vertex graph
   std::vector<int> vcptr(nvo + 1, 0);
-  for (size_t k = 0; k < 4 * (size_t)nc; k++) vcptr[c->h_cells[k] + 1]++;
+  for (size_t k = 0; k < 4 * (size_t)nc; k++) if (c->h_cells[k] < nvo) vcptr[c->h_cells[k] + 1]++;
   for (int v = 0; v < nvo; v++) vcptr[v + 1] += vcptr[v];
   const int ninc = vcptr[nvo];
   std::vector<int> vcell(ninc);
   {
     std::vector<int> fill(nvo, 0);
     for (int e = 0; e < nc; e++)
-      for (int a = 0; a < 4; a++) { const int v = c->h_cells[4 * (size_t)e + a]; vcell[vcptr[v] + fill[v]++] = 4 * e + a; }
+      for (int a = 0; a < 4; a++) { const int v = c->h_cells[4 * (size_t)e + a]; if (v < nvo) vcell[vcptr[v] + fill[v]++] = 4 * e + a; }
   }
   c->h_vptr.assign(nvo + 1, 0);
   c->h_vcol.clear(); c->h_vcol.reserve((size_t)16 * nvo);
@@ -150,6 +155,7 @@ int cfdh_build_mesh3(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, con
     for (int i = 0; i < 3; i++) g[0][i] = -(g[1][i] + g[2][i] + g[3][i]);
     const double vol = std::fabs(det) / 6.0;
     for (int a = 0; a < 4; a++) {
+      if (v[a] >= nvo) continue;
       c->h_Ml[v[a]] += vol / 4.0;
       const int *nb = &c->h_vcol[c->h_vptr[v[a]]];
       const int deg = c->h_vptr[v[a] + 1] - c->h_vptr[v[a]];
@@ -210,7 +216,9 @@ int cfdh_build_mesh3(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, con
   HIPCHK(c, c->a3_inc_cell.upload(inc_cell, s));
   HIPCHK(c, c->a3_inc_row.upload(inc_row, s));
   HIPCHK(c, c->a3_inc_slots.upload(inc_slots, s));
+  // with overlapping parts a cell is integrated (global functionals) only by the rank that owns its first vertex
   std::vector<unsigned char> cown(nc, 1);  // lives until the stream synchronisation at the end of this function
+  for (int k = 0; k < nc; k++) cown[k] = cells[4 * (size_t)c->cell_user[k]] < nvo ? 1 : 0;
   HIPCHK(c, c->cell_owned.upload(cown, s));
   if (c->nfac) {
     HIPCHK(c, c->d_fac_cell.upload(c->fac_cell, s));

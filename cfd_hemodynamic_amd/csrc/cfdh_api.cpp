@@ -448,7 +448,8 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
   if (nvg <= 0 || ncg <= 0 || !cells || !coords || !owned_global || (n_pbc > 0 && !pbc_nodes))
     return cfdh_fail(c, CFDH_E_ARG, "bad global pressure space arguments");
   const int n = (int)nvg;
-  for (int64_t k = 0; k < 3 * ncg; k++) if (cells[k] < 0 || cells[k] >= n) return cfdh_fail(c, CFDH_E_ARG, "global cell vertex out of range");
+  const int D = c->dim, NLc = D + 1;  // global cells [ncg][D + 1], coords [nvg][D]
+  for (int64_t k = 0; k < NLc * ncg; k++) if (cells[k] < 0 || cells[k] >= n) return cfdh_fail(c, CFDH_E_ARG, "global cell vertex out of range");
   std::vector<unsigned char> pbc(n, 0);
   for (int64_t k = 0; k < n_pbc; k++) {
     if (pbc_nodes[k] < 0 || pbc_nodes[k] >= n) return cfdh_fail(c, CFDH_E_ARG, "global Dirichlet node out of range");
@@ -456,7 +457,30 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
   }
   // global P1 stiffness as (row, col, value) triplets -> CSR with Dirichlet rows/cols removed
   std::vector<std::vector<std::pair<int, double>>> rows(n);
-  for (int64_t e = 0; e < ncg; e++) {
+  for (int64_t e = 0; e < ncg && D == 3; e++) {
+    // tetrahedra: rows of the inverse of [x1-x0 | x2-x0 | x3-x0] are grad lambda_1..3, volume |det| / 6
+    const int32_t *v = cells + 4 * e;
+    double d[3][3], cr[3][3], g[4][3];
+    for (int a = 0; a < 3; a++)
+      for (int i = 0; i < 3; i++) d[a][i] = coords[3 * (size_t)v[a + 1] + i] - coords[3 * (size_t)v[0] + i];
+    for (int a = 0; a < 3; a++) {
+      const double *p = d[(a + 1) % 3], *q = d[(a + 2) % 3];
+      cr[a][0] = p[1] * q[2] - p[2] * q[1]; cr[a][1] = p[2] * q[0] - p[0] * q[2]; cr[a][2] = p[0] * q[1] - p[1] * q[0];
+    }
+    const double det = d[0][0] * cr[0][0] + d[0][1] * cr[0][1] + d[0][2] * cr[0][2], vol = std::fabs(det) / 6.0;
+    if (!(vol > 0)) return cfdh_fail(c, CFDH_E_ARG, "zero-volume global cell");
+    for (int a = 0; a < 3; a++)
+      for (int i = 0; i < 3; i++) g[a + 1][i] = cr[a][i] / det;
+    for (int i = 0; i < 3; i++) g[0][i] = -(g[1][i] + g[2][i] + g[3][i]);
+    for (int a = 0; a < 4; a++) {
+      if (pbc[v[a]]) continue;
+      for (int b = 0; b < 4; b++) {
+        if (pbc[v[b]]) continue;
+        rows[v[a]].push_back({v[b], vol * (g[a][0] * g[b][0] + g[a][1] * g[b][1] + g[a][2] * g[b][2])});
+      }
+    }
+  }
+  for (int64_t e = 0; e < ncg && D == 2; e++) {
     const int32_t *v = cells + 3 * e;
     const double x0 = coords[2 * v[0]], y0 = coords[2 * v[0] + 1], x1 = coords[2 * v[1]], y1 = coords[2 * v[1] + 1],
                  x2 = coords[2 * v[2]], y2 = coords[2 * v[2] + 1];
@@ -500,7 +524,7 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
   c->h_gid.clear(); c->h_g2l.clear();
   if (c->nranks > 1 && c->ng > 0 && c->nnbr > 0) {
     std::vector<double> hv((size_t)c->NL, -1.0);
-    for (int k = 0; k < c->nvo; k++) hv[2 * (size_t)k] = (double)l2g[k];
+    for (int k = 0; k < c->nvo; k++) hv[(size_t)D * k] = (double)l2g[k];  // first velocity slot of the vertex record
     if (!c->pcw.p) HIPCHK(c, c->pcw.alloc(c->NL));
     HIPCHK(c, c->pcw.upload(hv, c->stream));
     CHK(comm_halo(c, c->pcw.p));
@@ -512,7 +536,7 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
     bool ok = true;
     for (int k = 0; k < c->nvo; k++) c->h_gid[k] = l2g[k];
     for (int i = 0; i < c->ng; i++) {
-      const double gd = hv[3 * (size_t)c->nvo + 3 * (size_t)i];
+      const double gd = hv[(size_t)NLc * c->nvo + (size_t)NLc * i];
       if (!(gd >= 0 && gd < n)) { ok = false; break; }
       c->h_gid[c->nvo + i] = (int)gd;
     }

@@ -155,7 +155,8 @@ int comm_halo(cfdh_ctx *c, double *vec) {
   if (c->nnbr == 0) return cfdh_fail(c, CFDH_E_STATE, "ghost vertices present but cfdh_set_halo was not called");
   CHK(k_halo_pack(c, vec));
   c->n_halo++;
-  double *tail = vec + 3 * (size_t)c->nvo;
+  const size_t W = (size_t)c->dim + 1;  // doubles per vertex record: (ux, uy[, uz], p)
+  double *tail = vec + W * (size_t)c->nvo;
   if (c->nccl_comm) {
     NCCLCHK(c, g_nccl.GroupStart());
     // an error inside the group must not leave it open: remember the first one, always close, then report
@@ -163,8 +164,8 @@ int comm_halo(cfdh_ctx *c, double *vec) {
     const char *what = "";
     for (int k = 0; k < c->nnbr && !first; k++) {
       const size_t ns = (size_t)(c->send_ptr[k + 1] - c->send_ptr[k]), nr = (size_t)(c->recv_ptr[k + 1] - c->recv_ptr[k]);
-      if (ns && (first = g_nccl.Send(c->send_buf.p + 3 * c->send_ptr[k], 3 * ns, NCCL_FLOAT64, c->nbr_rank[k], (nccl_comm_t)c->nccl_comm, c->stream))) { what = "ncclSend"; break; }
-      if (nr && (first = g_nccl.Recv(tail + 3 * c->recv_ptr[k], 3 * nr, NCCL_FLOAT64, c->nbr_rank[k], (nccl_comm_t)c->nccl_comm, c->stream))) { what = "ncclRecv"; break; }
+      if (ns && (first = g_nccl.Send(c->send_buf.p + W * c->send_ptr[k], W * ns, NCCL_FLOAT64, c->nbr_rank[k], (nccl_comm_t)c->nccl_comm, c->stream))) { what = "ncclSend"; break; }
+      if (nr && (first = g_nccl.Recv(tail + W * c->recv_ptr[k], W * nr, NCCL_FLOAT64, c->nbr_rank[k], (nccl_comm_t)c->nccl_comm, c->stream))) { what = "ncclRecv"; break; }
     }
     const int endrc = g_nccl.GroupEnd();
     if (first) return cfdh_fail(c, CFDH_E_COMM, "%s (halo exchange): %s", what, g_nccl.GetErrorString(first));
@@ -172,7 +173,7 @@ int comm_halo(cfdh_ctx *c, double *vec) {
     return 0;
   }
   if (!c->cb_ex) return cfdh_fail(c, CFDH_E_COMM, "multi-rank context without communicator");
-  const size_t nsend = 3 * (size_t)c->send_ptr[c->nnbr], nrecv = 3 * (size_t)c->recv_ptr[c->nnbr];
+  const size_t nsend = W * (size_t)c->send_ptr[c->nnbr], nrecv = W * (size_t)c->recv_ptr[c->nnbr];
   c->h_send.resize(nsend); c->h_recv.resize(nrecv);
   if (nsend) HIPCHK(c, hipMemcpyAsync(c->h_send.data(), c->send_buf.p, sizeof(double) * nsend, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -185,7 +186,7 @@ int comm_halo(cfdh_ctx *c, double *vec) {
 extern "C" int cfdh_set_halo(cfdh_ctx *c, int nnbr, const int32_t *nbr_rank, const int64_t *send_ptr, const int32_t *send_idx,
                              const int64_t *recv_ptr, const int32_t *recv_idx) {
   if (!c || nnbr < 0) return cfdh_fail(c, CFDH_E_ARG, "bad halo arguments");
-  if (c->dim == 3 && nnbr > 0) return cfdh_fail(c, CFDH_E_ARG, "tetrahedral contexts are single-GPU in this version");
+  if (c->gen && nnbr > 0) return cfdh_fail(c, CFDH_E_ARG, "P2 / Q1 contexts are single-GPU");
   c->nnbr = nnbr;
   c->nbr_rank.assign(nbr_rank, nbr_rank + nnbr);
   c->send_ptr.assign(send_ptr, send_ptr + nnbr + 1);
@@ -199,7 +200,7 @@ extern "C" int cfdh_set_halo(cfdh_ctx *c, int nnbr, const int32_t *nbr_rank, con
     sidx[i] = c->perm[send_idx[i]];
   }
   HIPCHK(c, c->send_idx.upload(sidx, c->stream));
-  HIPCHK(c, c->send_buf.alloc(3 * sidx.size() + 3));
+  HIPCHK(c, c->send_buf.alloc(((size_t)c->dim + 1) * sidx.size() + 4));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }

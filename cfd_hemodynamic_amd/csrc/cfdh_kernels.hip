@@ -826,6 +826,7 @@ __global__ __launch_bounds__(TPB) void spmv_blk_ghost_kernel(int nvo, const int 
   }
 }
 int k_spmv_block_ghost(cfdh_ctx *c, int blk, const double *xv, double *y, const double *b) {
+  if (c->dim == 3) return k3_spmv_block_ghost(c, blk, xv, y, b);
   const long long nthreads = 8ll * c->nvo;
   dim3 grid((unsigned)((nthreads + TPB - 1) / TPB)), block(TPB);
   if (blk == 2) hipLaunchKernelGGL((spmv_blk_ghost_kernel<2>), grid, block, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A01.p, xv, y, b);
@@ -1644,11 +1645,12 @@ static int amg_cycle_cheb(cfdh_ctx *c, AmgHier &H, size_t lev, const double *b, 
 
 // ---- distributed finest level of the replicated pressure hierarchy (cfdh_ctx::DistL0)
 // b_loc = pressure slot of a halo-layout vector on owned + ghost vertices; xa = w D^-1 b on all of them
-__global__ __launch_bounds__(TPB) void dl0_pack_kernel(int nvo, int nv, const double *__restrict__ vec, const double *__restrict__ wdinv,
+__global__ __launch_bounds__(TPB) void dl0_pack_kernel(int nvo, int nv, int dim, const double *__restrict__ vec, const double *__restrict__ wdinv,
                                                        double *__restrict__ b, double *__restrict__ xa) {
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i >= nv) return;
-  const double v = i < nvo ? vec[2 * (size_t)nvo + i] : vec[3 * (size_t)nvo + 3 * (size_t)(i - nvo) + 2];
+  // pressure slot: owned at dim nvo + i, ghost record (u..., p) of dim + 1 doubles behind the owned part
+  const double v = i < nvo ? vec[(size_t)dim * nvo + i] : vec[((size_t)dim + 1) * nvo + ((size_t)dim + 1) * (size_t)(i - nvo) + dim];
   b[i] = v;
   xa[i] = wdinv[i] * v;
 }
@@ -1657,7 +1659,7 @@ int k_dl0_down(cfdh_ctx *c, const double *halo_vec) {
   cfdh_ctx::DistL0 &d = c->dl0;
   AmgLevel *N = c->hLg.lev[1];
   const int nvo = c->nvo, nv = c->nv;
-  hipLaunchKernelGGL(dl0_pack_kernel, dim3((nv + TPB - 1) / TPB), dim3(TPB), 0, c->stream, nvo, nv, halo_vec, d.wdinv.p, d.b.p, d.xa.p);
+  hipLaunchKernelGGL(dl0_pack_kernel, dim3((nv + TPB - 1) / TPB), dim3(TPB), 0, c->stream, nvo, nv, c->dim, halo_vec, d.wdinv.p, d.b.p, d.xa.p);
   dim3 block(TPB), grid((unsigned)((8ll * nvo + TPB - 1) / TPB)), gridS((unsigned)((nvo + TPB - 1) / TPB));
   if (d.A.nnz <= 12ll * nvo && nvo >= 16384)  // short regular rows: SELL-64 (as the replicated level 0 would use)
     hipLaunchKernelGGL((sell_jacobi_pre_kernel<double>), gridS, block, 0, c->stream, nvo, d.A.sptr.p, d.A.scol.p, d.A.svalw.p,
@@ -1736,7 +1738,18 @@ __global__ __launch_bounds__(TPB) void ext_pack_kernel(int nvo, int nv, const do
     out[i] = make_double2(t[0], t[1]);
   }
 }
+__global__ __launch_bounds__(TPB) void ext_pack3_kernel(int nvo, int nv, const double *__restrict__ vec, double *__restrict__ out) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= nv) return;
+  const double *t = i < nvo ? vec + 3 * (size_t)i : vec + 4 * (size_t)i;  // ghost record (ux, uy, uz, p) at 4 nvo + 4 (i - nvo)
+  out[3 * (size_t)i] = t[0]; out[3 * (size_t)i + 1] = t[1]; out[3 * (size_t)i + 2] = t[2];
+}
 int k_ext_pack(cfdh_ctx *c, const double *vec, double *out) {
+  if (c->dim == 3) {
+    hipLaunchKernelGGL(ext_pack3_kernel, dim3((c->nv + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nvo, c->nv, vec, out);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(ext_pack_kernel, dim3((c->nv + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->nvo, c->nv, vec, (double2 *)out);
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -2359,9 +2372,24 @@ __global__ __launch_bounds__(TPB) void halo_pack_kernel(int n, int nvo, const in
   buf[3 * (size_t)i + 1] = vec[2 * (size_t)v + 1];
   buf[3 * (size_t)i + 2] = vec[2 * (size_t)nvo + v];
 }
+__global__ __launch_bounds__(TPB) void halo_pack3_kernel(int n, int nvo, const int *__restrict__ idx, const double *__restrict__ vec,
+                                                         double *__restrict__ buf) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const int v = idx[i];
+  buf[4 * (size_t)i] = vec[3 * (size_t)v];
+  buf[4 * (size_t)i + 1] = vec[3 * (size_t)v + 1];
+  buf[4 * (size_t)i + 2] = vec[3 * (size_t)v + 2];
+  buf[4 * (size_t)i + 3] = vec[3 * (size_t)nvo + v];
+}
 int k_halo_pack(cfdh_ctx *c, const double *vec) {
   const int n = (int)c->send_idx.n;
   if (n == 0) return 0;
+  if (c->dim == 3) {
+    hipLaunchKernelGGL(halo_pack3_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, c->nvo, c->send_idx.p, vec, c->send_buf.p);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(halo_pack_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, c->nvo, c->send_idx.p, vec,
                      c->send_buf.p);
   HIPCHK(c, hipGetLastError());

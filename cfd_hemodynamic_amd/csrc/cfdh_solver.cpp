@@ -162,18 +162,20 @@ static int build_cc_host(cfdh_ctx *c) {
         std::fill(hv.begin(), hv.end(), -1.0);
         for (int i = 0; i < nvo; i++) {
           const int p = Ah.rowptr[i] + k;
-          if (p < Ah.rowptr[i + 1]) { hv[2 * (size_t)i] = (double)c->h_gid[Ah.col[p]]; hv[2 * (size_t)i + 1] = Ah.val[p]; }
+          // the pair (global column id, value) rides in the first two velocity slots of the vertex record
+          if (p < Ah.rowptr[i + 1]) { hv[(size_t)c->dim * i] = (double)c->h_gid[Ah.col[p]]; hv[(size_t)c->dim * i + 1] = Ah.val[p]; }
         }
         HIPCHK(c, c->pcw.upload(hv, c->stream));
         CHK(comm_halo(c, c->pcw.p));
-        HIPCHK(c, hipMemcpyAsync(hv.data() + 3 * (size_t)nvo, c->pcw.p + 3 * (size_t)nvo, sizeof(double) * 3 * (size_t)c->ng,
+        const size_t W = (size_t)c->dim + 1;  // doubles per vertex record
+        HIPCHK(c, hipMemcpyAsync(hv.data() + W * (size_t)nvo, c->pcw.p + W * (size_t)nvo, sizeof(double) * W * (size_t)c->ng,
                                  hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (int g = 0; g < c->ng; g++) {
-          const double gd = hv[3 * (size_t)nvo + 3 * (size_t)g];
+          const double gd = hv[W * (size_t)nvo + W * (size_t)g];
           if (!(gd >= 0)) continue;
           const int loc = c->h_g2l[(int)gd];
-          if (loc >= 0) grow[g].push_back({loc, hv[3 * (size_t)nvo + 3 * (size_t)g + 1]});
+          if (loc >= 0) grow[g].push_back({loc, hv[W * (size_t)nvo + W * (size_t)g + 1]});
         }
       }
       HIPCHK(c, c->pcw.zero(c->stream));
@@ -185,7 +187,7 @@ static int build_cc_host(cfdh_ctx *c) {
         if (!diag) return cfdh_fail(c, CFDH_E_COMM, "ghost row %d arrived without its diagonal", g);
         Ah.rowptr[nvo + g + 1] = (int)Ah.col.size();
       }
-      if (!c->ras_b.p) { HIPCHK(c, c->ras_b.alloc(2 * (size_t)c->nv)); HIPCHK(c, c->ras_x.alloc(2 * (size_t)c->nv)); }
+      if (!c->ras_b.p) { HIPCHK(c, c->ras_b.alloc((size_t)c->dim * c->nv)); HIPCHK(c, c->ras_x.alloc((size_t)c->dim * c->nv)); }
     }
     c->ras = ras;
     CHK(cfdh_amg_setup(c, c->hA, Ah, false, c->dim));

@@ -85,8 +85,9 @@ class LocalPart:
         # vertices of mine needed by q: share a cell with a q-owned vertex
         need = set()
         send = {}
-        for a in range(3):
-            for b in range(3):
+        nloc = cells.shape[1]  # 3: triangles, 4: tetrahedra
+        for a in range(nloc):
+            for b in range(nloc):
                 if a == b:
                     continue
                 sel = (cown[:, a] == rank) & (cown[:, b] != rank)
@@ -134,7 +135,10 @@ class PartComm:
             return cls(0, 1, backend)
         return cls(dist.get_rank(), dist.get_world_size(), backend)
 
+    width = 3  # doubles per vertex record of the halo exchange: gdim + 1
+
     def make_part(self, mesh):
+        self.width = mesh.geometry.dim + 1
         owner = np.asarray(self.partitioner(mesh.x, self.size), dtype=np.int32)
         if owner.shape != (mesh.num_vertices,) or owner.min() < 0 or owner.max() >= self.size:
             raise ValueError("partitioner must return one owner rank in [0, size) per vertex")
@@ -172,11 +176,12 @@ class PartComm:
             out.reshape(-1, bs)[g] = v
         return out
 
-    def host_exchange(self, s, r, width=3):
+    def host_exchange(self, s, r, width=None):
         """Forward halo over torch.distributed: `s` holds `width` doubles per send vertex in
         send_idx order, `r` receives `width` doubles per ghost in ghost order."""
         import torch.distributed as dist
         part = self.part
+        width = width or self.width
         reqs = []
         for k, q in enumerate(part.nbr):
             a, b = width * int(part.recv_ptr[k]), width * int(part.recv_ptr[k + 1])
@@ -224,9 +229,11 @@ class PartComm:
         """One halo exchange and one all-reduce of the attached communicator against values known on the
         host (collective).  Needs a context with parameters and state set.  Returns None or the defect."""
         part = self.part
+        d = mesh.geometry.dim
         gid = part.l2g.astype(np.float64)
         f = 1.0 + 1e-6 * gid                       # nodal field known on every rank
-        u = np.stack([f, -0.5 * f], axis=1)
+        comp = np.array([1.0, -0.5, 0.25])[:d]     # u = f * comp
+        u = f[:, None] * comp[None, :]
         u[part.nvo:] = -7.0                        # ghosts: to be overwritten by the exchange
         p = 3.0 * f
         p[part.nvo:] = -7.0
@@ -234,14 +241,15 @@ class PartComm:
         ctx.assemble(False)                        # refreshes the halo of the iterate
         gu, gp = ctx.get_solution()
         bad = None
-        if not (np.array_equal(gu.reshape(-1, 2)[:, 0], f) and np.array_equal(gu.reshape(-1, 2)[:, 1], -0.5 * f)
-                and np.array_equal(gp, 3.0 * f)):
+        if not (np.array_equal(gu.reshape(-1, d), f[:, None] * comp[None, :]) and np.array_equal(gp, 3.0 * f)):
             bad = "halo exchange delivered wrong ghost values"
-        # ||u||_L2 over the whole mesh through the library's all-reduce vs the host value
+        # ||u||_L2 over the whole mesh through the library's all-reduce vs the host value:
+        # int_K f^2 = |K| (sum_a f_a^2 + sum_{a<b} f_a f_b) * 2 / ((d+1)(d+2))
         fg = 1.0 + 1e-6 * np.arange(mesh.num_vertices)
         fc = fg[mesh.cells]
-        ff = (fc ** 2).sum(axis=1) + fc[:, 0] * fc[:, 1] + fc[:, 0] * fc[:, 2] + fc[:, 1] * fc[:, 2]
-        ref = np.sqrt(1.25 * (mesh.cell_areas() / 6.0 * ff).sum())
+        ff = (fc ** 2).sum(axis=1) + sum(fc[:, a] * fc[:, b] for a in range(d + 1) for b in range(a + 1, d + 1))
+        vol = mesh.cell_areas() if d == 2 else mesh.cell_volumes()
+        ref = np.sqrt((comp ** 2).sum() * (vol * 2.0 / ((d + 1) * (d + 2)) * ff).sum())
         got = ctx.functional(2)
         if bad is None and not abs(got - ref) <= 1e-10 * ref:
             bad = "all-reduce gave %r, expected %r" % (got, ref)
@@ -266,8 +274,8 @@ class PartComm:
 
         def exchange(user, sendbuf, recvbuf):
             try:
-                s = torch.from_numpy(np.ctypeslib.as_array(sendbuf, shape=(max(3 * nsend, 1),)))
-                r = torch.from_numpy(np.ctypeslib.as_array(recvbuf, shape=(max(3 * nrecv, 1),)))
+                s = torch.from_numpy(np.ctypeslib.as_array(sendbuf, shape=(max(self.width * nsend, 1),)))
+                r = torch.from_numpy(np.ctypeslib.as_array(recvbuf, shape=(max(self.width * nrecv, 1),)))
                 self.host_exchange(s, r)
                 return 0
             except Exception as e:

@@ -129,7 +129,7 @@ class Solver(SolverBase):
             self._dev_newer["wss"] = False
             w = self.ctx.wall_shear_stress(download=True)
             a = self.shear_stress.x._array
-            a[:] = w if self._part is None else self._comm.allgather_owned(w, 2, self.mesh.num_vertices)
+            a[:] = w if self._part is None else self._comm.allgather_owned(w, self.mesh.geometry.dim, self.mesh.num_vertices)
 
     def assemble_wss(self):
         """solverBase.py:185-195 on the device (cfdh_wall_shear_stress); the host array behind
@@ -197,7 +197,7 @@ class Solver(SolverBase):
                 for bc in self.bcu_d:
                     fixed[bc.dofs] = True
                 fv = self.mesh.facet_vertices
-                open_f = ~(fixed[fv[:, 0]] & fixed[fv[:, 1]])
+                open_f = ~np.all(fixed[fv], axis=1)
                 pnodes = np.unique(np.concatenate([pnodes, fv[open_f].ravel()])).astype(np.int32)
             self.ctx.set_global_pressure_space(self.mesh.x, self.mesh.cells, self._part.owned_global, pnodes)
         # x_n = (u_prev, p_prev): initial guess of the first step (stabilized_schur.py:216-223)

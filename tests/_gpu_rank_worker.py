@@ -44,6 +44,11 @@ def main():
         sc = StenosisWithTreeSimulation("stabilized_schur", 0.001, float(os.environ.get("CFDH_TEST_T", "0.0035")), grade="moderate",
                                         res=float(os.environ.get("CFDH_TEST_RES", "5e-5")), pulse_amplitude=0.5, ramp_time=0.005,
                                         inlet_max_velocity=0.05, quiet=True, device=0, comm=comm, options=tight)
+    elif case == "bif3d":  # tetrahedra: the 3-D bifurcation (BASELINE config 5b), inlet parabola, two p = 0 outlets
+        from cfd_hemodynamic_amd.scenarios.simple_bifurcation import MicrovasculatureSimulation
+        tight["remove_p_mean"] = 0
+        sc = MicrovasculatureSimulation("stabilized_schur", 0.01, float(os.environ.get("CFDH_TEST_T", "0.025")),
+                                        res=float(os.environ.get("CFDH_TEST_RES", "8e-4")), quiet=True, device=0, comm=comm, options=tight)
     elif case == "stenosis_backflow":  # do-nothing outlet, backflow facet term, no pressure Dirichlet set
         from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
         sc = StenosisSimulation("stabilized_schur_backflow", 0.01, 0.035, ny=12, L=30.0, x_sten=10.0, v_max=60.0, quiet=True,
@@ -57,11 +62,13 @@ def main():
     sc.solve(outdir)
     counters = [ctx.info(k) for k in (13, 14, 15, 16, 17, 18)]
     # facet functionals are collective: a rank whose part has no exterior facet must still take part
-    fd_all, fl_all = sc.solver.functional(0, 0), sc.solver.functional(1, 0)
+    fd_all, fl_all = (sc.solver.functional(0, 0), sc.solver.functional(1, 0)) if sc.mesh.geometry.dim == 2 else (0.0, 0.0)
     nfac_local = len(sc.solver._part.facet_cells)
     u = sc.solver.u_sol.x.array.copy()   # gathers the owned slices of every rank
     p = sc.solver.p_sol.x.array.copy()
     extra = {}
+    if case == "bif3d":
+        extra["flows"] = np.array(sc.flow_rates())
     if case == "tree_c5":
         extra["outlet_flows"] = sc.outlet_flow_rates()
         extra["inlet_peak"] = float(np.abs(np.asarray(sc._u_inlet.x.array)).max())

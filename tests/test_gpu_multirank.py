@@ -295,3 +295,30 @@ def test_config5_tree_partitioned_over_4_ranks(tmp_path):
     assert abs(float(r["inlet_peak"]) - float(np.abs(np.asarray(ref._u_inlet.x.array)).max())) <= 1e-14
     assert int(r["ras"]) == 1 and int(r["dist_coarse"]) > 0
     assert int(r["krylov"]) <= 1.5 * ref_krylov, (int(r["krylov"]), ref_krylov)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tetrahedra_partitioned_over_ranks(tmp_path, world):
+    """The 3-D path on more than one rank (BASELINE config 5b, simple_bifurcation.py:77-133): element partition of the
+    tetrahedra, halo records of four doubles (u_x, u_y, u_z, p), overlapping velocity cycle with three components,
+    distributed finest level of the replicated pressure hierarchy -- through the RCCL code path (shared-memory stand-in).
+    Solution, L2 norms and the three boundary fluxes equal the single-rank run's."""
+    from cfd_hemodynamic_amd.scenarios.simple_bifurcation import MicrovasculatureSimulation
+    fake = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "fake_rccl"), "-s"])
+    tight = dict(snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-9, remove_p_mean=0)
+    ref = MicrovasculatureSimulation("stabilized_schur", 0.01, 0.025, res=8e-4, quiet=True, options=tight)
+    ref.solve(None)
+    ref_krylov = sum(st.krylov_its for _, st in ref.step_stats)
+    u0, p0 = np.asarray(ref.solver.u_sol.x.array).copy(), np.asarray(ref.solver.p_sol.x.array).copy()
+    q0 = np.array(ref.flow_rates())
+    r = _run(world, str(tmp_path / ("bif%d.npz" % world)), timeout=600, CFDH_TEST_BACKEND="rccl", CFDH_RCCL_LIB=fake, CFDH_TEST_CASE="bif3d",
+             CFDH_TEST_SNES_RTOL="1e-11", CFDH_TEST_KSP_RTOL="1e-9")
+    assert int(r["steps"]) == ref.num_steps == 3 and str(r["backend"]) == "rccl" and int(r["rccl_attached"]) == 1
+    assert np.linalg.norm(r["u"] - u0) <= 1e-8 * np.linalg.norm(u0)
+    assert np.linalg.norm(r["p"] - p0) <= 1e-7 * np.linalg.norm(p0)
+    assert abs(float(r["norm_v"]) - ref.norm_v) <= 1e-9 * ref.norm_v and abs(float(r["norm_p"]) - ref.norm_p) <= 1e-8 * ref.norm_p
+    assert np.abs(r["flows"] - q0).max() <= 1e-7 * np.abs(q0).max()
+    assert int(r["ras"]) == 1 and int(r["dist_coarse"]) > 0
+    assert int(r["krylov"]) <= 1.5 * ref_krylov, (int(r["krylov"]), ref_krylov)
