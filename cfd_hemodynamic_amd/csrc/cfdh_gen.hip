@@ -154,6 +154,7 @@ __global__ __launch_bounds__(TPB) void gen_asm_kernel(GenArgs P) {
   constexpr int CPB = TPB / NL;  // cells per workgroup
   constexpr int NV = ET == 2 ? 4 : 3, NF = ET == 2 ? 4 : 3;
   __shared__ CellData<NL> sh[CPB];
+  __shared__ double sh_tau[CPB][GEN_NQ][2];  // tau, tau_L at the quadrature points of each cell: computed once, by its lanes in turn
   const int lc = threadIdx.x / NL, a = threadIdx.x % NL;
   const int cell = blockIdx.x * CPB + lc;
   const bool live = lc < CPB && cell < P.nc;
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(TPB) void gen_asm_kernel(GenArgs P) {
     D.lift[a][2] = (bf >> 2) & 1 ? P.bcval[3 * (size_t)v + 2] - pv : 0.0;
   }
   __syncthreads();
-  if (!live) return;
-  const CellData<NL> &D = sh[lc];
+  // idle lanes (tail of the last workgroup, 256 mod nloc) follow cell 0 of the workgroup up to the barrier below and write nothing
+  const CellData<NL> &D = sh[live ? lc : 0];
   // affine map from the first three vertices
   const double J00 = D.X[1][0] - D.X[0][0], J01 = D.X[2][0] - D.X[0][0], J10 = D.X[1][1] - D.X[0][1], J11 = D.X[2][1] - D.X[0][1];
   const double det = J00 * J11 - J01 * J10, adet = fabs(det), idet = 1.0 / det;
@@ -201,6 +202,17 @@ __global__ __launch_bounds__(TPB) void gen_asm_kernel(GenArgs P) {
     visc[1] += P.mu * (lapb * D.ub[b][1] + Hs[b][1] * D.ub[b][0] + Hs[b][2] * D.ub[b][1]);
   }
   const double rho = P.rho, mu = P.mu, th = P.theta, a0dt = P.a0 / P.dt, nu = mu / rho;
+  // stabilisation parameters (functions of u_prev and h only): lane a of the cell takes the points a, a + NL, ...
+  for (int q = a; q < GEN_NQ; q += NL) {
+    double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+    for (int b = 0; b < NL; b++) { u0 += d_tab[ET].phi[q][b] * D.un[b][0]; u1 += d_tab[ET].phi[q][b] * D.un[b][1]; }
+    double tq, tlq;
+    tau_pair(u0 * u0 + u1 * u1, h, P.dt, nu, tq, tlq);
+    if (live) { sh_tau[lc][q][0] = tq; sh_tau[lc][q][1] = tlq; }
+  }
+  __syncthreads();
+  if (!live) return;
   // row block of test node a: residual (u_x, u_y, p) and the 3 x 3 blocks against every node b
   double Fa[3] = {0.0, 0.0, 0.0};
   double Juu[NL][2][2], Jup[NL][2], Jpu[NL][2], Jpp[NL];
@@ -216,12 +228,12 @@ __global__ __launch_bounds__(TPB) void gen_asm_kernel(GenArgs P) {
       g[b][0] = T.dphi[q][b][0] * Ji[0][0] + T.dphi[q][b][1] * Ji[1][0];
       g[b][1] = T.dphi[q][b][0] * Ji[0][1] + T.dphi[q][b][1] * Ji[1][1];
     }
-    double uq[2] = {0, 0}, wv[2] = {0, 0}, unq[2] = {0, 0}, G[2][2] = {{0, 0}, {0, 0}}, gp[2] = {0, 0}, pq = 0.0;
+    double uq[2] = {0, 0}, wv[2] = {0, 0}, G[2][2] = {{0, 0}, {0, 0}}, gp[2] = {0, 0}, pq = 0.0;
 #pragma unroll
     for (int b = 0; b < NL; b++) {
 #pragma unroll
       for (int i = 0; i < 2; i++) {
-        uq[i] += ph[b] * D.ub[b][i]; wv[i] += ph[b] * D.wn[b][i]; unq[i] += ph[b] * D.un[b][i];
+        uq[i] += ph[b] * D.ub[b][i]; wv[i] += ph[b] * D.wn[b][i];
         gp[i] += g[b][i] * D.p[b];
         G[i][0] += g[b][i] * D.ub[b][0]; G[i][1] += g[b][i] * D.ub[b][1];
       }
@@ -230,8 +242,7 @@ __global__ __launch_bounds__(TPB) void gen_asm_kernel(GenArgs P) {
     const double divu = G[0][0] + G[1][1];
     const double C[2] = {uq[0] * G[0][0] + uq[1] * G[1][0], uq[0] * G[0][1] + uq[1] * G[1][1]};
     const double R[2] = {rho * (wv[0] + C[0]) - visc[0] + gp[0] - rho * P.f0, rho * (wv[1] + C[1]) - visc[1] + gp[1] - rho * P.f1};
-    double tau, tauL;
-    tau_pair(unq[0] * unq[0] + unq[1] * unq[1], h, P.dt, nu, tau, tauL);
+    const double tau = sh_tau[lc][q][0], tauL = sh_tau[lc][q][1];
     const double bga = uq[0] * g[a][0] + uq[1] * g[a][1];  // ubar . grad phi_a
     const double fvec[2] = {P.f0, P.f1};
 #pragma unroll
