@@ -1109,7 +1109,10 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
     const bool last = A.n <= o.amg_max_coarse || (int)H.lev.size() >= maxlev;
     int na = 0;
     dbuf<int> agg;
-    if (!last) {
+    // P2 elements: the first coarse level is the P1 subspace (p-multigrid step) with its exact interpolation, not an aggregation
+    static const bool no_pmg = getenv("CFDH_NO_PMG") && getenv("CFDH_NO_PMG")[0] == '1';
+    const bool pmg = !last && !no_pmg && H.lev.size() == 1 && c->etype == 1 && c->gen_P1.n == A.n && c->gen_P1.m > 0;
+    if (!last && !pmg) {
       if (host_agg) {
         CsrHost Ah;
         Ah.n = Ah.m = A.n;
@@ -1127,6 +1130,7 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
       }
     }
     TICK(1);
+    if (pmg) na = c->gen_P1.m;
     if (last || na >= A.n || na < 1) {
       // coarsest level: keep the operator (CSR) for the closing step
       move_csr(L->A, A);
@@ -1135,6 +1139,11 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
     // P = (I - omega D^-1 A) P0
     const MatV Am{A.rowptr.p, A.col.p, A.val.p};
     CsrDev P, R, AP, Ac;
+    if (pmg) {
+      P.n = c->gen_P1.n; P.m = c->gen_P1.m; P.nnz = c->gen_P1.nnz();
+      HIPCHK(c, P.rowptr.upload(c->gen_P1.rowptr, s)); HIPCHK(c, P.col.upload(c->gen_P1.col, s)); HIPCHK(c, P.val.upload(c->gen_P1.val, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+    } else
     CHK((Spgemm<AOpImwDA, BOpAgg>::run(B.dv, A.n, na, AOpImwDA{Am, L->dinv.p, 4.0 / 3.0 / lm, agg.p}, BOpAgg{agg.p}, P, B.lists, B.tmp, B.cnts)));
     TICK(2);
     CHK(B.transpose(P, R));

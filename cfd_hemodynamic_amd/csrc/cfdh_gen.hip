@@ -702,6 +702,30 @@ int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, cons
       }
     }
   }
+  if (et == 1) {
+    // P1 subspace of the P2 space: vertex nodes (local positions 0..2) numbered in order of first appearance along the node
+    // numbering; an edge node interpolates its two end vertices
+    std::vector<int> vid(nv, -1), ea(nv, -1), eb(nv, -1);
+    for (int e = 0; e < nc; e++) {
+      const int *v = &c->h_cells[(size_t)NL * e];
+      const int ed[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+      for (int q = 0; q < 3; q++) { vid[v[q]] = 0; ea[v[3 + q]] = v[ed[q][0]]; eb[v[3 + q]] = v[ed[q][1]]; }
+    }
+    int nvert = 0;
+    for (int v = 0; v < nv; v++) if (vid[v] == 0) vid[v] = nvert++;
+    CsrHost &P = c->gen_P1;
+    P.n = nv; P.m = nvert;
+    P.rowptr.assign(nv + 1, 0); P.col.clear(); P.val.clear();
+    for (int v = 0; v < nv; v++) {
+      if (vid[v] >= 0) { P.col.push_back(vid[v]); P.val.push_back(1.0); }
+      else {
+        int a = vid[ea[v]], b = vid[eb[v]];
+        if (a > b) std::swap(a, b);
+        P.col.push_back(a); P.val.push_back(0.5); P.col.push_back(b); P.val.push_back(0.5);
+      }
+      P.rowptr[v + 1] = (int)P.col.size();
+    }
+  }
   // diagonal mass scaled to the total measure (HRZ lumping: row sums vanish at P2 vertices); preconditioner only
   for (int v = 0; v < nv; v++) c->h_Ml[v] = mdiag[v] * (msum / dsum);
   // ---- uploads and allocations

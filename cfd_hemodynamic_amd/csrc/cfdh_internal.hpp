@@ -156,6 +156,9 @@ struct cfdh_ctx {
   bool gen = false;
   dbuf<int> gslot;             // [nc][nloc * nloc] value slot of the local node pair (a, b) in the vertex-graph arrays
   dbuf<unsigned short> gflag;  // [nc] bit f: exterior facet f, bit 8 + f: backflow facet f
+  // P2: the P1 subspace as the first coarse level of both hierarchies (p-multigrid step): prolongator [nodes x vertex nodes],
+  // 1 at a vertex node, 1/2 + 1/2 at an edge node (host copy; internal numbering)
+  CsrHost gen_P1;
   // sizes (local part): nv = nvo owned + ng ghosts
   int nv = 0, nvo = 0, ng = 0, nc = 0, nfac = 0;
   int NL = 0;   // vector length incl. ghost tail = 3*nvo + 3*ng
