@@ -193,7 +193,7 @@ def self_launch(n):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), "--", os.path.abspath(__file__)] + sys.argv[1:]  # "--": the launcher must not parse bench.py's options
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
     line = None
