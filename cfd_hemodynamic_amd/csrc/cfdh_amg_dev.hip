@@ -930,7 +930,7 @@ struct Builder {
   }
 
   // aggregate ids on the device; *na_out = number of aggregates
-  int aggregate(const CsrDev &A, double theta, dbuf<int> &agg, int *na_out) {
+  int aggregate(const CsrDev &A, double theta, int gap, dbuf<int> &agg, int *na_out) {
     const int n = A.n;
     const dim3 gr((n + TPB - 1) / TPB), bl(TPB);
     dbuf<double> d;
@@ -969,8 +969,7 @@ struct Builder {
     hipLaunchKernelGGL(agg_phase1_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, state.p, flag.p, agg.p);
     int na = 0;
     CHK(dv.read_int(flag.p + n, &na));
-    static const int gap = getenv("CFDH_AGG_GAP") ? atoi(getenv("CFDH_AGG_GAP")) : 4;  // 0: off, k: secondary roots with >= k leftover neighbours
-    if (gap > 0) {
+    if (gap > 0) {  // 0: off, k: secondary roots with >= k leftover neighbours
       hipLaunchKernelGGL(agg_gap_key_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, agg.p, gap, key.p);
       HIPCHK(c, hipMemsetAsync(flag.p, 0, sizeof(int), s));
       hipLaunchKernelGGL(agg_gap_root_kernel, gr, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, d.p, theta, key.p, flag.p);
@@ -1089,6 +1088,10 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
   static const double theta_env = getenv("CFDH_AMG_THETA") ? atof(getenv("CFDH_AMG_THETA")) : -1.0;
   const double theta = o.amg_theta >= 0 ? o.amg_theta : (theta_env >= 0 ? theta_env : (c->dim == 3 ? 0.02 : 0.07));
   const bool host_agg = getenv("CFDH_AMG_AGG") && !strcmp(getenv("CFDH_AMG_AGG"), "host");
+  // secondary roots (section 6 of DESIGN.md): CFDH_AGG_GAP for both hierarchies, CFDH_AGG_GAP_A / _L for the velocity proxy / the pressure Laplacian
+  const char *gap_env = getenv(&H == &c->hA ? "CFDH_AGG_GAP_A" : "CFDH_AGG_GAP_L");
+  if (!gap_env) gap_env = getenv("CFDH_AGG_GAP");
+  const int gap = gap_env ? atoi(gap_env) : 4;
   CsrDev A;
   move_csr(A, A0);
   AmgLevel *lastL = nullptr;
@@ -1126,7 +1129,7 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
         HIPCHK(c, agg.upload(ha, s));
         HIPCHK(c, hipStreamSynchronize(s));
       } else {
-        CHK(B.aggregate(A, theta, agg, &na));
+        CHK(B.aggregate(A, theta, gap, agg, &na));
       }
     }
     TICK(1);
