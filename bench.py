@@ -446,6 +446,10 @@ def main():
         "krylov_its_per_step": float(np.mean(its_krylov)),
         "per_krylov_iteration": {"allreduce": counters["allreduce"] / kits, "halo_exchange": counters["halo"] / kits,
                                  "allgather": counters["allgather"] / kits, "host_sync": counters["host_sync"] / kits},
+        # initial guess of the linear solves (cfdh_options.ksp_guess, PETSc's KSPGuess): each solve starts from the projection of its
+        # right-hand side onto the solutions of the same Newton solve of the last steps; every solve is still run to rtol |b|
+        "linear_solver_initial_guess": {"ksp_guess": int(sc.solver.options.ksp_guess), "solves_with_a_projected_guess": int(sc.solver.ctx.info(70)),
+                                        "mean_initial_residual_over_rhs": 1e-6 * sc.solver.ctx.info(71)},
         "setup_s": t_setup,
         # the reference's literal loop `u_prev.x.array[:] = u_sol.x.array[:]` (scenario.py:306-307): the lazy array proxy maps
         # that idiom to a device copy, so no field crosses PCIe in it
@@ -501,7 +505,7 @@ def main():
             "value": ncpu / tcpu, "unit": "time-steps/s", "cores": cores, "kind": "port", "host_cores_available": host_cores(),
             "sample": "steps %d..%d of the same mesh/dt from t=0 with the C oracle (oracle/cfdh_oracle.c, pc_kind=2: "
                       "same Newton + FGMRES + Cahouet-Chabard/AMG preconditioner and tolerances, FULL Schur factorisation = "
-                      "the faster variant on the CPU, OpenMP)" % (args.warmup + 1, nst),
+                      "the faster variant on the CPU, OpenMP; zero initial guess in every linear solve, as the reference's KSP)" % (args.warmup + 1, nst),
             "ms_per_step": 1e3 * tcpu / max(ncpu, 1),
         }
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -24,7 +24,7 @@ class Options(C.Structure):
         ("cheb_degree", C.c_int32), ("cheb_ratio", C.c_double), ("schur_full", C.c_int32),
         ("amg_smooth_degree", C.c_int32), ("amg_smooth_ratio", C.c_double), ("amg_theta", C.c_double),
         ("amg_max_coarse", C.c_int32), ("pc_refresh", C.c_int32), ("remove_p_mean", C.c_int32), ("verbose", C.c_int32),
-        ("pc_type", C.c_int32), ("cc_smooth_degree", C.c_int32),
+        ("pc_type", C.c_int32), ("cc_smooth_degree", C.c_int32), ("ksp_guess", C.c_int32),
     ]
 
 

@@ -30,6 +30,7 @@ int cfdh_default_options(cfdh_options *o) {
   o->cheb_degree = 3; o->cheb_ratio = 10.0; o->schur_full = 2;
   o->amg_smooth_degree = 1; o->amg_smooth_ratio = 8.0; o->amg_theta = -1.0; o->amg_max_coarse = 1000;
   o->pc_refresh = 0; o->remove_p_mean = 1; o->verbose = 0; o->pc_type = 1; o->cc_smooth_degree = 2;
+  o->ksp_guess = getenv("CFDH_KSP_GUESS") ? atoi(getenv("CFDH_KSP_GUESS")) : 3;
   return 0;
 }
 
@@ -120,7 +121,7 @@ int cfdh_set_params(cfdh_ctx *c, double dt, double rho, double mu, double mu_fac
 int cfdh_set_options(cfdh_ctx *c, const cfdh_options *o) {
   if (!c || !o) return CFDH_E_ARG;
   if (o->ksp_restart < 1 || o->ksp_restart > 1000 || o->cheb_degree < 1 || o->cc_smooth_degree < 1 || !(o->cheb_ratio > 1) || o->amg_smooth_degree < 1 ||
-      !(o->amg_smooth_ratio > 1) || o->amg_max_coarse < 8 || o->amg_max_coarse > 4000)
+      !(o->amg_smooth_ratio > 1) || o->amg_max_coarse < 8 || o->amg_max_coarse > 4000 || o->ksp_guess < 0 || o->ksp_guess > 8)
     return cfdh_fail(c, CFDH_E_ARG, "option out of range");
   const bool pc_changed = o->amg_theta != c->opt.amg_theta || o->amg_max_coarse != c->opt.amg_max_coarse ||
                           o->amg_smooth_ratio != c->opt.amg_smooth_ratio || o->pc_type != c->opt.pc_type ||
@@ -698,6 +699,8 @@ int64_t cfdh_info(const cfdh_ctx *c, int what) {
       return ((what / 10) & 1) ? (int64_t)h.lev[l]->n : (int64_t)h.lev[l]->A.nnz;
     }
     case 28: return c->etype;
+    case 70: return c->n_guess_solves;  // linear solves started from a projected guess (cfdh_options.ksp_guess)
+    case 71: return c->n_guess_solves ? (int64_t)(1e6 * c->guess_reduction_sum / (double)c->n_guess_solves) : 0;  // mean |r0| / |b| of those, in 1e-6
     case 29: return c->nloc;
     case 27: return (int64_t)(1000.0 * c->ms_pc_build_dev);  // microseconds of the last device-side preconditioner build (0: host build)
     case 19: return c->opt.pc_type == 1 ? c->hL.nnz_S0 : c->hS.nnz_S0;

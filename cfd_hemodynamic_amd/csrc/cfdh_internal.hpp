@@ -253,6 +253,14 @@ struct cfdh_ctx {
 
   // Krylov workspace
   int kry_m = 0;
+  // projected initial guess (cfdh_options.ksp_guess): ring of earlier solutions per Newton index, [GUESS_NEWTON][ksp_guess] vectors
+  // of leading dimension ld; guess_slot = Newton index of the solve in progress (-1: zero guess)
+  static constexpr int GUESS_NEWTON = 4;
+  dbuf<double> guessU;
+  int guess_m = 0, guess_slot = -1;
+  int guess_cnt[GUESS_NEWTON] = {0, 0, 0, 0}, guess_head[GUESS_NEWTON] = {0, 0, 0, 0};
+  long long n_guess_solves = 0;
+  double guess_reduction_sum = 0.0;  // sum of |r0| / |b| over the solves that started from a projected guess
   dbuf<double> kV, kZ, kw, kh;  // V[(m+1)*NL], Z[m*NL], w[NL], h[2*(m+1)+2]
   dbuf<double> ky;
 

@@ -655,7 +655,113 @@ static int ensure_krylov(cfdh_ctx *c) {
   return 0;
 }
 
-// Solve J x = b, x0 = 0.  Right preconditioning, convergence on the true
+// ---- projected initial guess (cfdh_options.ksp_guess; PETSc's KSPGuess of Fischer type, with the CURRENT matrix) ----------
+// The sequence of linear systems of a time-stepping run is smooth in time: the k-th Newton update of step n+1 is close to
+// the k-th update of step n.  U = the last few solutions of solves with the same Newton index; W = J U (one SpMV each);
+// x0 = U y with y = argmin |b - W y| from the normal equations (at most 8 x 8, solved on the host with a pivoted Cholesky that
+// drops directions which have become numerically dependent).  |b - J x0| <= |b| by construction, so a bad history can only
+// cost the SpMVs.  The Krylov workspace is free before the first cycle: V_1.. hold the halo-extended copies, Z_0.. hold W.
+static int guess_ensure(cfdh_ctx *c) {
+  const int m = c->opt.ksp_guess;
+  const size_t ld = ((size_t)c->NL + 1) & ~(size_t)1;
+  if (m == c->guess_m && (m == 0 || c->guessU.p)) return 0;
+  c->guess_m = m;
+  for (int k = 0; k < cfdh_ctx::GUESS_NEWTON; k++) c->guess_cnt[k] = c->guess_head[k] = 0;
+  if (m > 0) { HIPCHK(c, c->guessU.alloc(ld * (size_t)m * cfdh_ctx::GUESS_NEWTON)); HIPCHK(c, c->guessU.zero(c->stream)); }
+  return 0;
+}
+
+static int guess_project(cfdh_ctx *c, const double *b, double *x, bool *used) {
+  *used = false;
+  CHK(guess_ensure(c));
+  const int slot = c->guess_slot, m = c->guess_m;
+  if (m <= 0 || slot < 0 || slot >= cfdh_ctx::GUESS_NEWTON || c->guess_cnt[slot] == 0 || c->kry_m < m + 1) return 0;
+  const int k = c->guess_cnt[slot], n = c->NO;
+  const size_t ld = ((size_t)c->NL + 1) & ~(size_t)1;
+  double *U = c->guessU.p + ld * (size_t)m * slot;  // the ring of this Newton index (order is irrelevant to the projection)
+  double *V = c->kV.p, *Z = c->kZ.p, *hd = c->kh.p;
+  for (int i = 0; i < k; i++) {
+    double *t = V + (size_t)(i + 1) * ld;
+    CHK(v_copy(c, n, U + (size_t)i * ld, t));
+    CHK(comm_halo(c, t));
+    CHK(k_spmv_full(c, t, Z + (size_t)i * ld));
+  }
+  // Gram matrix G = W^T W (column by column) and g = W^T b
+  std::vector<double> G((size_t)k * k), g(k), y(k, 0.0);
+  for (int i = 0; i <= k; i++) {
+    const double *vec = i < k ? Z + (size_t)i * ld : b;
+    CHK(v_multidot(c, n, Z, (int)ld, k, vec, hd, false, false));
+    HIPCHK(c, hipMemcpyAsync(c->h_pinned, hd, sizeof(double) * k, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int q = 0; q < k; q++) (i < k ? G[(size_t)q * k + i] : g[q]) = c->h_pinned[q];
+  }
+  if (c->opt.verbose > 1) {
+    double bb = 0.0;
+    CHK(v_norm2(c, n, b, &bb));
+    fprintf(stderr, "[cfdh]     guess diag (newton %d): cos(W_i, b) =", slot);
+    for (int i = 0; i < k; i++) fprintf(stderr, " %.6f", g[i] / (std::sqrt(G[(size_t)i * k + i]) * bb));
+    fprintf(stderr, "; |W_i|/|b| =");
+    for (int i = 0; i < k; i++) fprintf(stderr, " %.4f", std::sqrt(G[(size_t)i * k + i]) / bb);
+    fprintf(stderr, "\n");
+  }
+  // pivoted Cholesky of G with a relative drop tolerance, then the two triangular solves
+  std::vector<int> piv;
+  std::vector<double> Lc((size_t)k * k, 0.0), dg(k);
+  std::vector<char> taken(k, 0);
+  for (int i = 0; i < k; i++) dg[i] = G[(size_t)i * k + i];
+  const double dmax0 = *std::max_element(dg.begin(), dg.end());
+  if (!(dmax0 > 0.0) || !std::isfinite(dmax0)) return 0;
+  for (int r = 0; r < k; r++) {
+    int p = -1;
+    for (int i = 0; i < k; i++) if (!taken[i] && (p < 0 || dg[i] > dg[p])) p = i;
+    if (p < 0 || !(dg[p] > 1e-10 * G[(size_t)p * k + p]) || !(dg[p] > 1e-14 * dmax0)) break;
+    taken[p] = 1;
+    const int rr = (int)piv.size();
+    piv.push_back(p);
+    const double lpp = std::sqrt(dg[p]);
+    Lc[(size_t)p * k + rr] = lpp;
+    for (int i = 0; i < k; i++) {
+      if (taken[i]) continue;
+      double sacc = G[(size_t)i * k + p];
+      for (int q = 0; q < rr; q++) sacc -= Lc[(size_t)i * k + q] * Lc[(size_t)p * k + q];
+      Lc[(size_t)i * k + rr] = sacc / lpp;
+      dg[i] -= Lc[(size_t)i * k + rr] * Lc[(size_t)i * k + rr];
+    }
+  }
+  const int r = (int)piv.size();
+  if (r == 0) return 0;
+  std::vector<double> t(r);
+  for (int a = 0; a < r; a++) {
+    double sacc = g[piv[a]];
+    for (int q = 0; q < a; q++) sacc -= Lc[(size_t)piv[a] * k + q] * t[q];
+    t[a] = sacc / Lc[(size_t)piv[a] * k + a];
+  }
+  for (int a = r - 1; a >= 0; a--) {
+    double sacc = t[a];
+    for (int q = a + 1; q < r; q++) sacc -= Lc[(size_t)piv[q] * k + a] * y[piv[q]];
+    y[piv[a]] = sacc / Lc[(size_t)piv[a] * k + a];
+  }
+  for (int i = 0; i < k; i++) if (!std::isfinite(y[i])) return 0;
+  HIPCHK(c, hipMemcpyAsync(c->ky.p, y.data(), sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
+  CHK(v_lincomb(c, n, U, (int)ld, k, c->ky.p, x));  // x (zeroed by the caller) += U y
+  HIPCHK(c, hipStreamSynchronize(c->stream));        // y is a host temporary
+  *used = true;
+  return 0;
+}
+
+// keep the solution of a converged solve for the guesses of later time steps
+static int guess_store(cfdh_ctx *c, const double *x) {
+  const int slot = c->guess_slot, m = c->guess_m;
+  if (m <= 0 || slot < 0 || slot >= cfdh_ctx::GUESS_NEWTON) return 0;
+  const size_t ld = ((size_t)c->NL + 1) & ~(size_t)1;
+  double *U = c->guessU.p + ld * (size_t)m * slot;
+  CHK(v_copy(c, c->NO, x, U + (size_t)c->guess_head[slot] * ld));
+  c->guess_head[slot] = (c->guess_head[slot] + 1) % m;
+  if (c->guess_cnt[slot] < m) c->guess_cnt[slot]++;
+  return 0;
+}
+
+// Solve J x = b, x0 = 0 or the projected guess.  Right preconditioning, convergence on the true
 // residual norm relative to |b| (KSP defaults: rtol, atol; KSP_NORM_UNPRECONDITIONED
 // for FGMRES).  Classical Gram-Schmidt with one re-orthogonalisation pass; the
 // 2j+3 scalars of an iteration come back in a single read.
@@ -674,6 +780,9 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
   const double tol = std::max(o.ksp_rtol * bn, o.ksp_atol);
   double *V = c->kV.p, *Z = c->kZ.p, *w = c->kw.p, *hd = c->kh.p;
   bool first = true;
+  bool guessed = false;
+  CHK(guess_project(c, b, x, &guessed));
+  if (guessed) first = false;  // the cycle starts from the true residual of x0, as after a restart
   double est_prev = 0.0, beta_start = bn;  // residual estimate at the end / true residual at the start of the last cycle
   int j_prev = 0;
   for (;;) {
@@ -685,11 +794,15 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       CHK(k_spmv_full(c, x, w));
       CHK(v_waxpy(c, n, -1.0, w, b, V));
       CHK(v_norm2(c, n, V, &beta));
+      if (guessed && its == 0 && j_prev == 0) {
+        c->n_guess_solves++; c->guess_reduction_sum += beta / bn;
+        if (o.verbose) fprintf(stderr, "[cfdh]     projected guess (newton %d, %d vectors): |r0| / |b| = %.3e\n", c->guess_slot, c->guess_cnt[c->guess_slot], beta / bn);
+      }
       // Orthogonality watchdog.  Unrefined classical Gram-Schmidt (PETSc's default) can lose the basis in a long cycle:
       // the recurrence then reports convergence while the true residual, formed here after every cycle anyway, does not
       // follow.  Once that is seen on a context, long cycles are re-orthogonalised (DGKS) from then on, and a cycle that
       // made the residual worse is taken back.
-      if (!c->gs_refine_long && beta > 10.0 * std::max(est_prev, tol)) {
+      if (!c->gs_refine_long && j_prev > 0 && beta > 10.0 * std::max(est_prev, tol)) {
         c->gs_refine_long = true;
         if (o.verbose) fprintf(stderr, "[cfdh]     fgmres: true residual %.3e vs recurrence %.3e after a %d-vector cycle: re-orthogonalising long cycles from now on\n", beta, est_prev, j_prev);
         if (beta > beta_start && j_prev > 0) {
@@ -796,6 +909,7 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
   c->n_krylov += its;
   *its_out = its;
   *reason_out = reason;
+  if (reason > 0) CHK(guess_store(c, x));
   return 0;
 }
 
@@ -905,6 +1019,7 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
     st->ms_pc_setup += wall_ms() - t0;
     t0 = wall_ms();
     int kits = 0, kreason = 0;
+    c->guess_slot = it;
     CHK(cfdh_fgmres(c, c->F.p, d, &kits, &kreason, fn));
     if (kreason < 0 && c->pc_its_ref > 0) {
       // a lagged hierarchy that stopped working: rebuild once and retry
@@ -912,6 +1027,7 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
       st->krylov_its += kits;
       CHK(cfdh_fgmres(c, c->F.p, d, &kits, &kreason, fn));
     }
+    c->guess_slot = -1;
     st->krylov_its += kits;
     st->ms_solve += wall_ms() - t0;
     if (kreason < 0) { reason = CFDH_DIVERGED_LINEAR_SOLVE; cfdh_fail(c, CFDH_E_DIVERGED, "FGMRES failed (reason %d) after %d iterations", kreason, kits); break; }

@@ -91,6 +91,11 @@ typedef struct cfdh_options {
   int32_t pc_type;          /* 0: SELFP Schur matrix + Chebyshev(A00) (the reference's SELFP, :235);
                              * 1: Cahouet-Chabard Schur approximation + AMG(A00) (mesh-independent) */
   int32_t cc_smooth_degree; /* pc_type 1: Chebyshev steps on the mass-like operator H (default 2) */
+  int32_t ksp_guess;        /* initial guess of the linear solves (PETSc: KSPGuess, -ksp_guess_type fischer): the solutions of the
+                             * last ksp_guess time steps' solves of the same Newton iteration are kept and the new solve starts
+                             * from their best combination, x0 = U y with y = argmin |b - J U y| (so |r0| <= |b|); convergence
+                             * is still tested against rtol |b|.  0: zero initial guess (what the reference's KSP does);
+                             * default 3.  Converged results do not depend on it, iteration counts do. */
 } cfdh_options;
 
 typedef struct cfdh_stats {
@@ -280,7 +285,8 @@ int cfdh_profile_reset(cfdh_ctx *ctx);
  * level 0, 23 / 24 size of level 1, 25: fused cycle in use; 26: gdim;
  * 27: microseconds the last preconditioner build took on the device (0: it was built on the host); 28: element type (CFDH_ELEM_*),
  * 29: nodes per cell;
- * 30 + l / 40 + l: rows / entries of level l of the velocity hierarchy, 50 + l / 60 + l: of the pressure hierarchy (l < 10, 0 past the end) */
+ * 30 + l / 40 + l: rows / entries of level l of the velocity hierarchy, 50 + l / 60 + l: of the pressure hierarchy (l < 10, 0 past the end);
+ * 70: linear solves that started from a projected initial guess (cfdh_options.ksp_guess), 71: their mean |r0| / |b| in units of 1e-6 */
 int64_t cfdh_info(const cfdh_ctx *ctx, int what);
 
 #ifdef __cplusplus

@@ -24,4 +24,4 @@ for k in range(steps):
 print("variant host=%s agg=%s | %s size %s nv=%d | setup %.2fs | its %s | pc_setup ms %s | step wall ms %s" % (
     os.environ.get("CFDH_AMG_HOST", "0"), os.environ.get("CFDH_AMG_AGG", "dev"), cfg, size, sc.mesh.num_vertices, t_setup, its,
     ["%.1f" % p for p in pcs], ["%.1f" % (1e3 * w) for w in walls]))
-print("  L2 norms: %.12e %.12e" % (s.functional(2), s.functional(3)))
+print("  L2 norms: %.12e %.12e | guessed solves %d, mean |r0|/|b| %.2e | mean step wall of the last half %.2f ms" % (s.functional(2), s.functional(3), s.ctx.info(70), 1e-6 * s.ctx.info(71), 1e3 * sum(walls[len(walls) // 2:]) / max(1, len(walls) - len(walls) // 2)))
