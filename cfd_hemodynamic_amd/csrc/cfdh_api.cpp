@@ -30,7 +30,7 @@ int cfdh_default_options(cfdh_options *o) {
   o->cheb_degree = 3; o->cheb_ratio = 10.0; o->schur_full = 2;
   o->amg_smooth_degree = 1; o->amg_smooth_ratio = 8.0; o->amg_theta = -1.0; o->amg_max_coarse = 1000;
   o->pc_refresh = 0; o->remove_p_mean = 1; o->verbose = 0; o->pc_type = 1; o->cc_smooth_degree = 2;
-  o->ksp_guess = getenv("CFDH_KSP_GUESS") ? atoi(getenv("CFDH_KSP_GUESS")) : 3;
+  o->ksp_guess = getenv("CFDH_KSP_GUESS") ? atoi(getenv("CFDH_KSP_GUESS")) : 4;
   return 0;
 }
 

@@ -256,7 +256,8 @@ struct cfdh_ctx {
   // projected initial guess (cfdh_options.ksp_guess): ring of earlier solutions per Newton index, [GUESS_NEWTON][ksp_guess] vectors
   // of leading dimension ld; guess_slot = Newton index of the solve in progress (-1: zero guess)
   static constexpr int GUESS_NEWTON = 4;
-  dbuf<double> guessU;
+  dbuf<double> guessU, guessX;  // guessX: the Newton iterates x_k of the step in progress (k < GUESS_NEWTON)
+  bool guess_stored[GUESS_NEWTON] = {false, false, false, false};
   int guess_m = 0, guess_slot = -1;
   int guess_cnt[GUESS_NEWTON] = {0, 0, 0, 0}, guess_head[GUESS_NEWTON] = {0, 0, 0, 0};
   long long n_guess_solves = 0;

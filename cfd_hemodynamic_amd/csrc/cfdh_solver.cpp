@@ -667,7 +667,10 @@ static int guess_ensure(cfdh_ctx *c) {
   if (m == c->guess_m && (m == 0 || c->guessU.p)) return 0;
   c->guess_m = m;
   for (int k = 0; k < cfdh_ctx::GUESS_NEWTON; k++) c->guess_cnt[k] = c->guess_head[k] = 0;
-  if (m > 0) { HIPCHK(c, c->guessU.alloc(ld * (size_t)m * cfdh_ctx::GUESS_NEWTON)); HIPCHK(c, c->guessU.zero(c->stream)); }
+  if (m > 0) {
+    HIPCHK(c, c->guessU.alloc(ld * (size_t)m * cfdh_ctx::GUESS_NEWTON)); HIPCHK(c, c->guessU.zero(c->stream));
+    HIPCHK(c, c->guessX.alloc(ld * (size_t)cfdh_ctx::GUESS_NEWTON));
+  }
   return 0;
 }
 
@@ -688,13 +691,13 @@ static int guess_project(cfdh_ctx *c, const double *b, double *x, bool *used) {
   }
   // Gram matrix G = W^T W (column by column) and g = W^T b
   std::vector<double> G((size_t)k * k), g(k), y(k, 0.0);
-  for (int i = 0; i <= k; i++) {
-    const double *vec = i < k ? Z + (size_t)i * ld : b;
-    CHK(v_multidot(c, n, Z, (int)ld, k, vec, hd, false, false));
-    HIPCHK(c, hipMemcpyAsync(c->h_pinned, hd, sizeof(double) * k, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int q = 0; q < k; q++) (i < k ? G[(size_t)q * k + i] : g[q]) = c->h_pinned[q];
-  }
+  for (int i = 0; i <= k; i++)  // k + 1 multi-dots into consecutive slots of the scalar scratch, ONE read-back
+    CHK(v_multidot(c, n, Z, (int)ld, k, i < k ? Z + (size_t)i * ld : b, hd + (size_t)i * 8, false, false));
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, hd, sizeof(double) * 8 * (size_t)(k + 1), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->n_host_sync++;
+  for (int i = 0; i <= k; i++)
+    for (int q = 0; q < k; q++) (i < k ? G[(size_t)q * k + i] : g[q]) = c->h_pinned[(size_t)i * 8 + q];
   if (c->opt.verbose > 1) {
     double bb = 0.0;
     CHK(v_norm2(c, n, b, &bb));
@@ -744,6 +747,9 @@ static int guess_project(cfdh_ctx *c, const double *b, double *x, bool *used) {
   for (int i = 0; i < k; i++) if (!std::isfinite(y[i])) return 0;
   HIPCHK(c, hipMemcpyAsync(c->ky.p, y.data(), sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
   CHK(v_lincomb(c, n, U, (int)ld, k, c->ky.p, x));  // x (zeroed by the caller) += U y
+  // singular system: the guess, like every preconditioned vector, carries no constant-pressure component (the Krylov vectors
+  // cannot remove one, and through the kept corrections it would feed back from step to step)
+  if (c->singular) CHK(v_sub_mean(c, c->nvo, x + (size_t)c->dim * c->nvo));
   HIPCHK(c, hipStreamSynchronize(c->stream));        // y is a host temporary
   *used = true;
   return 0;
@@ -756,8 +762,26 @@ static int guess_store(cfdh_ctx *c, const double *x) {
   const size_t ld = ((size_t)c->NL + 1) & ~(size_t)1;
   double *U = c->guessU.p + ld * (size_t)m * slot;
   CHK(v_copy(c, c->NO, x, U + (size_t)c->guess_head[slot] * ld));
+  c->guess_stored[slot] = true;
   c->guess_head[slot] = (c->guess_head[slot] + 1) % m;
   if (c->guess_cnt[slot] < m) c->guess_cnt[slot]++;
+  return 0;
+}
+
+// At the end of a converged step the kept solutions are replaced by what the solves were approximating: the remaining Newton
+// correction x_k - x_final (J_k d = F(x_k), x_final = x_k - d up to the quadratic remainder).  The linear solves stop at
+// rtol 1e-5; x_final is converged to snes_rtol, so the kept vectors lose the solver noise that otherwise bounds the quality of
+// the next steps' projections at ~1e-4.
+static int guess_refine(cfdh_ctx *c, int newton_its, const double *x_final) {
+  const int m = c->guess_m;
+  if (m <= 0 || !c->guessX.p) return 0;
+  const size_t ld = ((size_t)c->NL + 1) & ~(size_t)1;
+  for (int k = 0; k < newton_its && k < cfdh_ctx::GUESS_NEWTON; k++) {
+    if (!c->guess_stored[k]) continue;
+    double *U = c->guessU.p + ld * (size_t)m * k;
+    const int latest = (c->guess_head[k] + m - 1) % m;
+    CHK(v_waxpy(c, c->NO, -1.0, x_final, c->guessX.p + (size_t)k * ld, U + (size_t)latest * ld));
+  }
   return 0;
 }
 
@@ -999,6 +1023,7 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
   // assembled there (mode 2: same residual bit for bit, no matrix written); a wrong prediction costs one more pass.
   bool jac_current = true;
   double fn_before = 0.0;
+  CHK(guess_ensure(c));
   for (int it = 0;; it++) {
     if (o.verbose) fprintf(stderr, "[cfdh]   newton %d |F| = %.6e\n", it, fn);
     if (!std::isfinite(fn)) { reason = CFDH_DIVERGED_FNORM_NAN; break; }
@@ -1020,6 +1045,10 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
     t0 = wall_ms();
     int kits = 0, kreason = 0;
     c->guess_slot = it;
+    if (it < cfdh_ctx::GUESS_NEWTON) {
+      c->guess_stored[it] = false;
+      if (c->guessX.p) CHK(v_copy(c, n, x, c->guessX.p + (size_t)it * (((size_t)c->NL + 1) & ~(size_t)1)));
+    }
     CHK(cfdh_fgmres(c, c->F.p, d, &kits, &kreason, fn));
     if (kreason < 0 && c->pc_its_ref > 0) {
       // a lagged hierarchy that stopped working: rebuild once and retry
@@ -1069,6 +1098,7 @@ int cfdh_newton_step(cfdh_ctx *c, cfdh_stats *st) {
       break;
     }
   }
+  if (reason > 0) CHK(guess_refine(c, st->newton_its, c->x.p));
   c->steps_since_refresh++;
   st->fnorm = fn;
   st->reason = reason;

@@ -91,11 +91,12 @@ typedef struct cfdh_options {
   int32_t pc_type;          /* 0: SELFP Schur matrix + Chebyshev(A00) (the reference's SELFP, :235);
                              * 1: Cahouet-Chabard Schur approximation + AMG(A00) (mesh-independent) */
   int32_t cc_smooth_degree; /* pc_type 1: Chebyshev steps on the mass-like operator H (default 2) */
-  int32_t ksp_guess;        /* initial guess of the linear solves (PETSc: KSPGuess, -ksp_guess_type fischer): the solutions of the
-                             * last ksp_guess time steps' solves of the same Newton iteration are kept and the new solve starts
-                             * from their best combination, x0 = U y with y = argmin |b - J U y| (so |r0| <= |b|); convergence
-                             * is still tested against rtol |b|.  0: zero initial guess (what the reference's KSP does);
-                             * default 3.  Converged results do not depend on it, iteration counts do. */
+  int32_t ksp_guess;        /* initial guess of the linear solves (PETSc: KSPGuess, -ksp_guess_type fischer): for each Newton index the
+                             * corrections of the last ksp_guess time steps are kept (at the end of a step: iterate minus converged
+                             * solution) and the new solve starts from their best combination, x0 = U y with
+                             * y = argmin |b - J U y| on the CURRENT Jacobian (so |r0| <= |b|); convergence is still tested against
+                             * rtol |b|.  0: zero initial guess (what the reference's KSP does); default 4.  Converged results do
+                             * not depend on it, iteration counts do. */
 } cfdh_options;
 
 typedef struct cfdh_stats {

@@ -168,11 +168,11 @@ def test_config1_dfg_coarse_full_run_to_T1(oracle_double):
 
 def test_projected_initial_guess_changes_iteration_counts_not_results():
     """cfdh_options.ksp_guess (KSPGuess of Fischer type on the CURRENT Jacobian): the k-th Newton solve of a step starts from the
-    best combination of the k-th solves of the last three steps.  |r0| <= |b| by construction; converged results are the same
+    best combination of the k-th corrections of the last four steps.  |r0| <= |b| by construction; converged results are the same
     with and without it; the first Newton solve of a developed flow starts orders of magnitude below |b|."""
     from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
     runs = {}
-    for guess in (0, 3):
+    for guess in (0, 4):
         sc = DFG1Benchmark("stabilized_schur", 0.01, 1.0, m=36, quiet=True, options=dict(ksp_guess=guess, snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-9))
         its = []
         for k in range(10):
@@ -183,11 +183,11 @@ def test_projected_initial_guess_changes_iteration_counts_not_results():
         x = np.concatenate([np.asarray(sc.solver.u_sol.x.array), np.asarray(sc.solver.p_sol.x.array)])
         runs[guess] = (x, its, sc.solver.ctx.info(70), 1e-6 * sc.solver.ctx.info(71), sc.solver.functional(0, 5), sc.solver.functional(1, 5))
     x0, its0, n0, _, d0, l0 = runs[0]
-    x3, its3, n3, red3, d3, l3 = runs[3]
+    x4, its4, n4, red4, d4, l4 = runs[4]
     nv = len(x0) // 3
-    assert n0 == 0 and n3 >= 2 * 9                       # every solve after the first step started from a projection
-    assert red3 < 0.5                                    # mean |r0| / |b| over both Newton solves (the first alone: ~1e-4)
-    assert its3[0] == its0[0] and sum(its3[3:]) < 0.9 * sum(its0[3:])
-    assert np.linalg.norm(x3[: 2 * nv] - x0[: 2 * nv]) <= 1e-8 * np.linalg.norm(x0[: 2 * nv])
-    assert np.linalg.norm(x3[2 * nv:] - x0[2 * nv:]) <= 1e-7 * np.linalg.norm(x0[2 * nv:])
-    assert abs(d3 - d0) <= 1e-8 * abs(d0) and abs(l3 - l0) <= 1e-6 * abs(l0) + 1e-12
+    assert n0 == 0 and n4 >= 2 * 9                       # every solve after the first step started from a projection
+    assert red4 < 0.5                                    # mean |r0| / |b| over both Newton solves (the first alone: ~1e-4)
+    assert its4[0] == its0[0] and sum(its4[3:]) < 0.9 * sum(its0[3:])
+    assert np.linalg.norm(x4[: 2 * nv] - x0[: 2 * nv]) <= 1e-8 * np.linalg.norm(x0[: 2 * nv])
+    assert np.linalg.norm(x4[2 * nv:] - x0[2 * nv:]) <= 1e-7 * np.linalg.norm(x0[2 * nv:])
+    assert abs(d4 - d0) <= 1e-8 * abs(d0) and abs(l4 - l0) <= 1e-6 * abs(l0) + 1e-12
