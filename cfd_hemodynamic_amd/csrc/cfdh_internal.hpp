@@ -421,6 +421,7 @@ int v_pointwise_mult(cfdh_ctx *c, int n, const double *a, const double *b, doubl
 int k_moments(cfdh_ctx *c);
 int k_assemble(cfdh_ctx *c, const double *xstate, int mode);  // mode 0: F only, 1: F+J, 2: F with lifting (no J write)
 int k_spmv_full(cfdh_ctx *c, const double *x, double *y);
+int k_spmv_full_multi(cfdh_ctx *c, const double *X, double *Y, int ld, int nvec);  // Y_v = J X_v, vectors ld apart
 int k_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b, double alpha);  // y = b*? see .hip
 int k_spmv_block_ghost(cfdh_ctx *c, int blk, const double *xv, double *y, const double *b);
 int k_extract_diag(cfdh_ctx *c);

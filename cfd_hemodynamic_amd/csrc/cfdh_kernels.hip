@@ -702,6 +702,63 @@ __global__ __launch_bounds__(TPB) void spmv_full_kernel(int nvo, const int *__re
 }
 
 
+// The same product for NV vectors at once (leading dimension ld): the Jacobian is read once -- the projected initial guess of
+// the linear solves multiplies its 2-4 kept corrections with the current matrix (cfdh_solver.cpp::guess_project).
+template <int NV>
+__global__ __launch_bounds__(TPB) void spmv_full_multi_kernel(int nvo, const int *__restrict__ vptr, const int *__restrict__ vcol,
+                                                              const double *__restrict__ A00, const double *__restrict__ A01,
+                                                              const double *__restrict__ A10, const double *__restrict__ A11,
+                                                              const double *__restrict__ X, double *__restrict__ Y, size_t ld) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  double a0[NV], a1[NV], a2[NV];
+#pragma unroll
+  for (int v = 0; v < NV; v++) a0[v] = a1[v] = a2[v] = 0.0;
+  if (row < nvo) {
+    const int ks = vptr[row], ke = vptr[row + 1];
+    for (int k = ks + l; k < ke; k += 8) {
+      const int w = vcol[k];
+      const int uo = uoff(w, nvo), po = poff(w, nvo);
+      const double2 b0 = *(const double2 *)(A00 + 4 * (size_t)k), b1 = *(const double2 *)(A00 + 4 * (size_t)k + 2);
+      const double2 c01 = *(const double2 *)(A01 + 2 * (size_t)k), c10 = *(const double2 *)(A10 + 2 * (size_t)k);
+      const double c11 = A11[k];
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        const double *x = X + (size_t)v * ld;
+        const double xu0 = x[uo], xu1 = x[uo + 1], xp = x[po];
+        a0[v] += b0.x * xu0 + b0.y * xu1 + c01.x * xp;
+        a1[v] += b1.x * xu0 + b1.y * xu1 + c01.y * xp;
+        a2[v] += c10.x * xu0 + c10.y * xu1 + c11 * xp;
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    const double s0 = group8_sum(a0[v]), s1 = group8_sum(a1[v]), s2 = group8_sum(a2[v]);
+    if (row < nvo && l == 0) {
+      double *y = Y + (size_t)v * ld;
+      *(double2 *)(y + 2 * (size_t)row) = make_double2(s0, s1);
+      y[2 * (size_t)nvo + row] = s2;
+    }
+  }
+}
+
+// Y_v = J X_v for v < nvec (vectors ld apart; ghost tails of X filled by the caller)
+int k_spmv_full_multi(cfdh_ctx *c, const double *X, double *Y, int ld, int nvec) {
+  if (c->dim == 3 || nvec < 2 || nvec > 4) {
+    for (int v = 0; v < nvec; v++) CHK(k_spmv_full(c, X + (size_t)v * ld, Y + (size_t)v * ld));
+    return 0;
+  }
+  const long long nthreads = 8ll * c->nvo;
+  const dim3 gr((unsigned)((nthreads + TPB - 1) / TPB)), bl(TPB);
+#define CFDH_SPMM(NV) hipLaunchKernelGGL((spmv_full_multi_kernel<NV>), gr, bl, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A00.p, \
+                                         c->A01.p, c->A10.p, c->A11.p, X, Y, (size_t)ld)
+  if (nvec == 2) CFDH_SPMM(2); else if (nvec == 3) CFDH_SPMM(3); else CFDH_SPMM(4);
+#undef CFDH_SPMM
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int k_spmv_full(cfdh_ctx *c, const double *x, double *y) {
   if (c->dim == 3) return k3_spmv_full(c, x, y);
   const long long nthreads = 8ll * c->nvo;

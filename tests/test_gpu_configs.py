@@ -166,11 +166,12 @@ def test_config1_dfg_coarse_full_run_to_T1(oracle_double):
     assert abs(g.p_diff - o.p_diff) <= 1e-5 * abs(o.p_diff)   # pressure difference p(0.15, 0.2) - p(0.25, 0.2), dfg_1.py:213-253
 
 
-def test_projected_initial_guess_changes_iteration_counts_not_results():
+def test_projected_initial_guess_changes_iteration_counts_not_results(monkeypatch):
     """cfdh_options.ksp_guess (KSPGuess of Fischer type on the CURRENT Jacobian): the k-th Newton solve of a step starts from the
     best combination of the k-th corrections of the last four steps.  |r0| <= |b| by construction; converged results are the same
     with and without it; the first Newton solve of a developed flow starts orders of magnitude below |b|."""
     from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+    monkeypatch.setenv("CFDH_GUESS_CHECK", "1")  # the library compares b - W y (multi-vector SpMV) with the true residual of x0
     runs = {}
     for guess in (0, 4):
         sc = DFG1Benchmark("stabilized_schur", 0.01, 1.0, m=36, quiet=True, options=dict(ksp_guess=guess, snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-9))
