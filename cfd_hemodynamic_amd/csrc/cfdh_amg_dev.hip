@@ -907,7 +907,7 @@ struct Builder {
     double *nrm = c->red_out.p + 30;
     for (int it = 0; it < 15; it++) {
       hipLaunchKernelGGL(spmv_dinv_kernel, gr8, bl, 0, s, n, A.rowptr.p, A.col.p, A.val.p, L.dinv.p, v.p, w.p);
-      CHK(v_norm_to_dev(c, n, w.p, nrm));
+      CHK(v_norm_to_dev_local(c, n, w.p, nrm));  // rank-local operator: no reduction over the ranks
       CHK(v_scale_inv_dev(c, n, w.p, nrm, v.p));
     }
     double lm = 1.0;
@@ -1152,6 +1152,22 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
     } else
     CHK((Spgemm<AOpImwDA, BOpAgg>::run(B.dv, A.n, na, AOpImwDA{Am, L->dinv.p, 4.0 / 3.0 / lm, agg.p}, BOpAgg{agg.p}, P, B.lists, B.tmp, B.cnts)));
     TICK(2);
+    if (H.keep_host0 && H.lev.size() == 1) {
+      // partitioned run, replicated global pressure space: the caller cuts this rank's rows of the level-0 operator and
+      // prolongator out of host copies (cfdh_solver.cpp, distributed finest level)
+      auto down = [&](const CsrDev &D, CsrHost &Hc) -> int {
+        Hc.n = D.n; Hc.m = D.m;
+        Hc.rowptr.resize((size_t)D.n + 1); Hc.col.resize((size_t)D.nnz); Hc.val.resize((size_t)D.nnz);
+        HIPCHK(c, hipMemcpyAsync(Hc.rowptr.data(), D.rowptr.p, sizeof(int) * ((size_t)D.n + 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(Hc.col.data(), D.col.p, sizeof(int) * (size_t)D.nnz, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(Hc.val.data(), D.val.p, sizeof(double) * (size_t)D.nnz, hipMemcpyDeviceToHost, s));
+        return 0;
+      };
+      CHK(down(A, H.h_A0)); CHK(down(P, H.h_P0));
+      H.h_wdinv0.resize((size_t)A.n);
+      HIPCHK(c, hipMemcpyAsync(H.h_wdinv0.data(), L->wdinv.p, sizeof(double) * (size_t)A.n, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+    }
     CHK(B.transpose(P, R));
     TICK(3);
     const MatV Pm{P.rowptr.p, P.col.p, P.val.p}, Rm{R.rowptr.p, R.col.p, R.val.p};
@@ -1183,6 +1199,9 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
     if (L->fine) CHK(B.formats(L->G, CFDH_UP_CSRF));
     if (L->sell) { CHK(B.formats(L->Sb, CFDH_UP_SELL)); CHK(B.formats(L->Sc, CFDH_UP_SELL)); }
     if (H.lev.size() == 1) { H.nnz_G0 = L->G.nnz; H.nnz_S0 = (long long)L->Sb.nnz + L->Sc.nnz; }
+    // a partitioned run also uses the sweep-by-sweep cycle (distributed finest pressure level, overlapping velocity block): it
+    // needs the plain transfer operators
+    if (c->nranks > 1) { move_csr(L->P, P); move_csr(L->R, R); }
     move_csr(L->A, A);
     lastL = L;
     move_csr(A, Ac);

@@ -459,6 +459,7 @@ int v_multiaxpy(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const dou
 // s (or sqrt(w.w) when the difference cancels) is stored in *s_dev
 int v_gs_update_normalize(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, const double *w, double *vn, double *s_dev);
 int v_norm_to_dev(cfdh_ctx *c, int n, const double *w, double *out_dev);  // ||w|| (global) into device scalar
+int v_norm_to_dev_local(cfdh_ctx *c, int n, const double *w, double *out_dev);  // no reduction over the ranks
 int v_scale_inv_dev(cfdh_ctx *c, int n, const double *w, const double *nrm_dev, double *v);  // v = w / *nrm
 int v_lincomb(cfdh_ctx *c, int n, const double *Z, int ld, int nvec, const double *y_dev, double *x);  // x += sum y_k Z_k
 int v_pack_state(cfdh_ctx *c, const double *u_user, const double *p_user, double *dst);  // host staging helpers

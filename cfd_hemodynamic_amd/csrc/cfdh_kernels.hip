@@ -2162,6 +2162,15 @@ int v_norm_to_dev(cfdh_ctx *c, int n, const double *w, double *out_dev) {
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+// the same without the reduction over the ranks: norms of rank-local operators (hierarchy set-up of a partitioned run)
+int v_norm_to_dev_local(cfdh_ctx *c, int n, const double *w, double *out_dev) {
+  const int nb = vgrid(n) > c->red_blocks ? c->red_blocks : vgrid(n);
+  hipLaunchKernelGGL(reduce_partial_kernel<0>, dim3(nb), dim3(TPB), 0, c->stream, n, w, w, c->red_partial.p);
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, out_dev, (double *)nullptr);
+  hipLaunchKernelGGL(sqrt_kernel, dim3(1), dim3(1), 0, c->stream, out_dev);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 __global__ __launch_bounds__(TPB) void scale_inv_dev_kernel(int n, const double *__restrict__ w, const double *__restrict__ nrm,
                                                             double *__restrict__ v) {
   const double s = nrm[0] != 0.0 ? 1.0 / nrm[0] : 0.0;

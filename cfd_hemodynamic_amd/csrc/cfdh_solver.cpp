@@ -116,6 +116,22 @@ static void mark_outflow_nodes(const cfdh_ctx *c, std::vector<unsigned char> &pb
 //   * H  = (I + a'T) M_l + b' A11 with a' = 2 rho/dt, b' = mu, T = diag(A11)/diag(L) (nodal tau/rho):
 //          S^-1 ~ (a' L^-1 + b' M_l^-1) [ (I + a'T) + b' A11 M_l^-1 ]^-1 for
 //          S = A11 + (1/2) B A00^-1 B^T ~ A11 + (a' L^-1 + b' M_l^-1)^-1   (A11 = (tau/rho)-weighted Laplacian).
+static int upload_csr_plain(cfdh_ctx *c, const CsrHost &H, CsrDev &D);
+
+// Hierarchy of a level-0 operator assembled on the host (partitioned runs: ghost rows, replicated pressure space): the sparse
+// products, aggregation and formats still run on the device (cfdh_amg_dev.hip) -- the operator is uploaded once.  Falls back to
+// the host build when the device build is switched off or gives up.
+static int amg_setup_from_host(cfdh_ctx *c, AmgHier &H, const CsrHost &A, bool singular, int ncol) {
+  static const bool host_multi = getenv("CFDH_AMG_HOST_MULTI") && getenv("CFDH_AMG_HOST_MULTI")[0] == '1';
+  if (cfdh_amg_dev_enabled(c) && !host_multi) {
+    CsrDev Ad;
+    if (upload_csr_plain(c, A, Ad) == 0 && cfdh_amg_setup_dev(c, H, Ad, singular, ncol) == 0) return 0;
+    if (c->opt.verbose) fprintf(stderr, "[cfdh] device-side AMG set-up gave up (%s): building this hierarchy on the host\n", c->err.c_str());
+    c->err.clear();
+  }
+  return cfdh_amg_setup(c, H, A, singular, ncol);
+}
+
 static int build_cc_host(cfdh_ctx *c) {
   std::vector<double> a00, a01, a10, a11;
   CHK(cfdh_download_blocks(c, a00, a01, a10, a11));
@@ -190,7 +206,7 @@ static int build_cc_host(cfdh_ctx *c) {
       if (!c->ras_b.p) { HIPCHK(c, c->ras_b.alloc((size_t)c->dim * c->nv)); HIPCHK(c, c->ras_x.alloc((size_t)c->dim * c->nv)); }
     }
     c->ras = ras;
-    CHK(cfdh_amg_setup(c, c->hA, Ah, false, c->dim));
+    CHK(amg_setup_from_host(c, c->hA, Ah, false, c->dim));
   }
   // --- pressure Laplacian hierarchy (once per Dirichlet set)
   // pbc bit0: the pressure dof is Dirichlet (identity row in H, z_p = r_p); bit1: Dirichlet in L only --
@@ -217,7 +233,7 @@ static int build_cc_host(cfdh_ctx *c) {
     bool any_pbc = false;
     for (int i = 0; i < nvo; i++) any_pbc |= pbc[i] != 0;
     // a part without pressure-Dirichlet rows has a pure-Neumann (singular) local Laplacian
-    CHK(cfdh_amg_setup(c, c->hL, Lh, c->singular != 0 || !any_pbc, 1));
+    CHK(amg_setup_from_host(c, c->hL, Lh, c->singular != 0 || !any_pbc, 1));
     c->hL_pbc = pbc;
     c->hL_singular = c->singular;
     std::vector<double> ml(nvo);
@@ -228,7 +244,7 @@ static int build_cc_host(cfdh_ctx *c) {
   if (c->gp_n > 0 && (c->gp_dirty || !c->hLg.valid)) {
     const bool dist = c->nranks > 1 && (int)c->h_gid.size() == c->nv && c->ng > 0;
     c->hLg.keep_host0 = dist;
-    CHK(cfdh_amg_setup(c, c->hLg, c->gp_L, c->gp_singular, 1));
+    CHK(amg_setup_from_host(c, c->hLg, c->gp_L, c->gp_singular, 1));
     c->gp_dirty = false;
     // Distributed finest level: this rank's rows of the global level-0 operator / prolongator (the hierarchy is
     // geometry-only and identical on all ranks, so no exchange is needed to build them).  The cycle is then the
@@ -308,7 +324,9 @@ static int build_cc_host(cfdh_ctx *c) {
       }
       Hh.rowptr[i + 1] = (int)Hh.col.size();
     }
-    CHK(cfdh_level_setup(c, c->Hlev, Hh, 8.0, 1));
+    CsrDev Hd;
+    if (cfdh_amg_dev_enabled(c) && upload_csr_plain(c, Hh, Hd) == 0) CHK(cfdh_level_setup_dev(c, c->Hlev, Hd, 8.0, 1));
+    else CHK(cfdh_level_setup(c, c->Hlev, Hh, 8.0, 1));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;

