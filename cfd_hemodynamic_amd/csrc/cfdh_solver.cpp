@@ -333,8 +333,8 @@ static int build_cc_host(cfdh_ctx *c) {
 }
 
 // The same preconditioner data built where the Jacobian lives (cfdh_amg_dev.hip): no download of the blocks, sparse
-// products / aggregation / formats by kernels.  Single-rank contexts; a partitioned run keeps the host build (ghost rows and
-// the replicated pressure space are host data structures).
+// products / aggregation / formats by kernels.  Single-rank contexts; a partitioned run assembles its level-0 operators on the
+// host (ghost rows, replicated pressure space: build_cc_host) and hands them to the same device builder (amg_setup_from_host).
 static int upload_csr_plain(cfdh_ctx *c, const CsrHost &H, CsrDev &D) {
   D.n = H.n; D.m = H.m; D.nnz = H.nnz();
   HIPCHK(c, D.rowptr.upload(H.rowptr, c->stream));
