@@ -452,7 +452,8 @@ int v_dot(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host
 int v_norm2(cfdh_ctx *c, int n, const double *x, double *out_host);
 int v_norminf_diff(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host);  // y may be null
 int v_sub_mean(cfdh_ctx *c, int n, double *p);  // remove the (global) mean of p[0..n)
-int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror = false);
+int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror = false,
+               bool reduce_ranks = true);
 int v_scale_to(cfdh_ctx *c, int n, double a, const double *x, double *y);  // y = a x
 int v_multiaxpy(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, double *w);  // w -= sum h_i V_i
 // Gram-Schmidt update fused with the normalisation: vn = (w - sum h_i V_i) / s, s = sqrt(h[nvec] - sum h_i^2) (h[nvec] = w.w);

@@ -2070,7 +2070,7 @@ __global__ __launch_bounds__(TPB) void multidot_kernel(int n, const double *__re
 // (A "last block does the final reduction" variant was measured and dropped: the device-scope release fence every
 // block needs before taking its ticket writes the XCD's L2 back -- 133 us per launch against 17 + 4 us for two kernels.)
 // h_dev[0..nvec) = V^T w (and h_dev[nvec] = w.w when with_ww), reduced over all ranks
-int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror) {
+int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror, bool reduce_ranks) {
   const int nb = MD_NB, nout = nvec + (with_ww ? 1 : 0);
   if ((size_t)nout * nb > c->red_partial.n) return cfdh_fail(c, CFDH_E_STATE, "multidot workspace too small");
   hipLaunchKernelGGL(multidot_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, w, c->red_partial.p, nb,
@@ -2079,6 +2079,7 @@ int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const doub
   double *mir = (mirror && c->nranks <= 1) ? c->h_pinned_dev : nullptr;
   hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(nout), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, h_dev, mir);
   HIPCHK(c, hipGetLastError());
+  if (!reduce_ranks) return 0;  // the caller reduces several results over the ranks at once
   CHK(comm_allreduce_dev(c, h_dev, nout, 0));
   if (mirror && c->nranks > 1) {  // partitioned: publish the REDUCED coefficients the same way (behind the all-reduce)
     hipLaunchKernelGGL(mirror_copy_kernel, dim3(1), dim3(TPB), 0, c->stream, nout, (const double *)h_dev, c->h_pinned_dev);
