@@ -148,7 +148,9 @@ struct CellData {
   int node[NL];
 };
 
-template <int ET>
+// JAC = false: residual-only pass (trial point of the line search).  The element Jacobian is then formed only in cells whose
+// Dirichlet nodes still need lifting (F += J (g - x)) -- none once the first Newton update has put the boundary values in place.
+template <int ET, bool JAC>
 __global__ __launch_bounds__(TPB) void gen_asm_kernel(GenArgs P) {
   constexpr int NL = ET == 0 ? 3 : (ET == 1 ? 6 : 4);
   constexpr int CPB = TPB / NL;  // cells per workgroup
@@ -218,6 +220,11 @@ __global__ __launch_bounds__(TPB) void gen_asm_kernel(GenArgs P) {
   double Juu[NL][2][2], Jup[NL][2], Jpu[NL][2], Jpp[NL];
 #pragma unroll
   for (int b = 0; b < NL; b++) { Juu[b][0][0] = Juu[b][0][1] = Juu[b][1][0] = Juu[b][1][1] = 0.0; Jup[b][0] = Jup[b][1] = Jpu[b][0] = Jpu[b][1] = Jpp[b] = 0.0; }
+  bool needj = JAC;
+  if (!JAC) {
+#pragma unroll
+    for (int b = 0; b < NL; b++) needj = needj || D.lift[b][0] != 0.0 || D.lift[b][1] != 0.0 || D.lift[b][2] != 0.0;
+  }
   const GenTab &T = d_tab[ET];
   for (int q = 0; q < GEN_NQ; q++) {
     const double dv = adet * T.w[q];
@@ -252,6 +259,7 @@ __global__ __launch_bounds__(TPB) void gen_asm_kernel(GenArgs P) {
       Fa[i] += dv * v;
     }
     Fa[2] += dv * (ph[a] * divu + tau / rho * (R[0] * g[a][0] + R[1] * g[a][1]));
+    if (!needj) continue;
 #pragma unroll
     for (int b = 0; b < NL; b++) {
       const double bgb = uq[0] * g[b][0] + uq[1] * g[b][1];
@@ -801,9 +809,12 @@ int kg_assemble(cfdh_ctx *c, const double *xstate, int mode) {
   }
   const dim3 grid((c->nc + cpb - 1) / cpb), block(TPB);
   prof_begin(c, 0);
-  if (c->etype == 1) hipLaunchKernelGGL((gen_asm_kernel<1>), grid, block, 0, c->stream, P);
-  else if (c->etype == 2) hipLaunchKernelGGL((gen_asm_kernel<2>), grid, block, 0, c->stream, P);
-  else hipLaunchKernelGGL((gen_asm_kernel<0>), grid, block, 0, c->stream, P);
+#define CFDH_GEN_LAUNCH(ET) do { if (mode == 1) hipLaunchKernelGGL((gen_asm_kernel<ET, true>), grid, block, 0, c->stream, P); \
+                                 else hipLaunchKernelGGL((gen_asm_kernel<ET, false>), grid, block, 0, c->stream, P); } while (0)
+  if (c->etype == 1) CFDH_GEN_LAUNCH(1);
+  else if (c->etype == 2) CFDH_GEN_LAUNCH(2);
+  else CFDH_GEN_LAUNCH(0);
+#undef CFDH_GEN_LAUNCH
   hipLaunchKernelGGL(gen_bc_rows_kernel, dim3((c->nvo + TPB - 1) / TPB), block, 0, c->stream, c->nvo, mode, c->bcflag.p, c->bcval.p, c->bcmult.p,
                      c->vdiag.p, xstate, c->F.p, c->A00.p, c->A11.p);
   prof_end(c, 0);
