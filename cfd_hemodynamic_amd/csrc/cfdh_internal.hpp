@@ -455,6 +455,7 @@ int v_sub_mean(cfdh_ctx *c, int n, double *p);  // remove the (global) mean of p
 int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror = false,
                bool reduce_ranks = true);
 int v_scale_to(cfdh_ctx *c, int n, double a, const double *x, double *y);  // y = a x
+int v_gram(cfdh_ctx *c, int n, const double *W, int ld, int k, const double *b, double *out_dev);  // out[8 i + q] = W_q . (W_i | b), rank-local
 int v_multiaxpy(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, double *w);  // w -= sum h_i V_i
 // Gram-Schmidt update fused with the normalisation: vn = (w - sum h_i V_i) / s, s = sqrt(h[nvec] - sum h_i^2) (h[nvec] = w.w);
 // s (or sqrt(w.w) when the difference cancels) is stored in *s_dev

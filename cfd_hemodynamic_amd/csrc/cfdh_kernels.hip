@@ -2067,6 +2067,66 @@ __global__ __launch_bounds__(TPB) void multidot_kernel(int n, const double *__re
     __syncthreads();
   }
 }
+// Gram system of the projected initial guess in ONE pass over the K + 1 vectors: out slot (i, q) = W_q . W_i for i < K and
+// W_q . b for i = K, laid out as out[8 i + q] (the unused slots of the 8-wide rows are written as zeros).
+template <int K>
+__global__ __launch_bounds__(TPB) void gram_kernel(int n, const double *__restrict__ W, size_t ld, const double *__restrict__ b,
+                                                   double *__restrict__ partial, int nblk) {
+  constexpr int NP = K * (K + 1) / 2 + K;
+  __shared__ double sh[4][NP];
+  const int per = (((n + nblk - 1) / nblk) + 1) & ~1;
+  const int lo = blockIdx.x * per, hi = min(n, lo + per);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double acc[NP];
+#pragma unroll
+  for (int t = 0; t < NP; t++) acc[t] = 0.0;
+  for (int i = lo + threadIdx.x; i < hi; i += TPB) {
+    double x[K];
+#pragma unroll
+    for (int q = 0; q < K; q++) x[q] = W[(size_t)q * ld + i];
+    const double bi = b[i];
+    int t = 0;
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+#pragma unroll
+      for (int r = q; r < K; r++) acc[t++] += x[q] * x[r];
+    }
+#pragma unroll
+    for (int q = 0; q < K; q++) acc[t++] += x[q] * bi;
+  }
+#pragma unroll
+  for (int t = 0; t < NP; t++) {
+    const double r = wave_sum(acc[t]);
+    if (lane == 0) sh[wv][t] = r;
+  }
+  __syncthreads();
+  // scatter into the 8-wide slot layout (symmetric entries twice)
+  if (threadIdx.x < 8 * (K + 1)) {
+    const int i = threadIdx.x >> 3, q = threadIdx.x & 7;
+    double v = 0.0;
+    if (q < K) {
+      int t;
+      if (i < K) { const int lo_ = min(i, q), hi_ = max(i, q); t = lo_ * K - lo_ * (lo_ - 1) / 2 + (hi_ - lo_); }
+      else t = K * (K + 1) / 2 + q;
+      v = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
+    }
+    partial[(size_t)threadIdx.x * nblk + blockIdx.x] = v;
+  }
+}
+// out_dev[8 i + q] as above, NOT reduced over the ranks (the caller does that once)
+int v_gram(cfdh_ctx *c, int n, const double *W, int ld, int k, const double *b, double *out_dev) {
+  const int nb = MD_NB, nout = 8 * (k + 1);
+  if (k < 2 || k > 4 || (size_t)nout * nb > c->red_partial.n) {
+    for (int i = 0; i <= k; i++) CHK(v_multidot(c, n, W, ld, k, i < k ? W + (size_t)i * ld : b, out_dev + (size_t)i * 8, false, false, false));
+    return 0;
+  }
+  if (k == 2) hipLaunchKernelGGL((gram_kernel<2>), dim3(nb), dim3(TPB), 0, c->stream, n, W, (size_t)ld, b, c->red_partial.p, nb);
+  else if (k == 3) hipLaunchKernelGGL((gram_kernel<3>), dim3(nb), dim3(TPB), 0, c->stream, n, W, (size_t)ld, b, c->red_partial.p, nb);
+  else hipLaunchKernelGGL((gram_kernel<4>), dim3(nb), dim3(TPB), 0, c->stream, n, W, (size_t)ld, b, c->red_partial.p, nb);
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(nout), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, out_dev, (double *)nullptr);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 // (A "last block does the final reduction" variant was measured and dropped: the device-scope release fence every
 // block needs before taking its ticket writes the XCD's L2 back -- 133 us per launch against 17 + 4 us for two kernels.)
 // h_dev[0..nvec) = V^T w (and h_dev[nvec] = w.w when with_ww), reduced over all ranks

@@ -714,8 +714,7 @@ static int guess_project(cfdh_ctx *c, const double *b, double *x, bool *used) {
   // Gram matrix G = W^T W (column by column) and g = W^T b
   std::vector<double> G((size_t)k * k), g(k), y(k, 0.0);
   HIPCHK(c, hipMemsetAsync(hd, 0, sizeof(double) * 8 * (size_t)(k + 1), c->stream));
-  for (int i = 0; i <= k; i++)  // k + 1 multi-dots into consecutive slots of the scalar scratch, ONE read-back
-    CHK(v_multidot(c, n, Z, (int)ld, k, i < k ? Z + (size_t)i * ld : b, hd + (size_t)i * 8, false, false, false));
+  CHK(v_gram(c, n, Z, (int)ld, k, b, hd));  // one pass over W and b, ONE read-back
   CHK(comm_allreduce_dev(c, hd, 8 * (k + 1), 0));  // ONE reduction over the ranks for the whole Gram system
   HIPCHK(c, hipMemcpyAsync(c->h_pinned, hd, sizeof(double) * 8 * (size_t)(k + 1), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
