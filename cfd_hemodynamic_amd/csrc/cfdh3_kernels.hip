@@ -553,6 +553,60 @@ __global__ __launch_bounds__(TPB) void spmv3_full_kernel(int nv, const int *__re
     y[3 * (size_t)nv + row] = a3;
   }
 }
+// NV vectors at once (leading dimension ld): one pass over the 4 x 4 blocks (projected initial guess, cfdh_solver.cpp)
+template <int NV>
+__global__ __launch_bounds__(TPB) void spmv3_full_multi_kernel(int nv, const int *__restrict__ vptr, const int *__restrict__ vcol,
+                                                               const double *__restrict__ A00, const double *__restrict__ A01,
+                                                               const double *__restrict__ A10, const double *__restrict__ A11,
+                                                               const double *__restrict__ X, double *__restrict__ Y, size_t ld) {
+  const int gid = blockIdx.x * TPB + threadIdx.x;
+  const int row = gid >> 3, l = gid & 7;
+  double a[NV][4];
+#pragma unroll
+  for (int v = 0; v < NV; v++) a[v][0] = a[v][1] = a[v][2] = a[v][3] = 0.0;
+  if (row < nv) {
+    for (int k = vptr[row] + l, ke = vptr[row + 1]; k < ke; k += 8) {
+      const int w = vcol[k];
+      const size_t uo = uo3(w, nv), po = po3(w, nv);
+      const double *b = A00 + 9 * (size_t)k, *c01 = A01 + 3 * (size_t)k, *c10 = A10 + 3 * (size_t)k;
+      double m[16];
+#pragma unroll
+      for (int t = 0; t < 9; t++) m[t] = b[t];
+      m[9] = c01[0]; m[10] = c01[1]; m[11] = c01[2]; m[12] = c10[0]; m[13] = c10[1]; m[14] = c10[2]; m[15] = A11[k];
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        const double *x = X + (size_t)v * ld;
+        const double x0 = x[uo], x1 = x[uo + 1], x2 = x[uo + 2], xp = x[po];
+        a[v][0] += m[0] * x0 + m[1] * x1 + m[2] * x2 + m[9] * xp;
+        a[v][1] += m[3] * x0 + m[4] * x1 + m[5] * x2 + m[10] * xp;
+        a[v][2] += m[6] * x0 + m[7] * x1 + m[8] * x2 + m[11] * xp;
+        a[v][3] += m[12] * x0 + m[13] * x1 + m[14] * x2 + m[15] * xp;
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    const double s0 = g8sum(a[v][0]), s1 = g8sum(a[v][1]), s2 = g8sum(a[v][2]), s3 = g8sum(a[v][3]);
+    if (row < nv && l == 0) {
+      double *y = Y + (size_t)v * ld;
+      y[3 * (size_t)row] = s0; y[3 * (size_t)row + 1] = s1; y[3 * (size_t)row + 2] = s2;
+      y[3 * (size_t)nv + row] = s3;
+    }
+  }
+}
+int k3_spmv_full_multi(cfdh_ctx *c, const double *X, double *Y, int ld, int nvec) {
+  if (nvec < 2 || nvec > 4) {
+    for (int v = 0; v < nvec; v++) CHK(k3_spmv_full(c, X + (size_t)v * ld, Y + (size_t)v * ld));
+    return 0;
+  }
+  const dim3 gr((unsigned)((8ll * c->nvo + TPB - 1) / TPB)), bl(TPB);
+#define CFDH_SPMM3(NV) hipLaunchKernelGGL((spmv3_full_multi_kernel<NV>), gr, bl, 0, c->stream, c->nvo, c->vptr.p, c->vcol.p, c->A00.p, \
+                                          c->A01.p, c->A10.p, c->A11.p, X, Y, (size_t)ld)
+  if (nvec == 2) CFDH_SPMM3(2); else if (nvec == 3) CFDH_SPMM3(3); else CFDH_SPMM3(4);
+#undef CFDH_SPMM3
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 int k3_spmv_full(cfdh_ctx *c, const double *x, double *y) {
   prof_begin(c, 1);
   hipLaunchKernelGGL(spmv3_full_kernel, dim3((unsigned)((8ll * c->nvo + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, c->nvo, c->vptr.p, c->vcol.p,

@@ -395,6 +395,7 @@ int k3_upload_quadrature(cfdh_ctx *c);
 int k3_moments(cfdh_ctx *c);
 int k3_assemble(cfdh_ctx *c, const double *xstate, int mode);
 int k3_spmv_full(cfdh_ctx *c, const double *x, double *y);
+int k3_spmv_full_multi(cfdh_ctx *c, const double *X, double *Y, int ld, int nvec);
 int k3_spmv_block(cfdh_ctx *c, int blk, const double *x, double *y, const double *b);
 int k3_spmv_block_ghost(cfdh_ctx *c, int blk, const double *xv, double *y, const double *b);  // xv: full vector with refreshed ghost tail  // 2: b - A01 x_p ; 3: b - A10 x_u (b may be null)
 int k3_nullspace_test(cfdh_ctx *c, double *nrm, double *absnrm);

@@ -745,7 +745,8 @@ __global__ __launch_bounds__(TPB) void spmv_full_multi_kernel(int nvo, const int
 
 // Y_v = J X_v for v < nvec (vectors ld apart; ghost tails of X filled by the caller)
 int k_spmv_full_multi(cfdh_ctx *c, const double *X, double *Y, int ld, int nvec) {
-  if (c->dim == 3 || nvec < 2 || nvec > 4) {
+  if (c->dim == 3) return k3_spmv_full_multi(c, X, Y, ld, nvec);
+  if (nvec < 2 || nvec > 4) {
     for (int v = 0; v < nvec; v++) CHK(k_spmv_full(c, X + (size_t)v * ld, Y + (size_t)v * ld));
     return 0;
   }
