@@ -263,6 +263,9 @@ struct cfdh_ctx {
   long long n_guess_solves = 0;
   double guess_reduction_sum = 0.0;  // sum of |r0| / |b| over the solves that started from a projected guess
   dbuf<double> kV, kZ, kw, kh;  // V[(m+1)*NL], Z[m*NL], w[NL], h[2*(m+1)+2]
+  dbuf<float> kV32;             // fp32 copy of V for the Gram-Schmidt passes of long cycles (allocated on first use)
+  bool krylov_fp32_ok = true;   // cleared when the orthogonality watchdog trips on a cycle that used the copy
+  int guess_last_its[4] = {0, 0, 0, 0};  // iterations of the last solve per Newton index (expected length of the next)
   dbuf<double> ky;
 
   // preconditioner
@@ -456,6 +459,10 @@ int v_sub_mean(cfdh_ctx *c, int n, double *p);  // remove the (global) mean of p
 int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror = false,
                bool reduce_ranks = true);
 int v_scale_to(cfdh_ctx *c, int n, double a, const double *x, double *y);  // y = a x
+int v_multidot32(cfdh_ctx *c, int n, const float *V, int ld, int nvec, const double *w, double *h_dev);  // fp32 copy of the basis
+int v_gs_update32(cfdh_ctx *c, int n, const float *V, int ld, int nvec, const double *h_dev, const double *w, double *vn, float *v32n,
+                  double *s_dev, int mirror_slot);
+int v_store32(cfdh_ctx *c, int n, const double *v, float *v32);
 int v_gram(cfdh_ctx *c, int n, const double *W, int ld, int k, const double *b, double *out_dev);  // out[8 i + q] = W_q . (W_i | b), rank-local
 int v_multiaxpy(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, double *w);  // w -= sum h_i V_i
 // Gram-Schmidt update fused with the normalisation: vn = (w - sum h_i V_i) / s, s = sqrt(h[nvec] - sum h_i^2) (h[nvec] = w.w);

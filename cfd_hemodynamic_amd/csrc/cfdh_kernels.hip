@@ -2212,6 +2212,131 @@ int v_gs_update_normalize(cfdh_ctx *c, int n, const double *V, int ld, int nvec,
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+__global__ void sqrt_kernel(double *s);
+// ---- Gram-Schmidt against an fp32 COPY of the basis (long Krylov cycles: the two passes over V are 40 % of an iteration at
+// depth 25; the fp64 vectors stay where the preconditioner reads them).  The norm of the new vector is measured, not inferred
+// from w.w - |h|^2 (that identity needs an orthonormal basis to round-off, which rounded columns are not).
+__global__ __launch_bounds__(TPB) void multidot32_kernel(int n, const float *__restrict__ V, size_t ld, int nvec,
+                                                         const double *__restrict__ w, double *__restrict__ partial, int nblk) {
+  __shared__ double sh[4][MD_G + 1];
+  const int per = (((n + nblk - 1) / nblk) + 3) & ~3;  // chunks of whole float4 / 2 x double2 groups
+  const int lo = blockIdx.x * per, hi = min(n, lo + per);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int hi4 = hi > lo ? lo + ((hi - lo) & ~3) : hi;
+  for (int g0 = 0; g0 < nvec; g0 += MD_G) {
+    const float *ptr[MD_G];
+    double acc[MD_G], aww = 0.0;
+#pragma unroll
+    for (int q = 0; q < MD_G; q++) { ptr[q] = V + (size_t)min(g0 + q, nvec - 1) * ld; acc[q] = 0.0; }  // past the end: a dummy, discarded
+    // four consecutive entries per lane: one 16-B load per fp32 column, two for w
+    for (int i = lo + 4 * threadIdx.x; i < hi4; i += 4 * TPB) {
+      const double2 w0 = *(const double2 *)(w + i), w1 = *(const double2 *)(w + i + 2);
+      if (g0 == 0) aww += (w0.x * w0.x + w0.y * w0.y) + (w1.x * w1.x + w1.y * w1.y);
+#pragma unroll
+      for (int q = 0; q < MD_G; q++) {
+        const float4 vi = *(const float4 *)(ptr[q] + i);
+        acc[q] += ((double)vi.x * w0.x + (double)vi.y * w0.y) + ((double)vi.z * w1.x + (double)vi.w * w1.y);
+      }
+    }
+    if (threadIdx.x == 0)
+      for (int i = hi4; i < hi; i++) {
+        const double wi = w[i];
+        if (g0 == 0) aww += wi * wi;
+#pragma unroll
+        for (int q = 0; q < MD_G; q++) acc[q] += (double)ptr[q][i] * wi;
+      }
+#pragma unroll
+    for (int q = 0; q < MD_G; q++) {
+      const double r = wave_sum(acc[q]);
+      if (lane == 0) sh[wv][q] = r;
+    }
+    if (g0 == 0) { const double r = wave_sum(aww); if (lane == 0) sh[wv][MD_G] = r; }
+    __syncthreads();
+    if (threadIdx.x < MD_G && g0 + (int)threadIdx.x < nvec)
+      partial[(size_t)(g0 + threadIdx.x) * nblk + blockIdx.x] =
+          (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (g0 == 0 && threadIdx.x == MD_G)
+      partial[(size_t)nvec * nblk + blockIdx.x] = (sh[0][MD_G] + sh[1][MD_G]) + (sh[2][MD_G] + sh[3][MD_G]);
+    __syncthreads();
+  }
+}
+// h_dev[0..nvec) = V32^T w, h_dev[nvec] = w.w (reduced over the ranks, mirrored like v_multidot)
+int v_multidot32(cfdh_ctx *c, int n, const float *V, int ld, int nvec, const double *w, double *h_dev) {
+  const int nb = MD_NB, nout = nvec + 1;
+  if ((size_t)nout * nb > c->red_partial.n) return cfdh_fail(c, CFDH_E_STATE, "multidot workspace too small");
+  hipLaunchKernelGGL(multidot32_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, w, c->red_partial.p, nb);
+  double *mir = c->nranks <= 1 ? c->h_pinned_dev : nullptr;
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(nout), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, h_dev, mir);
+  HIPCHK(c, hipGetLastError());
+  CHK(comm_allreduce_dev(c, h_dev, nout, 0));
+  if (c->nranks > 1) {
+    hipLaunchKernelGGL(mirror_copy_kernel, dim3(1), dim3(TPB), 0, c->stream, nout, (const double *)h_dev, c->h_pinned_dev);
+    HIPCHK(c, hipGetLastError());
+  }
+  return 0;
+}
+// vn = w - V32 h (not normalised) and the block partials of |vn|^2
+__global__ __launch_bounds__(TPB) void gs_update32_kernel(int n, const float *__restrict__ V, size_t ld, int nvec, const double *__restrict__ h,
+                                                          const double *__restrict__ w, double *__restrict__ vn, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double ss = 0.0;
+  const int n2 = n & ~1;
+  for (int i = 2 * (blockIdx.x * TPB + threadIdx.x); i < n2; i += 2 * gridDim.x * TPB) {
+    const double2 wi = *(const double2 *)(w + i);
+    double a0 = wi.x, a1 = 0.0, b0 = wi.y, b1 = 0.0;
+    int v = 0;
+    for (; v + 2 <= nvec; v += 2) {
+      const float2 x0 = *(const float2 *)(V + (size_t)v * ld + i), x1 = *(const float2 *)(V + (size_t)(v + 1) * ld + i);
+      a0 -= h[v] * (double)x0.x; a1 -= h[v + 1] * (double)x1.x;
+      b0 -= h[v] * (double)x0.y; b1 -= h[v + 1] * (double)x1.y;
+    }
+    for (; v < nvec; v++) { const float2 xv = *(const float2 *)(V + (size_t)v * ld + i); a0 -= h[v] * (double)xv.x; b0 -= h[v] * (double)xv.y; }
+    const double r0 = a0 + a1, r1 = b0 + b1;
+    *(double2 *)(vn + i) = make_double2(r0, r1);
+    ss += r0 * r0 + r1 * r1;
+  }
+  if (n2 < n && blockIdx.x == 0 && threadIdx.x == 0) {
+    double a0 = w[n2];
+    for (int v = 0; v < nvec; v++) a0 -= h[v] * (double)V[(size_t)v * ld + n2];
+    vn[n2] = a0;
+    ss += a0 * a0;
+  }
+  ss = block_sum(ss, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = ss;
+}
+// vn /= s (s on the device) and its fp32 copy
+__global__ __launch_bounds__(TPB) void scale_store32_kernel(int n, double *__restrict__ vn, const double *__restrict__ s, float *__restrict__ v32) {
+  const double inv = s[0] > 0.0 ? 1.0 / s[0] : 0.0;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) { const double x = vn[i] * inv; vn[i] = x; v32[i] = (float)x; }
+}
+__global__ __launch_bounds__(TPB) void store32_kernel(int n, const double *__restrict__ v, float *__restrict__ v32) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) v32[i] = (float)v[i];
+}
+int v_store32(cfdh_ctx *c, int n, const double *v, float *v32) {
+  hipLaunchKernelGGL(store32_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, v, v32);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+// vn = (w - V32 h) / |w - V32 h| with its fp32 copy in v32n; s_dev[0] = that norm (reduced over the ranks), mirrored to
+// h_pinned[mirror_slot] for the host
+int v_gs_update32(cfdh_ctx *c, int n, const float *V, int ld, int nvec, const double *h_dev, const double *w, double *vn, float *v32n,
+                  double *s_dev, int mirror_slot) {
+  const int nb = vgrid(n) > c->red_blocks ? c->red_blocks : vgrid(n);
+  double *part = c->red_partial.p + (size_t)(MD_NB) * 8;  // behind the first multi-dot groups (the stream serialises the users)
+  hipLaunchKernelGGL(gs_update32_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, h_dev, w, vn, part);
+  if (c->nranks <= 1) {  // square root and host-mapped copy in the reduction kernel itself
+    hipLaunchKernelGGL(reduce_final_kernel<2>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, part, s_dev, c->h_pinned_dev + mirror_slot);
+  } else {
+    hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, part, s_dev, (double *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    CHK(comm_allreduce_dev(c, s_dev, 1, 0));
+    hipLaunchKernelGGL(sqrt_kernel, dim3(1), dim3(1), 0, c->stream, s_dev);
+    hipLaunchKernelGGL(mirror_copy_kernel, dim3(1), dim3(TPB), 0, c->stream, 1, (const double *)s_dev, c->h_pinned_dev + mirror_slot);
+  }
+  hipLaunchKernelGGL(scale_store32_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, vn, (const double *)s_dev, v32n);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 int v_lincomb(cfdh_ctx *c, int n, const double *Z, int ld, int nvec, const double *y_dev, double *x) {
   hipLaunchKernelGGL(multiaxpy_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, Z, (size_t)ld, nvec, y_dev, x, 1.0);
   HIPCHK(c, hipGetLastError());

@@ -833,6 +833,21 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
   bool guessed = false;
   CHK(guess_project(c, b, x, &guessed));
   if (guessed) first = false;  // the cycle starts from the true residual of x0, as after a restart
+  // Long cycles at the default tolerance orthogonalise against an fp32 COPY of the basis (half the traffic of the two passes over
+  // V, which are ~40 % of an iteration at depth 25).  Chosen per solve from the length of the last solve with the same Newton
+  // index; never for tolerances below 1e-6 (parity runs), never again on a context whose watchdog tripped with the copy in use.
+  // CFDH_KRYLOV_FP32 = 0: never, 2: always (where the tolerance allows).
+  const int fp32_env = getenv("CFDH_KRYLOV_FP32") ? atoi(getenv("CFDH_KRYLOV_FP32")) : 1;
+  const int gslot = c->guess_slot;
+  const bool expect_long = gslot >= 0 && gslot < cfdh_ctx::GUESS_NEWTON && c->guess_last_its[gslot] >= 20;
+  bool use32 = fp32_env > 0 && o.ksp_rtol >= 1e-6 && c->krylov_fp32_ok && (expect_long || fp32_env >= 2);
+  float *V32 = nullptr;
+  const size_t ld32 = (ld + 3) & ~(size_t)3;  // columns of the copy start on 16-B boundaries (float4 loads)
+  if (use32) {
+    if (c->kV32.n < ld32 * (size_t)(m + 1)) HIPCHK(c, c->kV32.alloc(ld32 * (size_t)(m + 1)));
+    V32 = c->kV32.p;
+  }
+  double last_true = -1.0;  // true residual at the last disagreement between recurrence and true residual
   double est_prev = 0.0, beta_start = bn;  // residual estimate at the end / true residual at the start of the last cycle
   int j_prev = 0;
   for (;;) {
@@ -863,7 +878,11 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       // the recurrence then reports convergence while the true residual, formed here after every cycle anyway, does not
       // follow.  Once that is seen on a context, long cycles are re-orthogonalised (DGKS) from then on, and a cycle that
       // made the residual worse is taken back.
-      if (!c->gs_refine_long && j_prev > 0 && beta > 10.0 * std::max(est_prev, tol)) {
+      if (use32 && j_prev > 0 && beta > 10.0 * std::max(est_prev, tol)) {
+        // the fp32 copy is the first suspect: this solve and all later ones of the context go back to the fp64 basis
+        use32 = false; c->krylov_fp32_ok = false;
+        if (o.verbose) fprintf(stderr, "[cfdh]     fgmres: true residual %.3e vs recurrence %.3e after a %d-vector cycle with the fp32 basis copy: switched off\n", beta, est_prev, j_prev);
+      } else if (!c->gs_refine_long && j_prev > 0 && beta > 10.0 * std::max(est_prev, tol)) {
         c->gs_refine_long = true;
         if (o.verbose) fprintf(stderr, "[cfdh]     fgmres: true residual %.3e vs recurrence %.3e after a %d-vector cycle: re-orthogonalising long cycles from now on\n", beta, est_prev, j_prev);
         if (beta > beta_start && j_prev > 0) {
@@ -875,6 +894,19 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
           continue;
         }
       }
+      // Attainable accuracy.  The convergence test of a cycle is the recurrence norm (as in PETSc, which never looks further);
+      // here the true residual is formed after every cycle and another cycle follows if it disagrees.  When a second cycle
+      // in a row ends "converged" by the recurrence without halving the true residual, that residual is the floor of this
+      // system (rounding level of J x, or the component of b outside the range of a singular Jacobian: lid cavity at
+      // ksp_rtol 1e-10) and the iteration stops instead of spending ksp_max_it on it.
+      if (j_prev > 0 && est_prev <= tol && beta > tol) {
+        if (last_true > 0.0 && beta > 0.5 * last_true) {
+          if (o.verbose) fprintf(stderr, "[cfdh]     fgmres: true residual %.3e stays above the tolerance %.3e although the recurrence converged twice: attainable accuracy, stopping\n", beta, tol);
+          reason = 2;
+          break;
+        }
+        last_true = beta;
+      }
       beta_start = beta;
     }
     if (beta <= tol) { reason = 2; break; }
@@ -882,6 +914,7 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
     if (!std::isfinite(beta)) { reason = -9; break; }
     if (first) CHK(v_scale_to(c, n, 1.0 / beta, b, V));
     else CHK(v_scale(c, n, 1.0 / beta, V));
+    if (use32) CHK(v_store32(c, n, V, V32));
     first = false;
     std::fill(g.begin(), g.end(), 0.0);
     g[0] = beta;
@@ -895,19 +928,29 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       // classical Gram-Schmidt (PETSc's default for (F)GMRES) with one re-orthogonalisation
       // pass only when cancellation demands it (|w'|^2 < 1e-5 |w|^2, judged from
       // |w'|^2 = |w|^2 - |h|^2): h = [V^T w ; w.w] comes from ONE fused multi-dot
-      CHK(v_multidot(c, n, V, (int)ld, j + 1, w, hd, true, true));
-      // h (all-reduced in a partitioned run) sits in the host-mapped scratch: wait for THAT only, the update of w
-      // below overlaps with the host's Hessenberg bookkeeping and the next launches
-      HIPCHK(c, hipEventRecord(c->ev_h, c->stream));
-      // v_{j+1} = (w - V h) / s with s = sqrt(w.w - |h|^2) formed on the device from the reduced coefficients: update and
-      // normalisation in one pass (the host forms the same norm for the Hessenberg matrix from its copy of h)
       double *s_dev = hd + 2 * (m + 2) + 1;
-      CHK(v_gs_update_normalize(c, n, V, (int)ld, j + 1, hd, w, vn, s_dev));
+      const int s_slot = m + 8;  // host-mapped slot of the measured norm (fp32 copy in use)
+      if (use32) {
+        // the same Gram-Schmidt step against the fp32 copy: h = V32^T w, v_{j+1} = (w - V32 h) / |w - V32 h| with the norm
+        // MEASURED (the identity below needs columns that are orthonormal to round-off); both the fp64 vector (input of the
+        // next preconditioner application) and its fp32 copy are written
+        CHK(v_multidot32(c, n, V32, (int)ld32, j + 1, w, hd));
+        CHK(v_gs_update32(c, n, V32, (int)ld32, j + 1, hd, w, vn, V32 + (size_t)(j + 1) * ld32, s_dev, s_slot));
+        HIPCHK(c, hipEventRecord(c->ev_h, c->stream));
+      } else {
+        CHK(v_multidot(c, n, V, (int)ld, j + 1, w, hd, true, true));
+        // h (all-reduced in a partitioned run) sits in the host-mapped scratch: wait for THAT only, the update of w
+        // below overlaps with the host's Hessenberg bookkeeping and the next launches
+        HIPCHK(c, hipEventRecord(c->ev_h, c->stream));
+        // v_{j+1} = (w - V h) / s with s = sqrt(w.w - |h|^2) formed on the device from the reduced coefficients: update and
+        // normalisation in one pass (the host forms the same norm for the Hessenberg matrix from its copy of h)
+        CHK(v_gs_update_normalize(c, n, V, (int)ld, j + 1, hd, w, vn, s_dev));
+      }
       c->n_host_sync++;
       HIPCHK(c, hipEventSynchronize(c->ev_h));
       double ww = c->h_pinned[j + 1], hh2 = 0.0;
       for (int i = 0; i <= j; i++) { hh[i] = c->h_pinned[i]; hh2 += hh[i] * hh[i]; }
-      double nrm2 = ww - hh2;
+      double nrm2 = use32 ? c->h_pinned[s_slot] * c->h_pinned[s_slot] : ww - hh2;
       // PETSc's default never refines.  Here: tolerances down to ~1e-7 refine only when two digits
       // cancel; tighter solves (parity runs at 1e-10) use the DGKS criterion (|w'| < |w|/sqrt(2)),
       // because classical Gram-Schmidt then loses the orthogonality the deep convergence needs
@@ -933,6 +976,7 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
         for (int i = 0; i <= j; i++) hh[i] += s * c->h_pinned[i];
         hnorm = s * c->h_pinned[m + 2];
         CHK(v_scale_inv_dev(c, n, vn, hd + 2 * (m + 2), vn));
+        if (use32) CHK(v_store32(c, n, vn, V32 + (size_t)(j + 1) * ld32));
       } else {
         hnorm = std::sqrt(nrm2);
       }
@@ -970,6 +1014,7 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
   c->n_krylov += its;
   *its_out = its;
   *reason_out = reason;
+  if (gslot >= 0 && gslot < cfdh_ctx::GUESS_NEWTON) c->guess_last_its[gslot] = its;
   if (reason > 0) CHK(guess_store(c, x));
   return 0;
 }

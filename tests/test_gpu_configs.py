@@ -192,3 +192,28 @@ def test_projected_initial_guess_changes_iteration_counts_not_results(monkeypatc
     assert np.linalg.norm(x4[: 2 * nv] - x0[: 2 * nv]) <= 1e-8 * np.linalg.norm(x0[: 2 * nv])
     assert np.linalg.norm(x4[2 * nv:] - x0[2 * nv:]) <= 1e-7 * np.linalg.norm(x0[2 * nv:])
     assert abs(d4 - d0) <= 1e-8 * abs(d0) and abs(l4 - l0) <= 1e-6 * abs(l0) + 1e-12
+
+
+def test_fp32_copy_of_the_krylov_basis_for_long_cycles(monkeypatch):
+    """Long FGMRES cycles at the default tolerance run their Gram-Schmidt passes against an fp32 copy of the basis (measured norm
+    of the new vector, fp64 vectors for the preconditioner): same iteration counts within a few per cent and the same solution at
+    the solver-noise level as with the fp64 basis; tight tolerances never use the copy."""
+    from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
+    runs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("CFDH_KRYLOV_FP32", mode)
+        sc = StenosisSimulation("stabilized_schur", 0.01, 1.0, grade="moderate", ny=40, v_max=100.0, quiet=True, options=dict(ksp_guess=0))
+        its = []
+        for _ in range(5):
+            sc.solver.solveStep()
+            sc.solver.advance()
+            assert sc.solver.last_stats.reason > 0
+            its.append(sc.solver.last_stats.krylov_its)
+        runs[mode] = (np.asarray(sc.solver.u_sol.x.array).copy(), np.asarray(sc.solver.p_sol.x.array).copy(), its,
+                      sc.solver.functional(2), sc.solver.functional(3))
+    u0, p0, its0, nu0, np0 = runs["0"]
+    u2, p2, its2, nu2, np2 = runs["2"]
+    assert max(its0) >= 40                                   # cycles long enough to matter
+    assert abs(sum(its2) - sum(its0)) <= 0.1 * sum(its0)
+    assert np.linalg.norm(u2 - u0) <= 1e-5 * np.linalg.norm(u0) and np.linalg.norm(p2 - p0) <= 1e-4 * np.linalg.norm(p0)
+    assert abs(nu2 - nu0) <= 1e-6 * nu0 and abs(np2 - np0) <= 1e-5 * np0
