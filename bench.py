@@ -432,7 +432,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f64 (fp32 only where it cannot reach the result: AMG matrix values inside the flexible preconditioner; the read-only copy of the Krylov basis the Gram-Schmidt passes of >= 20-iteration solves use -- basis, iterate, Jacobian, residuals and convergence tests are f64)",
+        "dtype": "f64 (fp32 only in the AMG matrix values of the flexible preconditioner and in a read-only copy of the Krylov basis that Gram-Schmidt reads in solves of >= 20 iterations)",
         "data": "synthetic",
         "config": {"workload": workload_text(args, sc),
                    "parallelism": "element partition x%d (RCB), halo + dot all-reduce on %s; communicator size %d" % (
