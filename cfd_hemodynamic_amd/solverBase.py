@@ -117,9 +117,36 @@ class SolverBase(ABC):
         np.add.at(out, fv[:, 1], 0.5 * Tt)
 
     @staticmethod
+    def _simplex_gradients(mesh):
+        """grad(lambda_a) of every cell of a P1 simplex mesh, [nc, d + 1, d]."""
+        X = np.asarray(mesh.x)[np.asarray(mesh.cells)]
+        d = X.shape[2]
+        if X.shape[1] != d + 1:
+            raise NotImplementedError("epsilon / sigma: cell-wise values exist for P1 simplices (constant gradients) only")
+        M = X[:, 1:, :] - X[:, :1, :]                     # rows x_a - x_0
+        Minv = np.linalg.inv(M)                           # columns = grad(lambda_a), a >= 1
+        g = np.empty((len(X), d + 1, d))
+        g[:, 1:, :] = np.transpose(Minv, (0, 2, 1))
+        g[:, 0, :] = -g[:, 1:, :].sum(axis=1)
+        return g
+
+    @staticmethod
     def epsilon(u):
-        raise NotImplementedError("symbolic forms are not part of the GPU path; see csrc/cfdh_kernels.hip")
+        """`sym(nabla_grad(u))` of solverBase.py:176-178, evaluated: the reference returns the UFL expression, this mirror has no
+        form language, so it returns what the expression IS on a P1 field -- one symmetric d x d matrix per cell, [nc, d, d]
+        (`nabla_grad(u)[i, j] = d_i u_j`)."""
+        mesh = u.function_space.mesh
+        g = SolverBase._simplex_gradients(mesh)
+        uv = np.asarray(u.x.array, dtype=float).reshape(-1, u.function_space.bs)[np.asarray(mesh.cells)]
+        G = np.einsum("cai,caj->cij", g, uv)
+        return 0.5 * (G + np.transpose(G, (0, 2, 1)))
 
     @staticmethod
     def sigma(u, p, mu):
-        raise NotImplementedError("symbolic forms are not part of the GPU path; see csrc/cfdh_kernels.hip")
+        """`2 mu sym(nabla_grad(u)) - p I` of solverBase.py:180-182 per cell, [nc, d, d]; p enters with its cell mean (the value of
+        a P1 field at the centroid)."""
+        E = SolverBase.epsilon(u)
+        mesh = u.function_space.mesh
+        pc = np.asarray(p.x.array, dtype=float)[np.asarray(mesh.cells)].mean(axis=1)
+        d = E.shape[1]
+        return 2.0 * float(mu) * E - pc[:, None, None] * np.eye(d)[None, :, :]

@@ -177,3 +177,24 @@ def test_dfg_scenario_from_msh_file(oracle_backend, tmp_path):
     assert np.array_equal(a.mesh.cells, b.mesh.cells) and np.array_equal(a.mesh.facet_marker, b.mesh.facet_marker)
     assert np.allclose(a.solver.u_sol.x.array, b.solver.u_sol.x.array, rtol=0, atol=1e-10)
     assert abs(a.drag - b.drag) < 1e-8 and abs(a.lift - b.lift) < 1e-8 and abs(a.p_diff - b.p_diff) < 1e-8
+
+
+def test_epsilon_and_sigma_of_solver_base():
+    """solverBase.py:176-182 `epsilon(u) = sym(nabla_grad(u))`, `sigma(u, p, mu) = 2 mu epsilon(u) - p I`: the mirror evaluates them
+    per cell of a P1 field (exact for fields that are linear in x), in 2-D and on tetrahedra."""
+    from cfd_hemodynamic_amd.mesh3d import create_unit_cube
+    from cfd_hemodynamic_amd.solverBase import SolverBase
+    A2 = np.array([[0.3, -1.2], [0.7, 0.5]])   # u_j = sum_i x_i A[i, j]  =>  nabla_grad(u) = A
+    A3 = np.array([[0.3, -1.2, 0.4], [0.7, 0.5, -0.1], [0.2, 0.9, 1.1]])
+    for mesh, A in ((create_unit_square(5), A2), (create_unit_cube(3), A3)):
+        d = A.shape[0]
+        V, Q = FunctionSpace(mesh, d), FunctionSpace(mesh, 1)
+        u, p = Function(V), Function(Q)
+        u.x.array[:] = (np.asarray(mesh.x) @ A).ravel()
+        p.x.array[:] = 2.0 + np.asarray(mesh.x)[:, 0]
+        E = SolverBase.epsilon(u)
+        assert E.shape == (len(mesh.cells), d, d)
+        assert np.abs(E - 0.5 * (A + A.T)[None]).max() <= 1e-12
+        S = SolverBase.sigma(u, p, 0.04)
+        pc = 2.0 + np.asarray(mesh.x)[np.asarray(mesh.cells)][:, :, 0].mean(axis=1)
+        assert np.abs(S - (0.04 * (A + A.T)[None] - pc[:, None, None] * np.eye(d)[None])).max() <= 1e-12
