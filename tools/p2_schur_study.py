@@ -267,6 +267,14 @@ def study(kind, m, pb, J, F, outn):
 
     b = -F
     res = {}
+    # PSPG cancellation carried explicitly: A11' = A11 - C diag(A00)^-1 A01, C = A10 + A01^T (the stabilisation part of A10)
+    Cst = (A10 + A01.T).tocsr()
+    for dname, Dinv in (("diag(A00)", sp.diags(1.0 / A00.diagonal())), ("0.25 diag(A00)", sp.diags(0.25 / A00.diagonal())),
+                        ("0.5 diag(A00)", sp.diags(0.5 / A00.diagonal())), ("0.1 diag(A00)", sp.diags(0.1 / A00.diagonal()))):
+        A11c = (A11 - Cst @ Dinv @ A01).tocsc()
+        for kt in (1.0,):
+            Hk = (sp.diags((1.0 + kt * a_ * T_) * Ml_scaled) + b_ * A11c).tocsc()
+            res["CC exact, H'' = (1 + %g a'T) M + b' (A11 - C %s^-1 A01)" % (kt, dname)] = gmres_right(J, b, variant(spl.splu(Hk).solve, linv, A00s.solve))
     if kind == "P2":
         nvert_ = Pc_full.shape[1]
         Rinj = sp.csr_matrix((np.ones(nvert_), (np.arange(nvert_), np.arange(nvert_))), shape=(nvert_, nv))
