@@ -101,6 +101,9 @@ typedef struct orc_ctx {
   int hL_singular;
   int nthreads;
   char err[256];
+  /* projected initial guess (orc_opts.ksp_guess): per Newton index the kept corrections [gm vectors] and this step's iterate */
+  double *gU[4], *gX[4];
+  int gcnt[4], ghead[4], gm, gstored[4];
 } orc_ctx;
 
 typedef struct {
@@ -125,6 +128,8 @@ typedef struct {
   int amg_max_coarse;
   int cc_smooth_degree; /* pc_kind 2: Chebyshev steps on H */
   int schur_upper; /* pc_kind 2: block upper-triangular factor (z_p = S^-1 r_p; z_u = A^-1 (r_u - A01 z_p)), the GPU default */
+  int ksp_guess;   /* > 0: projected initial guess of the linear solves from the corrections of the last ksp_guess steps (the CPU
+                    * port of cfdh_options.ksp_guess, csrc/cfdh_solver.cpp::guess_project); 0 (default): zero guess, as the reference's KSP */
 } orc_opts;
 
 typedef struct {
@@ -456,6 +461,7 @@ void orc_destroy(orc_ctx *c) {
   free(c->vptr); free(c->vadj); free(c->rowptr); free(c->col); free(c->val); free(c->cellpos);
   free_csr(&c->A00f); free_csr(&c->Sp); free(c->sp_rowptr); free(c->sp_col);
   amg_free(c); free(c->dinvA);
+  for (int k = 0; k < 4; k++) { free(c->gU[k]); free(c->gX[k]); }
   free(c);
 }
 
@@ -1396,7 +1402,58 @@ static void remove_pmean(const orc_ctx *c, double *v) {
 }
 
 /* outer FGMRES (right preconditioned, true-residual norm test against |b|, x0 = 0) */
-static int fgmres(orc_ctx *c, const orc_opts *o, pc_ws *pc, const double *b, double *x, int singular, int *its_out) {
+static void guess_ensure(orc_ctx *c, const orc_opts *o) {
+  const int n = c->ndof, m = o->ksp_guess > 8 ? 8 : o->ksp_guess;
+  if (m <= 0 || c->gm == m) return;
+  for (int k = 0; k < 4; k++) {
+    free(c->gU[k]); free(c->gX[k]);
+    c->gU[k] = (double *)calloc((size_t)n * m, sizeof(double)); c->gX[k] = (double *)calloc(n, sizeof(double));
+    c->gcnt[k] = c->ghead[k] = c->gstored[k] = 0;
+  }
+  c->gm = m;
+}
+
+/* x0 = U y, y = argmin |b - J U y| over the kept corrections of Newton index `slot` (normal equations, pivoted Cholesky) */
+static void guess_project(orc_ctx *c, const orc_opts *o, int slot, const double *b, double *x, int singular) {
+  const int n = c->ndof;
+  if (o->ksp_guess <= 0 || slot < 0 || slot >= 4 || c->gm <= 0) return;
+  const int k = c->gcnt[slot];
+  if (k == 0) return;
+  double *W = (double *)malloc(sizeof(double) * (size_t)n * k);
+  double G[8][8], g[8], L[8][8], dg[8], t[8], y[8];
+  int piv[8], taken[8], r = 0;
+  for (int i = 0; i < k; i++) blk_mult(c, 0, c->gU[slot] + (size_t)i * n, W + (size_t)i * n);
+  for (int i = 0; i < k; i++) {
+    g[i] = vdot(n, W + (size_t)i * n, b);
+    for (int q = 0; q <= i; q++) G[i][q] = G[q][i] = vdot(n, W + (size_t)i * n, W + (size_t)q * n);
+  }
+  double dmax = 0.0;
+  for (int i = 0; i < k; i++) { dg[i] = G[i][i]; taken[i] = 0; y[i] = 0.0; if (dg[i] > dmax) dmax = dg[i]; for (int q = 0; q < k; q++) L[i][q] = 0.0; }
+  if (dmax > 0.0)
+    for (int rr = 0; rr < k; rr++) {
+      int p = -1;
+      for (int i = 0; i < k; i++) if (!taken[i] && (p < 0 || dg[i] > dg[p])) p = i;
+      if (p < 0 || !(dg[p] > 1e-10 * G[p][p]) || !(dg[p] > 1e-14 * dmax)) break;
+      taken[p] = 1; piv[r] = p;
+      const double lpp = sqrt(dg[p]);
+      L[p][r] = lpp;
+      for (int i = 0; i < k; i++) {
+        if (taken[i]) continue;
+        double sacc = G[i][p];
+        for (int q = 0; q < r; q++) sacc -= L[i][q] * L[p][q];
+        L[i][r] = sacc / lpp;
+        dg[i] -= L[i][r] * L[i][r];
+      }
+      r++;
+    }
+  for (int a = 0; a < r; a++) { double sacc = g[piv[a]]; for (int q = 0; q < a; q++) sacc -= L[piv[a]][q] * t[q]; t[a] = sacc / L[piv[a]][a]; }
+  for (int a = r - 1; a >= 0; a--) { double sacc = t[a]; for (int q = a + 1; q < r; q++) sacc -= L[piv[q]][a] * y[piv[q]]; y[piv[a]] = sacc / L[piv[a]][a]; }
+  for (int i = 0; i < k; i++) if (isfinite(y[i]) && y[i] != 0.0) vaxpy(n, y[i], c->gU[slot] + (size_t)i * n, x);
+  if (singular) remove_pmean(c, x);
+  free(W);
+}
+
+static int fgmres(orc_ctx *c, const orc_opts *o, pc_ws *pc, const double *b, double *x, int singular, int *its_out, int slot) {
   const int n = c->ndof, m = o->ksp_restart;
   double *V = (double *)malloc(sizeof(double) * (size_t)n * (m + 1));
   double *Z = (double *)malloc(sizeof(double) * (size_t)n * m);
@@ -1408,6 +1465,7 @@ static int fgmres(orc_ctx *c, const orc_opts *o, pc_ws *pc, const double *b, dou
   double bn = vnorm(n, b);
   int its = 0, reason = 0;
   if (bn == 0.0) { reason = 1; goto done; }
+  guess_project(c, o, slot, b, x, singular);  /* no-op unless orc_opts.ksp_guess > 0 */
   for (;;) {
     blk_mult(c, 0, x, w);
 #pragma omp parallel for schedule(static)
@@ -1455,6 +1513,12 @@ static int fgmres(orc_ctx *c, const orc_opts *o, pc_ws *pc, const double *b, dou
 done:
   free(V); free(Z); free(H); free(w); free(cs); free(sn); free(g); free(y);
   *its_out += its;
+  if (reason > 0 && o->ksp_guess > 0 && slot >= 0 && slot < 4 && c->gm > 0) {
+    vcopy(n, x, c->gU[slot] + (size_t)c->ghead[slot] * n);
+    c->gstored[slot] = 1;
+    c->ghead[slot] = (c->ghead[slot] + 1) % c->gm;
+    if (c->gcnt[slot] < c->gm) c->gcnt[slot]++;
+  }
   return reason;
 }
 
@@ -1466,6 +1530,7 @@ void orc_default_opts(orc_opts *o) {
   o->remove_p_mean = 1; o->verbose = 0;
   o->pc_kind = 0; o->cheb_degree = 3; o->cheb_ratio = 10.0; o->amg_smooth_degree = 1; o->amg_smooth_ratio = 8.0;
   o->amg_theta = 0.08; o->amg_max_coarse = 1000; o->cc_smooth_degree = 2; o->schur_upper = 0;
+  o->ksp_guess = 0;
 }
 
 /* One time step: Newton on the monolithic vector xv (in: initial guess = previous
@@ -1511,6 +1576,7 @@ int orc_solve_step(orc_ctx *c, double *xv, const orc_opts *o, orc_stats *st) {
     if (singular != c->singular) { c->singular = singular; c->amg_valid = 0; }
   }
   int reason = 0;
+  guess_ensure(c, o);
   for (int it = 0;; it++) {
     if (o->verbose) printf("  oracle newton %d |F| = %.6e\n", it, fn);
     if (fn < o->snes_atol) { reason = 2; break; }
@@ -1519,7 +1585,8 @@ int orc_solve_step(orc_ctx *c, double *xv, const orc_opts *o, orc_stats *st) {
     t0 = now_ms();
     if (pc_setup(c, o)) { reason = -3; break; }
     int its_before = st->krylov_its;
-    int kr = fgmres(c, o, &pc, F, d, singular, &st->krylov_its);
+    if (o->ksp_guess > 0 && it < 4) { c->gstored[it] = 0; vcopy(n, xv, c->gX[it]); }
+    int kr = fgmres(c, o, &pc, F, d, singular, &st->krylov_its, it < 4 ? it : -1);
     if (o->pc_kind >= 1) { /* adaptive lagging of the hierarchy, as in libcfdh */
       int kits = st->krylov_its - its_before;
       if (c->amg_its_ref == 0) c->amg_its_ref = kits > 0 ? kits : 1;
@@ -1556,6 +1623,12 @@ int orc_solve_step(orc_ctx *c, double *xv, const orc_opts *o, orc_stats *st) {
       reason = 4; break;
     }
   }
+  if (reason > 0 && o->ksp_guess > 0 && c->gm > 0)
+    for (int k = 0; k < st->newton_its && k < 4; k++) {  /* kept corrections become x_k - x_final (csrc/cfdh_solver.cpp::guess_refine) */
+      if (!c->gstored[k]) continue;
+      double *u = c->gU[k] + (size_t)((c->ghead[k] + c->gm - 1) % c->gm) * n;
+      for (int i = 0; i < n; i++) u[i] = c->gX[k][i] - xv[i];
+    }
   st->fnorm = fn;
   st->reason = reason;
   st->sub_its = pc.sub_its;

@@ -28,7 +28,7 @@ class Opts(C.Structure):
                 ("sub_max_it", C.c_int), ("sub_restart", C.c_int), ("remove_p_mean", C.c_int),
                 ("verbose", C.c_int), ("pc_kind", C.c_int), ("cheb_degree", C.c_int), ("cheb_ratio", C.c_double),
                 ("amg_smooth_degree", C.c_int), ("amg_smooth_ratio", C.c_double), ("amg_theta", C.c_double),
-                ("amg_max_coarse", C.c_int), ("cc_smooth_degree", C.c_int), ("schur_upper", C.c_int)]
+                ("amg_max_coarse", C.c_int), ("cc_smooth_degree", C.c_int), ("schur_upper", C.c_int), ("ksp_guess", C.c_int)]
 
 
 class Stats(C.Structure):

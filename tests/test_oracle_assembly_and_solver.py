@@ -106,3 +106,28 @@ def test_divergence_is_reported():
     O.set_un(np.zeros(2 * case.nv))
     with pytest.raises(RuntimeError, match="Did not converge"):
         O.solve_step(np.zeros(3 * case.nv), orc.default_opts(snes_max_it=1, snes_rtol=1e-14, snes_stol=0.0))
+
+
+def test_projected_initial_guess_in_the_cpu_port():
+    """orc_opts.ksp_guess: the CPU port of cfdh_options.ksp_guess (the bench's cpu_baseline leg runs with the GPU path's setting).
+    Off by default -- every other oracle test runs the reference's zero guess; on, the converged steps are the same and the
+    later steps need fewer iterations."""
+    from oracle import orc
+    case = dfg_case(14)
+    nv = case.nv
+    out = {}
+    for guess in (0, 4):
+        O = make_oracle(case)
+        O.set_un(np.zeros(2 * nv))
+        x = np.zeros(3 * nv)
+        opts = orc.default_opts(pc_kind=2, ksp_guess=guess, snes_rtol=1e-11, snes_stol=0.0, ksp_rtol=1e-9)
+        its = []
+        for _ in range(9):
+            x, st = O.solve_step(x, opts)
+            assert st.reason > 0
+            O.set_un(x[: 2 * nv])
+            its.append(st.krylov_its)
+        out[guess] = (x, its)
+    assert orc.default_opts().ksp_guess == 0
+    assert out[4][1][0] == out[0][1][0] and sum(out[4][1][4:]) < 0.9 * sum(out[0][1][4:])
+    assert np.linalg.norm(out[4][0] - out[0][0]) <= 1e-8 * np.linalg.norm(out[0][0])
