@@ -486,27 +486,42 @@ def main():
         bdf2 = args.solver == "stabilized_schur_bdf2"
         # same Newton / FGMRES / Cahouet-Chabard + AMG algorithm and tolerances; FULL Schur factorisation, which is
         # the faster variant on the CPU (4.0 vs 2.7 steps/s with the upper-triangular factor the GPU path prefers)
-        # ... and the same projected initial guess of the linear solves (orc_opts.ksp_guess = cfdh_options.ksp_guess)
-        osc = make_scenario(args, "_oracle_double", pc_kind=2, options=dict(schur_upper=0, ksp_guess=int(sc.solver.options.ksp_guess)), bdf2=bdf2)
-        osc.solver.O.set_threads(cores)
-        t0 = time.perf_counter()
-        nst = 0
-        for _ in range(args.warmup + args.cpu_steps):
-            step_hook(osc, nst, dt)
-            osc.solver.solveStep()
-            osc.solver.advance()
-            nst += 1
-            if nst == args.warmup:
-                t0 = time.perf_counter()
-            if time.perf_counter() - t0 > 60.0 and nst > args.warmup:
-                break
-        ncpu = nst - args.warmup
-        tcpu = time.perf_counter() - t0
+        # ... and the projected initial guess of the linear solves (orc_opts.ksp_guess = cfdh_options.ksp_guess) when that is the
+        # faster way on the CPU too: the sample is run with the GPU path's setting and with the zero guess, the FASTER one is reported
+        # (at 1 M DOF the four extra products cost the CPU port more than the iterations they save; elsewhere they pay)
+        g_gpu = int(sc.solver.options.ksp_guess)
+
+        def cpu_leg(guess):
+            o_sc = make_scenario(args, "_oracle_double", pc_kind=2, options=dict(schur_upper=0, ksp_guess=guess), bdf2=bdf2)
+            o_sc.solver.O.set_threads(cores)
+            t_start = time.perf_counter()
+            n_done = 0
+            for _ in range(args.warmup + args.cpu_steps):
+                step_hook(o_sc, n_done, dt)
+                o_sc.solver.solveStep()
+                o_sc.solver.advance()
+                n_done += 1
+                if n_done == args.warmup:
+                    t_start = time.perf_counter()
+                if time.perf_counter() - t_start > 60.0 and n_done > args.warmup:
+                    break
+            return o_sc, n_done, n_done - args.warmup, time.perf_counter() - t_start
+
+        osc, nst, ncpu, tcpu = cpu_leg(g_gpu)
+        legs = {g_gpu: ncpu / tcpu}
+        if g_gpu > 0:
+            o0, nst0, ncpu0, tcpu0 = cpu_leg(0)
+            legs[0] = ncpu0 / tcpu0
+            del o0
+            if legs[0] > legs[g_gpu]:
+                ncpu, tcpu = ncpu0, tcpu0
+        best = max(legs, key=legs.get)
         out["cpu_baseline"] = {
             "value": ncpu / tcpu, "unit": "time-steps/s", "cores": cores, "kind": "port", "host_cores_available": host_cores(),
             "sample": "steps %d..%d of the same mesh/dt from t=0 with the C oracle (oracle/cfdh_oracle.c, pc_kind=2: "
                       "same Newton + FGMRES + Cahouet-Chabard/AMG preconditioner and tolerances, FULL Schur factorisation = "
-                      "the faster variant on the CPU, OpenMP; the same projected initial guess of the linear solves, ksp_guess = %d)" % (args.warmup + 1, nst, int(sc.solver.options.ksp_guess)),
+                      "the faster variant on the CPU, OpenMP; initial guess of the linear solves: the faster of %s, here ksp_guess = %d)" % (
+                          args.warmup + 1, nst, " / ".join("ksp_guess = %d: %.3f steps/s" % (k, v) for k, v in sorted(legs.items())), best),
             "ms_per_step": 1e3 * tcpu / max(ncpu, 1),
         }
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
