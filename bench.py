@@ -353,6 +353,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
+    # The rest of the config's own run (T / dt steps from t = 0), so that the end-to-end rate is MEASURED, not extrapolated from the
+    # timed region: with the projected initial guess the steps get cheaper as the flow settles.  Bounded (20 s); every step so far
+    # was clocked, the first one with its preconditioner build and graph captures included.
+    n_run_total = run_length(args)
+    steps_before = kstep
+    t_rest0 = time.perf_counter()
+    while world == 1 and kstep < n_run_total and time.perf_counter() - t_rest0 < 20.0:
+        step_hook(sc, kstep, dt)
+        solver.solveStep()
+        solver.assemble_wss()
+        solver.advance()
+        kstep += 1
+    torch.cuda.synchronize()
+    t_rest = time.perf_counter() - t_rest0
+    e2e_steps = kstep
+    e2e_wall = sum(step_wall[:args.warmup]) + elapsed + t_rest
+    rest_rate = (kstep - steps_before) / t_rest if kstep > steps_before else None
+
     # the reference's literal loop: u_prev.x.array[:] = u_sol.x.array[:] (scenario.py:306-307), reported beside `value`
     literal_rate = None
     if world == 1 and args.host_loop_steps > 0:
@@ -463,6 +481,10 @@ def main():
     # time of all steps before the timed region (the AMG hierarchies are built in step 1 and lagged after).
     n_run = run_length(args)
     t_first = step_wall[0]
+    if world == 1 and e2e_steps > args.warmup + args.steps:
+        out["end_to_end_measured"] = {"steps": int(e2e_steps), "of_run_length": int(n_run), "wall_s": e2e_wall,
+                                      "steps_per_s": e2e_steps / e2e_wall, "steps_per_s_after_the_timed_region": rest_rate,
+                                      "note": "every step from t = 0 clocked (first step with its preconditioner build included); context creation excluded"}
     out["hierarchy_build_s"] = 1e-3 * sum(step_pc_ms[:max(args.warmup, 1)])
     out["first_step_s"] = t_first
     out["run_length_steps"] = n_run
