@@ -496,6 +496,32 @@ def main():
     if args.config == "c5b":
         qi, q1, q2 = sc.flow_rates()
         out["results"].update({"inflow": qi, "outflow_1": q1, "outflow_2": q2})
+    if world == 1 and rank == 0 and int(sc.solver.options.ksp_guess) > 0 and args.config in ("c2", "c3", "c4", "c5b", "q1"):
+        # The same timed region with the linear solver configured like the reference's KSP: zero initial guess in every solve (and
+        # the fp64 basis throughout) -- so that the line carries both numbers and the share of `value` that is due to the projected
+        # guess can be read off.  A fresh scenario from t = 0, the same warm-up and step counts, the same clock.
+        fp32_before = os.environ.get("CFDH_KRYLOV_FP32")
+        os.environ["CFDH_KRYLOV_FP32"] = "0"
+        sc0 = make_scenario(args, args.solver, device=local_rank, options=dict(ksp_guess=0))
+        k0 = 0
+        for _ in range(args.warmup):
+            step_hook(sc0, k0, dt); sc0.solver.solveStep(); sc0.solver.assemble_wss(); sc0.solver.advance(); k0 += 1
+        torch.cuda.synchronize()
+        t00 = time.perf_counter()
+        its0 = 0
+        for _ in range(args.steps):
+            step_hook(sc0, k0, dt); sc0.solver.solveStep(); sc0.solver.assemble_wss(); sc0.solver.advance(); k0 += 1
+            its0 += sc0.solver.last_stats.krylov_its
+        torch.cuda.synchronize()
+        e0 = time.perf_counter() - t00
+        if fp32_before is None:
+            os.environ.pop("CFDH_KRYLOV_FP32", None)
+        else:
+            os.environ["CFDH_KRYLOV_FP32"] = fp32_before
+        out["zero_initial_guess_check"] = {"ksp_guess": 0, "steps_per_s": args.steps / e0, "ms_per_step": 1e3 * e0 / args.steps,
+                                           "krylov_its_per_step": its0 / args.steps,
+                                           "note": "same timed region, linear solves started from zero as the reference's KSP does"}
+        del sc0
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         # CPU baseline and parity: the same Scenario class on the oracle-backed test double of the solver plugin
         # (tests/oracle_solver.py over oracle/cfdh_oracle.c) -- checker and reported baseline only, never the product.
