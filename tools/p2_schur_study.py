@@ -280,7 +280,11 @@ def study(kind, m, pb, J, F, outn):
         Rinj = sp.csr_matrix((np.ones(nvert_), (np.arange(nvert_), np.arange(nvert_))), shape=(nvert_, nv))
         E = (sp.identity(nv) - Pc_full @ Rinj).tocsr()          # hierarchical surplus: 0 at vertices, value - mean of the edge ends
         A11hp = (E.T @ A11 @ E).tocsc()
-        for kt in (1.0, 0.0):
+        for c_all, c_sur in ((0.25, 0.6), (0.2, 0.7), (0.3, 0.5), (0.15, 0.8)):
+            for kt in (1.0, 0.0):
+                Hk = (sp.diags((1.0 + kt * a_ * T_) * Ml_scaled) + b_ * (c_all * A11 + c_sur * A11hp)).tocsc()
+                res["CC exact, H = (1 + %g a'T) M + b' (%g A11 + %g E^T A11 E)" % (kt, c_all, c_sur)] = gmres_right(J, b, variant(spl.splu(Hk).solve, linv, A00s.solve))
+        for kt in ():
             for kap in (1.0, 0.8, 0.6):
                 Hk = (sp.diags((1.0 + kt * a_ * T_) * Ml_scaled) + kap * b_ * A11hp).tocsc()
                 res["CC exact, H' = (1 + %g a'T) M + %g b' E^T A11 E" % (kt, kap)] = gmres_right(J, b, variant(spl.splu(Hk).solve, linv, A00s.solve))
