@@ -1,5 +1,5 @@
 """Kernel time of the generic assembly (Q1 bench mesh): `ctx.assemble()` repeated, HIP events of the library (kind 0).
-Usage: python tools/gen_asm_time.py   (CFDH_GEN_NOATOMIC=1: diagnostic build only)"""
+Usage: python tools/gen_asm_time.py"""
 import os, sys, types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,8 +10,7 @@ s = sc.solver
 for _ in range(3):
     s.solveStep(); s.advance()
 ctx = s.ctx
-for mode, na in ((True, "0"), (False, "0"), (True, "1")):
-    os.environ["CFDH_GEN_NOATOMIC"] = na
+for mode, na in ((True, "0"), (False, "0")):
     ctx.profile_reset(); ctx.profile_enable(True)
     for _ in range(10):
         ctx.assemble(mode)
