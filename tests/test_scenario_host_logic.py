@@ -198,3 +198,22 @@ def test_epsilon_and_sigma_of_solver_base():
         S = SolverBase.sigma(u, p, 0.04)
         pc = 2.0 + np.asarray(mesh.x)[np.asarray(mesh.cells)][:, :, 0].mean(axis=1)
         assert np.abs(S - (0.04 * (A + A.T)[None] - pc[:, None, None] * np.eye(d)[None])).max() <= 1e-12
+
+
+def test_bench_contract_host_side():
+    """bench.py without a GPU: `--gpus N` never silently runs one rank (it refuses when fewer devices are visible than ranks), the
+    run length of every config is the reference's T / dt, and the kernel-source fingerprint that ties profiles/pmc_traffic.json to
+    a build is a pure function of the sources."""
+    import os
+    import subprocess
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+    assert r.returncode == 2 and "--gpus 2" in (r.stdout + r.stderr) and not r.stdout.strip().startswith("{")
+    for cfg, dt, n in (("c3", 0.01, 100), ("c2", 0.01, 1000), ("c4", 0.01, 100), ("c5", 0.001, 1000), ("c5b", 0.01, 100)):
+        assert bench.run_length(types.SimpleNamespace(config=cfg, dt=dt)) == n
+    a, b = bench.kernel_source_sha16(), bench.kernel_source_sha16()
+    assert a == b and len(a) == 16 and int(a, 16) >= 0
