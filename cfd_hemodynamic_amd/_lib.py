@@ -42,7 +42,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp)
 # every symbol include/cfdh.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "cfdh_create", "cfdh_create_elem", "cfdh_set_facet_markers", "cfdh_destroy", "cfdh_last_error", "cfdh_abi_version", "cfdh_set_params", "cfdh_default_options",
-    "cfdh_set_options", "cfdh_clear_dirichlet", "cfdh_add_dirichlet", "cfdh_set_state", "cfdh_get_solution",
+    "cfdh_set_options", "cfdh_clear_dirichlet", "cfdh_add_dirichlet", "cfdh_update_dirichlet", "cfdh_set_state", "cfdh_get_solution",
     "cfdh_get_previous", "cfdh_get_residual", "cfdh_advance", "cfdh_advance_field", "cfdh_set_time_scheme", "cfdh_set_previous2", "cfdh_get_previous2",
     "cfdh_shift_history", "cfdh_set_boundary_terms", "cfdh_assemble", "cfdh_get_csr", "cfdh_spmv", "cfdh_solve_step",
     "cfdh_functional", "cfdh_wall_shear_stress", "cfdh_set_global_pressure_space", "cfdh_set_halo", "cfdh_comm_unique_id", "cfdh_comm_init", "cfdh_comm_set_callbacks",
@@ -87,6 +87,7 @@ def lib():
     L.cfdh_set_options.argtypes = [vp, C.POINTER(Options)]
     L.cfdh_clear_dirichlet.argtypes = [vp]
     L.cfdh_add_dirichlet.argtypes = [vp, C.c_int, C.c_int64, ip, dp]
+    L.cfdh_update_dirichlet.argtypes = [vp, C.c_int, C.c_int64, ip, dp]
     L.cfdh_set_state.argtypes = [vp, dp, dp, dp, dp]
     L.cfdh_get_solution.argtypes = [vp, dp, dp]
     L.cfdh_set_time_scheme.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double]
@@ -213,6 +214,12 @@ class Context:
         nodes = np.ascontiguousarray(nodes, dtype=np.int32)
         values = np.ascontiguousarray(values, dtype=np.float64)
         self._chk(self.L.cfdh_add_dirichlet(self.h, int(field), len(nodes), _ip(nodes), _dp(values)))
+
+    def update_dirichlet(self, field, nodes, values):
+        """New values for dofs that are already constrained (no object added, diagonal counts unchanged)."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        self._chk(self.L.cfdh_update_dirichlet(self.h, int(field), len(nodes), _ip(nodes), _dp(values)))
 
     def set_state(self, u_prev=None, p_prev=None, u=None, p=None):
         a = [None if v is None else np.ascontiguousarray(v, dtype=np.float64).reshape(-1) for v in (u_prev, p_prev, u, p)]

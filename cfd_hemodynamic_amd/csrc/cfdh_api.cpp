@@ -174,6 +174,24 @@ int cfdh_add_dirichlet(cfdh_ctx *c, int field, int64_t n, const int32_t *nodes, 
   return 0;
 }
 
+int cfdh_update_dirichlet(cfdh_ctx *c, int field, int64_t n, const int32_t *nodes, const double *values) {
+  if (!c || (field != 0 && field != 1) || n < 0 || (n > 0 && (!nodes || !values))) return cfdh_fail(c, CFDH_E_ARG, "bad Dirichlet arguments");
+  const int d = c->dim, st = d + 1;
+  const unsigned need = field == 0 ? ((1u << d) - 1u) : (1u << d);
+  for (int64_t k = 0; k < n; k++) {
+    if (nodes[k] < 0 || nodes[k] >= c->nv) return cfdh_fail(c, CFDH_E_ARG, "Dirichlet node %d out of range", (int)nodes[k]);
+    if ((c->h_bcflag[c->perm[nodes[k]]] & need) != need) return cfdh_fail(c, CFDH_E_ARG, "cfdh_update_dirichlet: node %d is not constrained", (int)nodes[k]);
+  }
+  for (int64_t k = 0; k < n; k++) {
+    const int v = c->perm[nodes[k]];
+    c->bc_touched.push_back(v);
+    if (field == 0) for (int i = 0; i < d; i++) c->h_bcval[(size_t)st * v + i] = values[(size_t)d * k + i];
+    else c->h_bcval[(size_t)st * v + d] = values[k];
+  }
+  if (n > 0) c->bc_dirty = true;
+  return 0;
+}
+
 // user arrays (u [nv][2], p [nv], user numbering) -> internal vector layout
 // Host <-> device field transfers of the literal reference loop (scenario.py:306-307 copies the state through the
 // host every step): staged through one pinned buffer (pageable copies run at a fraction of the PCIe rate) and

@@ -77,6 +77,8 @@ class Solver(SolverBase):
         self.last_stats = None
         self._bcs = []
         self._bc_cache = None
+        self._bc_nodes = None
+        self._bc_owned = None
         # lazy host/device synchronisation of the state Functions
         self._dev_newer = {"sol": False, "res": False, "wss": False}
         self._prev_host_dirty = True
@@ -170,6 +172,8 @@ class Solver(SolverBase):
         self.bcp_d = [bc.getBC(self.Q) for bc in bcp]
         self._bcs = [(0, bc) for bc in self.bcu_d] + [(1, bc) for bc in self.bcp_d]
         self._bc_cache = None
+        self._bc_nodes = None
+        self._bc_owned = None
         if facet_tags is not None:
             # the reference hands the facet tags over here, not at construction (scenario.py:146-149):
             # drag/lift by marker and the backflow marker follow them
@@ -222,10 +226,29 @@ class Solver(SolverBase):
         if self._bc_cache is not None and len(vals) == len(self._bc_cache) and all(
                 np.array_equal(a, b) for a, b in zip(vals, self._bc_cache)):
             return
+        nodes_now = [n for n, _ in items]
+        same_sets = (self._bc_cache is not None and self._bc_nodes is not None and len(nodes_now) == len(self._bc_nodes)
+                     and all(a is b or np.array_equal(a, b) for a, b in zip(nodes_now, self._bc_nodes)))
+        if same_sets:
+            # time-dependent data on unchanged dof sets (pulsatile inlet): only the objects whose values changed are re-sent,
+            # and of those only the dofs they determine (a later object holding the same dof keeps its value)
+            for k, ((fld, _), (nodes, v)) in enumerate(zip(self._bcs, items)):
+                if not np.array_equal(v, self._bc_cache[k]):
+                    own = self._bc_owned[k]
+                    self.ctx.update_dirichlet(fld, nodes[own], v[own])
+            self._bc_cache = vals
+            return
         self.ctx.clear_dirichlet()
         for (fld, _), (nodes, v) in zip(self._bcs, items):
             self.ctx.add_dirichlet(fld, nodes, v)
         self._bc_cache = vals
+        self._bc_nodes = nodes_now
+        # dofs whose final value each object determines: not held by a LATER object of the same field
+        self._bc_owned = []
+        for k, ((fld, _), (nodes, _v)) in enumerate(zip(self._bcs, items)):
+            later = [items[j][0] for j in range(k + 1, len(items)) if self._bcs[j][0] == fld]
+            own = np.ones(len(nodes), dtype=bool) if not later else ~np.isin(nodes, np.concatenate(later))
+            self._bc_owned.append(own)
 
     def solveStep(self):
         for _, bc in self._bcs:

@@ -156,6 +156,11 @@ int cfdh_clear_dirichlet(cfdh_ctx *ctx);
  * value of a shared dof; the matrix diagonal counts the objects holding it.
  * Re-callable every step (bc.update(), stabilized_schur.py:170). */
 int cfdh_add_dirichlet(cfdh_ctx *ctx, int field, int64_t n, const int32_t *nodes, const double *values);
+/* New VALUES for dofs that are already constrained (`bc.update()` of a time-dependent condition, stabilized_schur.py:170, when
+ * the dof sets of all objects are unchanged): no object is added, the matrix diagonal keeps its counts, only the listed
+ * vertices are re-sent to the device.  The caller passes the dofs whose value this object determines (a later object that
+ * holds the same dof keeps its value).  CFDH_E_ARG if a listed dof is not constrained. */
+int cfdh_update_dirichlet(cfdh_ctx *ctx, int field, int64_t n, const int32_t *nodes, const double *values);
 
 /* ---- state ---------------------------------------------------------------- */
 
