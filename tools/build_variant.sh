@@ -9,7 +9,7 @@ tmp=/tmp/cfdh_variant_$name
 mkdir -p $tmp $root/cfd_hemodynamic_amd/variants
 FLAGS="-O3 -std=c++17 -fPIC -fopenmp -I$root/include -I$src -Wno-unused-result -Wno-unused-function --offload-arch=gfx950 $extra"
 pids=()
-for f in cfdh_kernels.hip cfdh3_kernels.hip cfdh_setup.cpp cfdh3_setup.cpp cfdh_solver.cpp cfdh_api.cpp cfdh_comm.cpp; do
+for f in cfdh_kernels.hip cfdh3_kernels.hip cfdh_amg_dev.hip cfdh_gen.hip cfdh_setup.cpp cfdh3_setup.cpp cfdh_solver.cpp cfdh_api.cpp cfdh_comm.cpp; do
   /opt/rocm/bin/hipcc $FLAGS -x hip -c $src/$f -o $tmp/${f%.*}.o &
   pids+=($!)
 done
