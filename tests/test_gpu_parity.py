@@ -318,6 +318,23 @@ def test_dirichlet_sets_can_be_replaced_sparse_updates_leave_nothing_stale():
     O.set_un(un)
     Fo = O.assemble(x)
     assert np.abs(F - Fo).max() <= 1e-13 * np.abs(Fo).max()
+    # cfdh_update_dirichlet: new values on the SAME dof sets without clear / add.  The first object of setB3 shares dofs with
+    # `extra`, which was added later and therefore determines their value: the caller passes only the dofs the object owns.
+    ctx.clear_dirichlet()
+    later = (0, setB2[0][1][3:12].copy(), rng.standard_normal((9, 2)))  # a later object on nine dofs of the first one
+    setB3 = setB2 + [later]
+    for fld, nodes, vals in setB3:
+        ctx.add_dirichlet(fld, nodes, vals)
+    new_vals = -0.5 * setB3[0][2]
+    own = ~np.isin(setB3[0][1], later[1])
+    assert own.any() and not own.all()
+    ctx.update_dirichlet(0, setB3[0][1][own], new_vals[own])
+    F, J = assembled(ctx)
+    F0, J0 = fresh([(0, setB3[0][1], new_vals), setB3[1], later])
+    assert np.array_equal(F, F0) and np.array_equal(J.data, J0.data)
+    free = np.setdiff1d(np.arange(nv, dtype=np.int32), np.concatenate([b[1] for b in setB3 if b[0] == 0]))[:3]
+    with pytest.raises(Exception):
+        ctx.update_dirichlet(0, free, np.zeros((3, 2)))   # not constrained: refused
     ctx.close()
 
 
