@@ -357,16 +357,26 @@ def main():
     # timed region: with the projected initial guess the steps get cheaper as the flow settles.  Bounded (20 s); every step so far
     # was clocked, the first one with its preconditioner build and graph captures included.
     n_run_total = run_length(args)
+    if args.config == "p2":
+        n_run_total = kstep  # the P2 stenosis does not reach its own T (Newton count climbs from step ~20)
     steps_before = kstep
     t_rest0 = time.perf_counter()
+    rest_failure = None
     while world == 1 and kstep < n_run_total and time.perf_counter() - t_rest0 < 20.0:
-        step_hook(sc, kstep, dt)
-        solver.solveStep()
-        solver.assemble_wss()
-        solver.advance()
+        try:
+            step_hook(sc, kstep, dt)
+            solver.solveStep()
+            solver.assemble_wss()
+            solver.advance()
+        except RuntimeError as e:  # a run that does not reach its own T (the P2 stenosis: DESIGN.md section 9) is reported, not fatal
+            rest_failure = "step %d: %s" % (kstep + 1, str(e)[:160])
+            break
         kstep += 1
     torch.cuda.synchronize()
     t_rest = time.perf_counter() - t_rest0
+    if rest_failure:  # the state is that of a failed step: no further legs on this scenario
+        args.host_loop_steps = 0
+        args.prof_steps = 0
     e2e_steps = kstep
     e2e_wall = sum(step_wall[:args.warmup]) + elapsed + t_rest
     rest_rate = (kstep - steps_before) / t_rest if kstep > steps_before else None
@@ -485,6 +495,8 @@ def main():
         out["end_to_end_measured"] = {"steps": int(e2e_steps), "of_run_length": int(n_run), "wall_s": e2e_wall,
                                       "steps_per_s": e2e_steps / e2e_wall, "steps_per_s_after_the_timed_region": rest_rate,
                                       "note": "every step from t = 0 clocked (first step with its preconditioner build included); context creation excluded"}
+        if rest_failure:
+            out["end_to_end_measured"]["stopped"] = rest_failure
     out["hierarchy_build_s"] = 1e-3 * sum(step_pc_ms[:max(args.warmup, 1)])
     out["first_step_s"] = t_first
     out["run_length_steps"] = n_run

@@ -1,0 +1,18 @@
+"""How far does the P2/P2 backflow stenosis of `bench.py --config p2` run?  (steps survived, iterations; env knobs CFDH_* apply)"""
+import os, sys, types
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+guess = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+args = types.SimpleNamespace(config="p2", m=200, nx=2935, ny=40, res=7.3e-6, res3=2e-4, dt=0.01, ramp=0.03, v_max=20.0)
+sc = bench.make_scenario(args, "stabilized_schur", device=0, options=dict(ksp_guess=guess))
+s = sc.solver
+log = []
+for k in range(steps):
+    try:
+        s.solveStep(); s.advance()
+    except Exception as e:
+        print("FAILED at step", k + 1, str(e)[:120]); break
+    log.append((s.last_stats.newton_its, s.last_stats.krylov_its))
+print("ksp_guess", guess, "fp32", os.environ.get("CFDH_KRYLOV_FP32", "auto"), "steps", len(log), log)
