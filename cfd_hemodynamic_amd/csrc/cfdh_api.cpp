@@ -143,6 +143,7 @@ int cfdh_clear_dirichlet(cfdh_ctx *c) {
   }
   c->bc_pending.insert(c->bc_pending.end(), c->bc_touched.begin(), c->bc_touched.end());  // must be reset on the device too
   c->bc_touched.clear();
+  c->bc_touched_sent = 0;
   c->n_pbc = 0;
   c->bc_dirty = true;
   c->bc_version++;
@@ -184,7 +185,7 @@ int cfdh_update_dirichlet(cfdh_ctx *c, int field, int64_t n, const int32_t *node
   }
   for (int64_t k = 0; k < n; k++) {
     const int v = c->perm[nodes[k]];
-    c->bc_touched.push_back(v);
+    c->bc_pending.push_back(v);  // the node is in bc_touched already (an add constrained it): only its device entry is stale
     if (field == 0) for (int i = 0; i < d; i++) c->h_bcval[(size_t)st * v + i] = values[(size_t)d * k + i];
     else c->h_bcval[(size_t)st * v + d] = values[k];
   }
@@ -720,6 +721,7 @@ int64_t cfdh_info(const cfdh_ctx *c, int what) {
     case 70: return c->n_guess_solves;  // linear solves started from a projected guess (cfdh_options.ksp_guess)
     case 71: return c->n_guess_solves ? (int64_t)(1e6 * c->guess_reduction_sum / (double)c->n_guess_solves) : 0;  // mean |r0| / |b| of those, in 1e-6
     case 29: return c->nloc;
+    case 72: return c->n_attainable_stops;  // solves stopped at the attainable accuracy (reason CFDH_KSP_CONVERGED_ATTAINABLE), above their tolerance
     case 27: return (int64_t)(1000.0 * c->ms_pc_build_dev);  // microseconds of the last device-side preconditioner build (0: host build)
     case 19: return c->opt.pc_type == 1 ? c->hL.nnz_S0 : c->hS.nnz_S0;
     case 20: return c->hA.nnz_S0;

@@ -219,6 +219,7 @@ struct cfdh_ctx {
   // vertices written by cfdh_add_dirichlet since the last clear / since the last upload: clearing and uploading touch these
   // only (a pulsatile inlet re-sends every object every step; the full arrays are 49 B per vertex)
   std::vector<int> bc_touched, bc_pending;
+  size_t bc_touched_sent = 0;          // bc_touched[0 .. sent) are on the device already (upload_bc takes the rest as pending)
   std::vector<int> bc_mark;            // epoch marker per vertex (de-duplication)
   int bc_epoch = 0;
   bool bc_full_upload = true;          // device arrays not initialised yet
@@ -359,6 +360,7 @@ struct cfdh_ctx {
   // communication / synchronisation counters (cfdh_info 13..17): all-reduces, halo exchanges, host synchronisations
   // of the solve, FGMRES iterations, all-gathers -- cumulative, reset by cfdh_profile_reset
   long long n_allreduce = 0, n_halo = 0, n_host_sync = 0, n_krylov = 0, n_allgather = 0;
+  long long n_attainable_stops = 0;  // FGMRES solves ended by the attainable-accuracy rule (cfdh_info 72), cumulative over the context's life
 };
 
 // ---- error helpers -----------------------------------------------------------

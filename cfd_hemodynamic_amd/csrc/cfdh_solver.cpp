@@ -665,7 +665,9 @@ static int ensure_krylov(cfdh_ctx *c) {
   HIPCHK(c, c->kV.alloc(NL * (m + 1)));
   HIPCHK(c, c->kZ.alloc(NL * m));
   HIPCHK(c, c->kw.alloc(NL));
-  HIPCHK(c, c->kh.alloc(2 * (size_t)(m + 2) + 8));
+  // kh also serves guess_project as the scratch of its Gram system: 8 (k + 1) doubles with k <= 8 kept vectors (the cap of
+  // cfdh_set_options), whatever the restart length
+  HIPCHK(c, c->kh.alloc(std::max(2 * (size_t)(m + 2) + 8, (size_t)8 * (8 + 1))));
   HIPCHK(c, c->ky.alloc(m + 8));
   HIPCHK(c, c->kV.zero(c->stream)); HIPCHK(c, c->kZ.zero(c->stream)); HIPCHK(c, c->kw.zero(c->stream));
   if ((size_t)(m + 2) * 1024 > c->red_partial.n) HIPCHK(c, c->red_partial.alloc((size_t)(m + 2) * 1024 + 1024));
@@ -899,13 +901,21 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       // in a row ends "converged" by the recurrence without halving the true residual, that residual is the floor of this
       // system (rounding level of J x, or the component of b outside the range of a singular Jacobian: lid cavity at
       // ksp_rtol 1e-10) and the iteration stops instead of spending ksp_max_it on it.
-      if (j_prev > 0 && est_prev <= tol && beta > tol) {
-        if (last_true > 0.0 && beta > 0.5 * last_true) {
+      // The stop is bounded and reported as what it is: it applies only within 10x the tolerance or once the residual is six
+      // orders below |b| (beyond what the reference's rtol = 1e-5 ever asks for); anything else runs on to ksp_max_it and fails
+      // like PETSc's DIVERGED_ITS.  It returns its own reason code (CFDH_KSP_CONVERGED_ATTAINABLE) and is counted
+      // (cfdh_info 72).  CFDH_NO_ATTAINABLE_STOP=1 disables it.
+      static const bool no_attainable = getenv("CFDH_NO_ATTAINABLE_STOP") && getenv("CFDH_NO_ATTAINABLE_STOP")[0] == '1';
+      if (j_prev > 0 && est_prev <= tol && beta > tol && !no_attainable) {
+        if (last_true > 0.0 && beta > 0.5 * last_true && (beta <= 10.0 * tol || beta <= 1e-6 * bn)) {
           if (o.verbose) fprintf(stderr, "[cfdh]     fgmres: true residual %.3e stays above the tolerance %.3e although the recurrence converged twice: attainable accuracy, stopping\n", beta, tol);
-          reason = 2;
+          reason = CFDH_KSP_CONVERGED_ATTAINABLE;
+          c->n_attainable_stops++;
           break;
         }
         last_true = beta;
+      } else {
+        last_true = -1.0;  // a cycle that ended without recurrence convergence (restart): the floor has to be seen twice IN A ROW
       }
       beta_start = beta;
     }
@@ -1023,7 +1033,8 @@ static int upload_bc(cfdh_ctx *c) {
   if (!c->bc_dirty) return 0;
   const int st = c->dim + 1;
   // vertices whose device entries may be stale: cleared since the last upload, or (re)written since
-  c->bc_pending.insert(c->bc_pending.end(), c->bc_touched.begin(), c->bc_touched.end());
+  // (entries of bc_touched below the watermark went up with an earlier upload; cfdh_update_dirichlet queues its nodes itself)
+  c->bc_pending.insert(c->bc_pending.end(), c->bc_touched.begin() + (std::ptrdiff_t)std::min(c->bc_touched_sent, c->bc_touched.size()), c->bc_touched.end());
   if ((int)c->bc_mark.size() != c->nv) { c->bc_mark.assign(c->nv, -1); c->bc_full_upload = true; }
   c->bc_epoch++;
   size_t K = 0;
@@ -1032,6 +1043,7 @@ static int upload_bc(cfdh_ctx *c) {
   c->bc_pending.resize(K);
   // bc_touched keeps growing with duplicates when objects are re-added without a clear in between: compact it as well
   if (c->bc_touched.size() > 4 * (size_t)c->nv) { std::sort(c->bc_touched.begin(), c->bc_touched.end()); c->bc_touched.erase(std::unique(c->bc_touched.begin(), c->bc_touched.end()), c->bc_touched.end()); }
+  c->bc_touched_sent = c->bc_touched.size();
   // staging of the sparse update: declared here so that they outlive the stream synchronisation below
   std::vector<unsigned char> fl;
   std::vector<double> va, mu;

@@ -64,6 +64,16 @@ enum {
   CFDH_DIVERGED_LINE_SEARCH = -6,
   CFDH_DIVERGED_FNORM_NAN = -4
 };
+/* reasons of the linear solve (numbered after PETSc's KSPConvergedReason: 2 = CONVERGED_RTOL/ATOL on the true residual,
+ * -3 = DIVERGED_ITS, -9 = DIVERGED_NANORINF).  One code has no PETSc counterpart: the solve was stopped ABOVE its tolerance
+ * because two cycles in a row converged by the recurrence without moving the true residual (attainable accuracy of the
+ * system; only within 10x the tolerance or below 1e-6 |b|).  Such stops are counted: cfdh_info(ctx, 72). */
+enum {
+  CFDH_KSP_CONVERGED_RTOL = 2,
+  CFDH_KSP_CONVERGED_ATTAINABLE = 12,
+  CFDH_KSP_DIVERGED_ITS = -3,
+  CFDH_KSP_DIVERGED_NANORINF = -9
+};
 
 typedef struct cfdh_ctx cfdh_ctx;
 

@@ -4,6 +4,9 @@
 import os, sys, time, types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("CFDH_IMPORT_TORCH_FIRST") == "1":
+    import torch  # noqa: F401  (the process then runs on the HIP runtime torch bundles, like bench.py)
+    torch.cuda.set_device(0)
 import bench
 cfg, size, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 args = types.SimpleNamespace(config=cfg, m=200, nx=288, ny=115, res=7.3e-6, res3=2e-4, dt=0.001 if cfg == "c5" else 0.01, ramp=0.03,
@@ -14,6 +17,8 @@ t0 = time.perf_counter()
 sc = bench.make_scenario(args, "stabilized_schur", device=0, verbose=verbose)
 t_setup = time.perf_counter() - t0
 s = sc.solver
+if os.environ.get("CFDH_DUMP_MAPS"):  # which libraries are mapped where (to resolve the frames of a native backtrace)
+    open(os.environ["CFDH_DUMP_MAPS"], "w").write(open("/proc/self/maps").read())
 its, pcs, walls = [], [], []
 for k in range(steps):
     bench.step_hook(sc, k, args.dt)
