@@ -346,7 +346,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if not step_wall:  # --warmup 0: the first timed step is the first step of the run
         step_wall.append(elapsed / args.steps + 1e-3 * step_pc_ms[0])
-    counters = {k: ctx.info(i) for k, i in (("allreduce", 13), ("halo", 14), ("host_sync", 15), ("krylov", 16), ("allgather", 17))}
+    counters = {k: ctx.info(i) for k, i in (("allreduce", 13), ("halo", 14), ("host_sync", 15), ("krylov", 16), ("allgather", 17), ("discarded", 73))}
     comm_size = ctx.info(18)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -471,7 +471,9 @@ def main():
         "newton_its_per_step": float(np.mean(its_newton)),
         "krylov_its_per_step": float(np.mean(its_krylov)),
         "per_krylov_iteration": {"allreduce": counters["allreduce"] / kits, "halo_exchange": counters["halo"] / kits,
-                                 "allgather": counters["allgather"] / kits, "host_sync": counters["host_sync"] / kits},
+                                 "allgather": counters["allgather"] / kits, "host_sync": counters["host_sync"] / kits,
+                                 # FGMRES iterations launched ahead of the host's convergence test and thrown away (not in krylov_its)
+                                 "launched_ahead_and_discarded": counters["discarded"] / kits},
         # initial guess of the linear solves (cfdh_options.ksp_guess, PETSc's KSPGuess): each solve starts from the projection of its
         # right-hand side onto the solutions of the same Newton solve of the last steps; every solve is still run to rtol |b|
         "linear_solver_initial_guess": {"ksp_guess": int(sc.solver.options.ksp_guess), "solves_with_a_projected_guess": int(sc.solver.ctx.info(70)),

@@ -1084,7 +1084,10 @@ int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int n
   H.ncol = ncol;
   H.fused = false; H.nnz_G0 = H.nnz_S0 = 0;
   H.fine_nnz = A0.nnz;
-  const int maxlev = 16;
+  // depth cap (experiments: CFDH_A_MAXLEV / CFDH_L_MAXLEV for the velocity proxy / the pressure Laplacian): a hierarchy cut short
+  // while its last level is still large is closed with two damped-Jacobi sweeps there (below)
+  const char *ml_env = getenv(&H == &c->hA ? "CFDH_A_MAXLEV" : "CFDH_L_MAXLEV");
+  const int maxlev = ml_env && atoi(ml_env) >= 1 ? std::min(atoi(ml_env), 16) : 16;
   static const double theta_env = getenv("CFDH_AMG_THETA") ? atof(getenv("CFDH_AMG_THETA")) : -1.0;
   const double theta = o.amg_theta >= 0 ? o.amg_theta : (theta_env >= 0 ? theta_env : (c->dim == 3 ? 0.02 : 0.07));
   const bool host_agg = getenv("CFDH_AMG_AGG") && !strcmp(getenv("CFDH_AMG_AGG"), "host");

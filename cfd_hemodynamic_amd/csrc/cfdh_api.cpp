@@ -3,6 +3,8 @@
 #include <cmath>
 #include <numeric>
 
+#include <dlfcn.h>
+
 #include "cfdh_internal.hpp"
 
 std::string g_cfdh_last_error;
@@ -54,6 +56,18 @@ static int create_ctx(cfdh_ctx **out, int device, int gdim, int etype, int64_t n
   c->device = device;
   cfdh_default_options(&c->opt);
   { const char *e = getenv("CFDH_NO_GRAPH"); c->use_graph = !(e && e[0] == '1'); }
+  // No hipGraph replay under a rocprofiler-sdk tool on a HIP runtime >= 7.2.  That runtime submits the kernel packets of a graph
+  // launch with ONE doorbell; ROCr's intercepted queue hands such a batch to the profiler's queue interceptor as (pointer into
+  // the ring, packet count) without splitting it at the ring's wrap-around, and the interceptor walks `count` packets linearly:
+  // the first graph launch whose packets straddle the end of the ring makes it read past the ring's mapping -- the SIGSEGV at
+  // a page-aligned address below cfdh_pc_apply -> hipGraphLaunch of VERDICT round 3 (frames resolved in DESIGN.md section 6).
+  // bench.py never met it because torch loads its own HIP 7.0 runtime first, which rings the doorbell per packet.  The kernels
+  // are the same with direct launches, so a kernel trace loses nothing.  CFDH_GRAPH_UNDER_PROFILER=1 overrides.
+  if (c->use_graph && (getenv("ROCP_TOOL_LIBRARIES") || dlsym(RTLD_DEFAULT, "rocprofiler_configure"))) {
+    int rt = 0;
+    const char *ov = getenv("CFDH_GRAPH_UNDER_PROFILER");
+    if (!(ov && ov[0] == '1') && hipRuntimeGetVersion(&rt) == hipSuccess && rt >= 70200000) c->use_graph = false;
+  }
   memset(&c->last_stats, 0, sizeof c->last_stats);
   int rc = 0;
   do {
@@ -102,6 +116,8 @@ void cfdh_destroy(cfdh_ctx *c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->ev_h) (void)hipEventDestroy(c->ev_h);
   if (c->h_big) (void)hipHostFree(c->h_big);
+  if (c->h_ring) (void)hipHostFree(c->h_ring);
+  for (hipEvent_t e : c->ev_ring) if (e) (void)hipEventDestroy(e);
   hipStream_t s = c->stream;
   delete c;
   if (s) (void)hipStreamDestroy(s);
@@ -682,6 +698,7 @@ int cfdh_profile_reset(cfdh_ctx *c) {
   prof_flush(c);
   for (auto &p : c->prof) { p.total_ms = 0; p.launches = 0; }
   c->n_allreduce = c->n_halo = c->n_host_sync = c->n_krylov = c->n_allgather = 0;
+  c->n_krylov_discarded = 0;
   return 0;
 }
 
@@ -721,6 +738,7 @@ int64_t cfdh_info(const cfdh_ctx *c, int what) {
     case 70: return c->n_guess_solves;  // linear solves started from a projected guess (cfdh_options.ksp_guess)
     case 71: return c->n_guess_solves ? (int64_t)(1e6 * c->guess_reduction_sum / (double)c->n_guess_solves) : 0;  // mean |r0| / |b| of those, in 1e-6
     case 29: return c->nloc;
+    case 73: return c->n_krylov_discarded;  // FGMRES iterations launched ahead of the host's convergence test and discarded (not in krylov_its)
     case 72: return c->n_attainable_stops;  // solves stopped at the attainable accuracy (reason CFDH_KSP_CONVERGED_ATTAINABLE), above their tolerance
     case 27: return (int64_t)(1000.0 * c->ms_pc_build_dev);  // microseconds of the last device-side preconditioner build (0: host build)
     case 19: return c->opt.pc_type == 1 ? c->hL.nnz_S0 : c->hS.nnz_S0;

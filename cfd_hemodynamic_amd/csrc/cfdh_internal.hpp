@@ -250,6 +250,13 @@ struct cfdh_ctx {
   const double *mirror_src = nullptr;  // device scalars whose host-mapped copy is current (see read_scalars)
   int mirror_cnt = 0;
   hipEvent_t ev_h = nullptr;   // marks 'Gram-Schmidt coefficients are in h_pinned'
+  // FGMRES read-back ring: the host processes the Gram-Schmidt coefficients of an iteration up to KRING - 2 iterations after it
+  // was launched (cfdh_fgmres), so every iteration in flight owns a slot of host-mapped memory and an event
+  static constexpr int KRING = 12;
+  double *h_ring = nullptr, *h_ring_dev = nullptr;
+  size_t h_ring_stride = 0;
+  hipEvent_t ev_ring[KRING] = {};
+  long long n_krylov_discarded = 0;  // iterations launched ahead of the convergence test and thrown away (cfdh_info 73)
   int red_blocks = 0;
 
   // Krylov workspace
@@ -458,12 +465,12 @@ int v_dot(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host
 int v_norm2(cfdh_ctx *c, int n, const double *x, double *out_host);
 int v_norminf_diff(cfdh_ctx *c, int n, const double *x, const double *y, double *out_host);  // y may be null
 int v_sub_mean(cfdh_ctx *c, int n, double *p);  // remove the (global) mean of p[0..n)
-int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror = false,
-               bool reduce_ranks = true);
+int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, double *mirror = nullptr,
+               bool reduce_ranks = true);  // mirror: device view of host-mapped memory that receives the reduced values as well
 int v_scale_to(cfdh_ctx *c, int n, double a, const double *x, double *y);  // y = a x
-int v_multidot32(cfdh_ctx *c, int n, const float *V, int ld, int nvec, const double *w, double *h_dev);  // fp32 copy of the basis
+int v_multidot32(cfdh_ctx *c, int n, const float *V, int ld, int nvec, const double *w, double *h_dev, double *mirror);  // fp32 copy of the basis
 int v_gs_update32(cfdh_ctx *c, int n, const float *V, int ld, int nvec, const double *h_dev, const double *w, double *vn, float *v32n,
-                  double *s_dev, int mirror_slot);
+                  double *s_dev, double *mirror);
 int v_store32(cfdh_ctx *c, int n, const double *v, float *v32);
 int v_gram(cfdh_ctx *c, int n, const double *W, int ld, int k, const double *b, double *out_dev);  // out[8 i + q] = W_q . (W_i | b), rank-local
 int v_multiaxpy(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *h_dev, double *w);  // w -= sum h_i V_i

@@ -2118,7 +2118,7 @@ __global__ __launch_bounds__(TPB) void gram_kernel(int n, const double *__restri
 int v_gram(cfdh_ctx *c, int n, const double *W, int ld, int k, const double *b, double *out_dev) {
   const int nb = MD_NB, nout = 8 * (k + 1);
   if (k < 2 || k > 4 || (size_t)nout * nb > c->red_partial.n) {
-    for (int i = 0; i <= k; i++) CHK(v_multidot(c, n, W, ld, k, i < k ? W + (size_t)i * ld : b, out_dev + (size_t)i * 8, false, false, false));
+    for (int i = 0; i <= k; i++) CHK(v_multidot(c, n, W, ld, k, i < k ? W + (size_t)i * ld : b, out_dev + (size_t)i * 8, false, nullptr, false));
     return 0;
   }
   if (k == 2) hipLaunchKernelGGL((gram_kernel<2>), dim3(nb), dim3(TPB), 0, c->stream, n, W, (size_t)ld, b, c->red_partial.p, nb);
@@ -2131,19 +2131,20 @@ int v_gram(cfdh_ctx *c, int n, const double *W, int ld, int k, const double *b, 
 // (A "last block does the final reduction" variant was measured and dropped: the device-scope release fence every
 // block needs before taking its ticket writes the XCD's L2 back -- 133 us per launch against 17 + 4 us for two kernels.)
 // h_dev[0..nvec) = V^T w (and h_dev[nvec] = w.w when with_ww), reduced over all ranks
-int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, bool mirror, bool reduce_ranks) {
+int v_multidot(cfdh_ctx *c, int n, const double *V, int ld, int nvec, const double *w, double *h_dev, bool with_ww, double *mirror, bool reduce_ranks) {
   const int nb = MD_NB, nout = nvec + (with_ww ? 1 : 0);
   if ((size_t)nout * nb > c->red_partial.n) return cfdh_fail(c, CFDH_E_STATE, "multidot workspace too small");
   hipLaunchKernelGGL(multidot_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, w, c->red_partial.p, nb,
                      with_ww ? 1 : 0);
-  // single rank: the h values also land in the host-mapped scratch (c->h_pinned) straight from the kernel
-  double *mir = (mirror && c->nranks <= 1) ? c->h_pinned_dev : nullptr;
+  // single rank: the h values also land in host-mapped memory (`mirror`: device view of a slot of the FGMRES read-back ring)
+  // straight from the kernel
+  double *mir = (mirror && c->nranks <= 1) ? mirror : nullptr;
   hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(nout), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, h_dev, mir);
   HIPCHK(c, hipGetLastError());
   if (!reduce_ranks) return 0;  // the caller reduces several results over the ranks at once
   CHK(comm_allreduce_dev(c, h_dev, nout, 0));
   if (mirror && c->nranks > 1) {  // partitioned: publish the REDUCED coefficients the same way (behind the all-reduce)
-    hipLaunchKernelGGL(mirror_copy_kernel, dim3(1), dim3(TPB), 0, c->stream, nout, (const double *)h_dev, c->h_pinned_dev);
+    hipLaunchKernelGGL(mirror_copy_kernel, dim3(1), dim3(TPB), 0, c->stream, nout, (const double *)h_dev, mirror);
     HIPCHK(c, hipGetLastError());
   }
   return 0;
@@ -2261,16 +2262,16 @@ __global__ __launch_bounds__(TPB) void multidot32_kernel(int n, const float *__r
   }
 }
 // h_dev[0..nvec) = V32^T w, h_dev[nvec] = w.w (reduced over the ranks, mirrored like v_multidot)
-int v_multidot32(cfdh_ctx *c, int n, const float *V, int ld, int nvec, const double *w, double *h_dev) {
+int v_multidot32(cfdh_ctx *c, int n, const float *V, int ld, int nvec, const double *w, double *h_dev, double *mirror) {
   const int nb = MD_NB, nout = nvec + 1;
   if ((size_t)nout * nb > c->red_partial.n) return cfdh_fail(c, CFDH_E_STATE, "multidot workspace too small");
   hipLaunchKernelGGL(multidot32_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, w, c->red_partial.p, nb);
-  double *mir = c->nranks <= 1 ? c->h_pinned_dev : nullptr;
+  double *mir = c->nranks <= 1 ? mirror : nullptr;
   hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(nout), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, h_dev, mir);
   HIPCHK(c, hipGetLastError());
   CHK(comm_allreduce_dev(c, h_dev, nout, 0));
   if (c->nranks > 1) {
-    hipLaunchKernelGGL(mirror_copy_kernel, dim3(1), dim3(TPB), 0, c->stream, nout, (const double *)h_dev, c->h_pinned_dev);
+    hipLaunchKernelGGL(mirror_copy_kernel, dim3(1), dim3(TPB), 0, c->stream, nout, (const double *)h_dev, mirror);
     HIPCHK(c, hipGetLastError());
   }
   return 0;
@@ -2318,20 +2319,20 @@ int v_store32(cfdh_ctx *c, int n, const double *v, float *v32) {
   return 0;
 }
 // vn = (w - V32 h) / |w - V32 h| with its fp32 copy in v32n; s_dev[0] = that norm (reduced over the ranks), mirrored to
-// h_pinned[mirror_slot] for the host
+// the host-mapped word `mirror` for the host
 int v_gs_update32(cfdh_ctx *c, int n, const float *V, int ld, int nvec, const double *h_dev, const double *w, double *vn, float *v32n,
-                  double *s_dev, int mirror_slot) {
+                  double *s_dev, double *mirror) {
   const int nb = vgrid(n) > c->red_blocks ? c->red_blocks : vgrid(n);
   double *part = c->red_partial.p + (size_t)(MD_NB) * 8;  // behind the first multi-dot groups (the stream serialises the users)
   hipLaunchKernelGGL(gs_update32_kernel, dim3(nb), dim3(TPB), 0, c->stream, n, V, (size_t)ld, nvec, h_dev, w, vn, part);
   if (c->nranks <= 1) {  // square root and host-mapped copy in the reduction kernel itself
-    hipLaunchKernelGGL(reduce_final_kernel<2>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, part, s_dev, c->h_pinned_dev + mirror_slot);
+    hipLaunchKernelGGL(reduce_final_kernel<2>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, part, s_dev, mirror);
   } else {
     hipLaunchKernelGGL(reduce_final_kernel<0>, dim3(1), dim3(TPB), 0, c->stream, nb, nb, part, s_dev, (double *)nullptr);
     HIPCHK(c, hipGetLastError());
     CHK(comm_allreduce_dev(c, s_dev, 1, 0));
     hipLaunchKernelGGL(sqrt_kernel, dim3(1), dim3(1), 0, c->stream, s_dev);
-    hipLaunchKernelGGL(mirror_copy_kernel, dim3(1), dim3(TPB), 0, c->stream, 1, (const double *)s_dev, c->h_pinned_dev + mirror_slot);
+    hipLaunchKernelGGL(mirror_copy_kernel, dim3(1), dim3(TPB), 0, c->stream, 1, (const double *)s_dev, mirror);
   }
   hipLaunchKernelGGL(scale_store32_kernel, dim3(vgrid(n)), dim3(TPB), 0, c->stream, n, vn, (const double *)s_dev, v32n);
   HIPCHK(c, hipGetLastError());

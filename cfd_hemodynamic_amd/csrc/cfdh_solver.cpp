@@ -669,6 +669,12 @@ static int ensure_krylov(cfdh_ctx *c) {
   // cfdh_set_options), whatever the restart length
   HIPCHK(c, c->kh.alloc(std::max(2 * (size_t)(m + 2) + 8, (size_t)8 * (8 + 1))));
   HIPCHK(c, c->ky.alloc(m + 8));
+  // read-back ring of the iterations in flight: host-mapped slots of [h_0 .. h_j, w.w, measured norm] and one event each
+  if (c->h_ring) { (void)hipHostFree(c->h_ring); c->h_ring = nullptr; }
+  c->h_ring_stride = ((size_t)m + 5) & ~(size_t)1;
+  HIPCHK(c, hipHostMalloc((void **)&c->h_ring, sizeof(double) * c->h_ring_stride * (cfdh_ctx::KRING + 1)));  // + one slot: staging of y
+  HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_ring_dev, c->h_ring, 0));
+  for (auto &e : c->ev_ring) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(c, c->kV.zero(c->stream)); HIPCHK(c, c->kZ.zero(c->stream)); HIPCHK(c, c->kw.zero(c->stream));
   if ((size_t)(m + 2) * 1024 > c->red_partial.n) HIPCHK(c, c->red_partial.alloc((size_t)(m + 2) * 1024 + 1024));
   c->kry_m = m;
@@ -928,85 +934,150 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
     first = false;
     std::fill(g.begin(), g.end(), 0.0);
     g[0] = beta;
-    int j = 0;
+    // ---- one cycle.  The device needs nothing from the host to go from one iteration to the next (the Gram-Schmidt update forms
+    // its own scale from the reduced coefficients), so iterations are LAUNCHED ahead of the host's bookkeeping: every iteration in
+    // flight publishes [h_0..h_j, w.w, (measured norm)] into its own slot of a host-mapped ring behind an event, and the host
+    // catches up -- Hessenberg column, Givens rotation, convergence test -- in batches, always leaving one iteration running so
+    // that the GPU never waits for the host.  How far to run ahead follows from the convergence rate seen so far (iterations the
+    // tolerance is still away at the current contraction factor, at most KRING - 3): an iteration launched beyond the one that
+    // converges is discarded (x uses the columns up to convergence only) and counted (cfdh_info 73).  Solves that decide a second
+    // Gram-Schmidt pass per vector (ksp_rtol < 1e-7, long cycles after the watchdog tripped) stay synchronous; the rare
+    // cancellation case (|w'|^2 < 1e-2 |w|^2) refines the vector when the host sees it and re-launches what ran ahead of it.
+    static const int refine_env = getenv("CFDH_GS_REFINE_FROM") ? atoi(getenv("CFDH_GS_REFINE_FROM")) : -1;
+    static const int lag_env = getenv("CFDH_KSP_LAG") ? atoi(getenv("CFDH_KSP_LAG")) : cfdh_ctx::KRING - 3;
+    const int refine_from = refine_env >= 0 ? refine_env : (c->gs_refine_long ? 24 : (1 << 30));
+    const int lagmax = (o.ksp_rtol < 1e-7 || c->prof_on) ? 0 : std::max(0, std::min(lag_env, cfdh_ctx::KRING - 3));
+    const int its_base = its;
+    const int maxl = std::min(m, o.ksp_max_it - its_base);  // iterations this cycle may run
+    int j = 0;    // iterations processed by the host (complete Hessenberg columns)
+    int jl = 0;   // iterations launched
+    // expected length of this solve: the last solve with the same Newton index took guess_last_its iterations (0: unknown)
+    const int e_its = (gslot >= 0 && gslot < cfdh_ctx::GUESS_NEWTON) ? c->guess_last_its[gslot] : 0;
+    // iterations still needed, counted from iteration j: from the history alone before any residual of this cycle is known,
+    // afterwards the smaller of the rate-based prediction and what the history leaves
+    int need = std::max(1, std::min(e_its - its - 2, 3));
+    double res_hist[4] = {beta, 0, 0, 0};
+    int nhist = 1;
     bool done = false;
-    for (; j < m && its < o.ksp_max_it; j++) {
-      double *vj = V + (size_t)j * ld, *zj = Z + (size_t)j * ld, *vn = V + (size_t)(j + 1) * ld;
+    double *s_dev = hd + 2 * (m + 2) + 1;
+    const size_t rs = c->h_ring_stride;
+    auto launch = [&](int jj) -> int {
+      double *vj = V + (size_t)jj * ld, *zj = Z + (size_t)jj * ld, *vn = V + (size_t)(jj + 1) * ld;
+      double *slot = c->h_ring_dev + (size_t)(jj % cfdh_ctx::KRING) * rs;
       CHK(cfdh_pc_apply(c, vj, zj));
       CHK(comm_halo(c, zj));
       CHK(k_spmv_full(c, zj, w));
-      // classical Gram-Schmidt (PETSc's default for (F)GMRES) with one re-orthogonalisation
-      // pass only when cancellation demands it (|w'|^2 < 1e-5 |w|^2, judged from
-      // |w'|^2 = |w|^2 - |h|^2): h = [V^T w ; w.w] comes from ONE fused multi-dot
-      double *s_dev = hd + 2 * (m + 2) + 1;
-      const int s_slot = m + 8;  // host-mapped slot of the measured norm (fp32 copy in use)
+      // classical Gram-Schmidt (PETSc's default for (F)GMRES): h = [V^T w ; w.w] comes from ONE fused multi-dot
       if (use32) {
         // the same Gram-Schmidt step against the fp32 copy: h = V32^T w, v_{j+1} = (w - V32 h) / |w - V32 h| with the norm
         // MEASURED (the identity below needs columns that are orthonormal to round-off); both the fp64 vector (input of the
         // next preconditioner application) and its fp32 copy are written
-        CHK(v_multidot32(c, n, V32, (int)ld32, j + 1, w, hd));
-        CHK(v_gs_update32(c, n, V32, (int)ld32, j + 1, hd, w, vn, V32 + (size_t)(j + 1) * ld32, s_dev, s_slot));
-        HIPCHK(c, hipEventRecord(c->ev_h, c->stream));
+        CHK(v_multidot32(c, n, V32, (int)ld32, jj + 1, w, hd, slot));
+        CHK(v_gs_update32(c, n, V32, (int)ld32, jj + 1, hd, w, vn, V32 + (size_t)(jj + 1) * ld32, s_dev, slot + (jj + 2)));
+        HIPCHK(c, hipEventRecord(c->ev_ring[jj % cfdh_ctx::KRING], c->stream));
       } else {
-        CHK(v_multidot(c, n, V, (int)ld, j + 1, w, hd, true, true));
-        // h (all-reduced in a partitioned run) sits in the host-mapped scratch: wait for THAT only, the update of w
-        // below overlaps with the host's Hessenberg bookkeeping and the next launches
-        HIPCHK(c, hipEventRecord(c->ev_h, c->stream));
+        CHK(v_multidot(c, n, V, (int)ld, jj + 1, w, hd, true, slot));
+        // h (all-reduced in a partitioned run) sits in the host-mapped slot: the event marks THAT; the update of w below
+        // overlaps with the host's Hessenberg bookkeeping and the next launches
+        HIPCHK(c, hipEventRecord(c->ev_ring[jj % cfdh_ctx::KRING], c->stream));
         // v_{j+1} = (w - V h) / s with s = sqrt(w.w - |h|^2) formed on the device from the reduced coefficients: update and
         // normalisation in one pass (the host forms the same norm for the Hessenberg matrix from its copy of h)
-        CHK(v_gs_update_normalize(c, n, V, (int)ld, j + 1, hd, w, vn, s_dev));
+        CHK(v_gs_update_normalize(c, n, V, (int)ld, jj + 1, hd, w, vn, s_dev));
       }
+      return 0;
+    };
+    while (!done && reason == 0) {
+      // launch: one iteration beyond the batch the host will process next stays in flight, unless the batch is predicted to
+      // contain the converging iteration
+      const bool sync_now = lagmax == 0 || j >= refine_from;
+      // (one short of the prediction when it is long: the last predicted iteration is confirmed before anything follows it)
+      const int ahead = sync_now ? 1 : std::max(1, std::min(need - (need >= 4 ? 1 : 0), lagmax + 1));   // iterations wanted in flight
+      while (jl < maxl && jl - j < ahead) { CHK(launch(jl)); jl++; }
+      if (jl == j) break;  // cycle full (restart) or iteration cap
+      // process: everything launched if that may finish the solve / the cycle, otherwise all but the newest
+      int upto = jl;
+      if (!sync_now && jl - j > 1 && jl < maxl && need > jl - j) upto = jl - 1;
       c->n_host_sync++;
-      HIPCHK(c, hipEventSynchronize(c->ev_h));
-      double ww = c->h_pinned[j + 1], hh2 = 0.0;
-      for (int i = 0; i <= j; i++) { hh[i] = c->h_pinned[i]; hh2 += hh[i] * hh[i]; }
-      double nrm2 = use32 ? c->h_pinned[s_slot] * c->h_pinned[s_slot] : ww - hh2;
-      // PETSc's default never refines.  Here: tolerances down to ~1e-7 refine only when two digits
-      // cancel; tighter solves (parity runs at 1e-10) use the DGKS criterion (|w'| < |w|/sqrt(2)),
-      // because classical Gram-Schmidt then loses the orthogonality the deep convergence needs
-      // ... and so can a long Krylov cycle: beyond ~two dozen vectors the unrefined basis may drift far enough from
-      // orthogonality that the least-squares solution picks up huge spurious components (Newton corrections ten times
-      // the size of the iterate on the tree domain, config 5) although the residual norm looks converged.  Paying the
-      // second pass on every long cycle costs 14 % of a 3-D step whose 47-vector cycles never need it, so it is switched
-      // on by the watchdog above (CFDH_GS_REFINE_FROM=<j> forces it from vector j on)
-      static const int refine_env = getenv("CFDH_GS_REFINE_FROM") ? atoi(getenv("CFDH_GS_REFINE_FROM")) : -1;
-      const int refine_from = refine_env >= 0 ? refine_env : (c->gs_refine_long ? 24 : (1 << 30));
-      const double eta2 = (o.ksp_rtol < 1e-7 || j >= refine_from) ? 0.5 : 1e-2;
-      bool refine = !(nrm2 > eta2 * ww);
-      double hnorm;
-      if (refine) {
-        // second Gram-Schmidt pass on the (already scaled) vector: vn = w'/s  ->  h2 = V^T vn, vn -= V h2, vn /= |vn|;
-        // in terms of w: h += s h2, |w''| = s |vn|
-        CHK(v_multidot(c, n, V, (int)ld, j + 1, vn, hd + (m + 2), false));
-        CHK(v_multiaxpy(c, n, V, (int)ld, j + 1, hd + (m + 2), vn));
-        CHK(v_norm_to_dev(c, n, vn, hd + 2 * (m + 2)));
-        HIPCHK(c, hipMemcpyAsync(c->h_pinned, hd + (m + 2), sizeof(double) * (m + 4), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const double s = c->h_pinned[m + 3];
-        for (int i = 0; i <= j; i++) hh[i] += s * c->h_pinned[i];
-        hnorm = s * c->h_pinned[m + 2];
-        CHK(v_scale_inv_dev(c, n, vn, hd + 2 * (m + 2), vn));
-        if (use32) CHK(v_store32(c, n, vn, V32 + (size_t)(j + 1) * ld32));
-      } else {
-        hnorm = std::sqrt(nrm2);
+      HIPCHK(c, hipEventSynchronize(c->ev_ring[(upto - 1) % cfdh_ctx::KRING]));
+      for (; j < upto && !done; ) {
+        const double *hs = c->h_ring + (size_t)(j % cfdh_ctx::KRING) * rs;
+        double *vn = V + (size_t)(j + 1) * ld;
+        double ww = hs[j + 1], hh2 = 0.0;
+        for (int i = 0; i <= j; i++) { hh[i] = hs[i]; hh2 += hh[i] * hh[i]; }
+        double nrm2 = use32 ? hs[j + 2] * hs[j + 2] : ww - hh2;
+        // PETSc's default never refines.  Here: tolerances down to ~1e-7 refine only when two digits
+        // cancel; tighter solves (parity runs at 1e-10) use the DGKS criterion (|w'| < |w|/sqrt(2)),
+        // because classical Gram-Schmidt then loses the orthogonality the deep convergence needs
+        // ... and so can a long Krylov cycle: beyond ~two dozen vectors the unrefined basis may drift far enough from
+        // orthogonality that the least-squares solution picks up huge spurious components (Newton corrections ten times
+        // the size of the iterate on the tree domain, config 5) although the residual norm looks converged.  Paying the
+        // second pass on every long cycle costs 14 % of a 3-D step whose 47-vector cycles never need it, so it is switched
+        // on by the watchdog above (CFDH_GS_REFINE_FROM=<j> forces it from vector j on)
+        // (at the reference's tolerance: only when three digits cancel -- one classical pass then leaves an orthogonality
+        // error of ~1e3 eps, far below rtol 1e-5.  With a good preconditioner w = J M^-1 v_j is close to v_j, so a threshold of
+        // 1e-2 -- rounds 2 and 3 -- sent a third of all iterations of the headline run through the second pass for nothing.)
+        static const double eta2_env = getenv("CFDH_GS_ETA2") ? atof(getenv("CFDH_GS_ETA2")) : 1e-6;
+        const double eta2 = (o.ksp_rtol < 1e-7 || j >= refine_from) ? 0.5 : eta2_env;
+        const bool refine = !(nrm2 > eta2 * ww);
+        double hnorm;
+        if (refine) {
+          // second Gram-Schmidt pass on the (already scaled) vector: vn = w'/s  ->  h2 = V^T vn, vn -= V h2, vn /= |vn|;
+          // in terms of w: h += s h2, |w''| = s |vn|.  The coefficients and the squared norm of the corrected vector travel
+          // in ONE reduction over the ranks: [h2 ; vn.vn] from one fused multi-dot, |vn - V h2|^2 = vn.vn - |h2|^2 (the basis is
+          // orthonormal to round-off here -- the fp32 copy measures its norm instead)
+          if (jl > j + 1) { c->n_krylov_discarded += jl - (j + 1); jl = j + 1; }  // what ran ahead used the unrefined vector
+          CHK(v_multidot(c, n, V, (int)ld, j + 1, vn, hd + (m + 2), true));
+          CHK(v_multiaxpy(c, n, V, (int)ld, j + 1, hd + (m + 2), vn));
+          if (use32) CHK(v_norm_to_dev(c, n, vn, hd + 2 * (m + 2)));
+          HIPCHK(c, hipMemcpyAsync(c->h_pinned, hd + (m + 2), sizeof(double) * (m + 4), hipMemcpyDeviceToHost, c->stream));
+          c->n_host_sync++;
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          // scale of the first pass, formed exactly as gs_update_normalize_kernel forms it (the device word s_dev may belong to
+          // an iteration that ran ahead by now); the fp32 path measured it: slot word j + 2
+          const double s = use32 ? hs[j + 2] : ((nrm2 > 0.0 && nrm2 <= ww) ? std::sqrt(nrm2) : std::sqrt(ww));
+          double h22 = 0.0;
+          for (int i = 0; i <= j; i++) { hh[i] += s * c->h_pinned[i]; h22 += c->h_pinned[i] * c->h_pinned[i]; }
+          double vnorm;
+          if (use32) vnorm = c->h_pinned[m + 2];
+          else {
+            const double d2 = c->h_pinned[j + 1] - h22;
+            vnorm = d2 > 0.0 ? std::sqrt(d2) : 0.0;
+          }
+          hnorm = s * vnorm;
+          if (use32) { CHK(v_scale_inv_dev(c, n, vn, hd + 2 * (m + 2), vn)); CHK(v_store32(c, n, vn, V32 + (size_t)(j + 1) * ld32)); }
+          else CHK(v_scale(c, n, vnorm > 0.0 ? 1.0 / vnorm : 0.0, vn));
+        } else {
+          hnorm = std::sqrt(nrm2);
+        }
+        double *Hj = &H[(size_t)j * (m + 1)];
+        for (int i = 0; i <= j; i++) Hj[i] = hh[i];
+        Hj[j + 1] = hnorm;
+        for (int i = 0; i < j; i++) {
+          const double t = cs[i] * Hj[i] + sn[i] * Hj[i + 1];
+          Hj[i + 1] = -sn[i] * Hj[i] + cs[i] * Hj[i + 1];
+          Hj[i] = t;
+        }
+        const double d = std::hypot(Hj[j], Hj[j + 1]);
+        if (!(d > 0) || !std::isfinite(d)) { reason = -9; j++; break; }
+        cs[j] = Hj[j] / d; sn[j] = Hj[j + 1] / d;
+        Hj[j] = d; Hj[j + 1] = 0.0;
+        g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
+        its++;
+        j++;
+        const double res = std::fabs(g[j]);
+        if (o.verbose > 1) fprintf(stderr, "[cfdh]     fgmres %3d  |r|/|b| = %.3e\n", its, res / bn);
+        if (res <= tol) { done = true; break; }
+        // iterations the tolerance is away at the contraction factor of the last (up to three) iterations
+        if (nhist < 4) res_hist[nhist++] = res;
+        else { res_hist[0] = res_hist[1]; res_hist[1] = res_hist[2]; res_hist[2] = res_hist[3]; res_hist[3] = res; }
+        const double rho = std::pow(res / res_hist[0], 1.0 / (nhist - 1));
+        int n_rem = (rho > 0.0 && rho < 0.97) ? (int)std::ceil(std::log(tol / res) / std::log(rho)) : (1 << 20);
+        if (nhist == 2) n_rem = std::min(n_rem, 3);  // one sample of the rate: a short look ahead only
+        need = std::max(1, e_its > 0 ? std::min(n_rem, std::max(e_its - its, 1) + 2) : n_rem);
       }
-      double *Hj = &H[(size_t)j * (m + 1)];
-      for (int i = 0; i <= j; i++) Hj[i] = hh[i];
-      Hj[j + 1] = hnorm;
-      for (int i = 0; i < j; i++) {
-        const double t = cs[i] * Hj[i] + sn[i] * Hj[i + 1];
-        Hj[i + 1] = -sn[i] * Hj[i] + cs[i] * Hj[i + 1];
-        Hj[i] = t;
-      }
-      const double d = std::hypot(Hj[j], Hj[j + 1]);
-      if (!(d > 0) || !std::isfinite(d)) { reason = -9; done = true; j++; break; }
-      cs[j] = Hj[j] / d; sn[j] = Hj[j + 1] / d;
-      Hj[j] = d; Hj[j + 1] = 0.0;
-      g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
-      its++;
-      if (o.verbose > 1) fprintf(stderr, "[cfdh]     fgmres %3d  |r|/|b| = %.3e\n", its, std::fabs(g[j + 1]) / bn);
-      if (std::fabs(g[j + 1]) <= tol) { j++; done = true; break; }
+      if (done || reason != 0) break;
     }
+    if (jl > j) c->n_krylov_discarded += jl - j;  // launched ahead of the converging iteration: not part of the solution
     if (reason == -9) break;
     // y = H^-1 g ; x += Z y
     for (int i = j - 1; i >= 0; i--) {
@@ -1014,9 +1085,12 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
       for (int k = i + 1; k < j; k++) s -= H[(size_t)k * (m + 1) + i] * y[k];
       y[i] = s / H[(size_t)i * (m + 1) + i];
     }
-    HIPCHK(c, hipMemcpyAsync(c->ky.p, y.data(), sizeof(double) * j, hipMemcpyHostToDevice, c->stream));
+    // y travels through a pinned slot behind the ring (no stream synchronisation: the slot is rewritten at the end of the next
+    // cycle at the earliest, after events recorded behind this copy have been waited for)
+    double *ystage = c->h_ring + c->h_ring_stride * cfdh_ctx::KRING;
+    for (int i = 0; i < j; i++) ystage[i] = y[i];
+    HIPCHK(c, hipMemcpyAsync(c->ky.p, ystage, sizeof(double) * j, hipMemcpyHostToDevice, c->stream));
     CHK(v_lincomb(c, n, Z, (int)ld, j, c->ky.p, x));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // y is a host temporary
     est_prev = std::fabs(g[j]);
     j_prev = j;
     (void)done;
