@@ -481,6 +481,7 @@ def main():
         # FGMRES solves that the attainable-accuracy rule ended ABOVE their tolerance (reason CFDH_KSP_CONVERGED_ATTAINABLE, cfdh_info 72;
         # DESIGN.md section 6): 0 means every solve of this context so far met rtol |b| on the true residual
         "solves_stopped_at_attainable_accuracy": int(ctx.info(72)),
+        "pressure_level1_rows": int(ctx.info(23)),  # rows of level 1 of the pressure hierarchy: the coarse right-hand side a partitioned run all-reduces
         "setup_s": t_setup,
         # the reference's literal loop `u_prev.x.array[:] = u_sol.x.array[:]` (scenario.py:306-307): the lazy array proxy maps
         # that idiom to a device copy, so no field crosses PCIe in it

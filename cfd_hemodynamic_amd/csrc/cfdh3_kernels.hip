@@ -216,9 +216,10 @@ __global__ __launch_bounds__(TPB, CFDH3_ASMQ_OCC) void asm3q_kernel(Asm3Args p) 
   __syncthreads();
   const int nv = p.nv;
   const double rho = p.rho, mu = p.mu, idt = 1.0 / p.dt, th = p.theta, a0idt = p.a0 * idt;
-  const int i0 = p.blk_iptr[blk], i1 = p.blk_iptr[blk + 1];
-  for (int base = i0; base < i1; base += TPB / 4) {
-    const int inc_raw = base + (t >> 2);
+  // each wavefront walks its own list of incidences (whole rows: cfdh3_setup.cpp), 16 quads at a time; no barrier inside the loop
+  const int i0 = p.blk_iptr[4 * blk + (t >> 6)], i1 = p.blk_iptr[4 * blk + (t >> 6) + 1];
+  for (int base = i0; base < i1; base += 16) {
+    const int inc_raw = base + (lane >> 2);
     const bool valid = inc_raw < i1;  // a whole quad is valid or not; invalid quads recompute the last incidence and add nothing
     const int inc = valid ? inc_raw : i1 - 1;
     const int ca = p.inc_cell[inc], e = ca >> 2, a = ca & 3;

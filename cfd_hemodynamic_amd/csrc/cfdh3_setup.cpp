@@ -176,19 +176,38 @@ int cfdh_build_mesh3(cfdh_ctx *c, int64_t nv64, int64_t nvo64, int64_t nc64, con
       const int s0 = c->h_vptr[r0];
       while (r1 < nvo && c->h_vptr[r1 + 1] - s0 <= CFDH3_MAX_SLOTS && r1 - r0 < 64) r1++;
       if (r1 == r0) return cfdh_fail(c, CFDH_E_ARG, "row too long for one assembly workgroup");
-      for (int r = r0; r < r1; r++) {
-        const int *nb = &c->h_vcol[c->h_vptr[r]];
-        const int deg = c->h_vptr[r + 1] - c->h_vptr[r];
-        for (int k = vcptr[r]; k < vcptr[r + 1]; k++) {
-          const int e = vcell[k] >> 2;
-          unsigned long long sl = 0;
-          for (int b = 0; b < 4; b++) {
-            const int w = c->h_cells[4 * (size_t)e + b];
-            const unsigned long long s = (unsigned long long)(c->h_vptr[r] - s0 + (int)(std::lower_bound(nb, nb + deg, w) - nb));
-            sl |= s << (16 * b);
+      // The rows of a workgroup are dealt to its four wavefronts (longest first, to the least loaded wavefront: deterministic),
+      // and ALL incidences of a row are processed by the wavefront that got it.  Every LDS accumulator (row, column) then
+      // receives its contributions from one wavefront only, in program order (and in lane order inside one ds_add_f64
+      // instruction): a FIXED order -- the assembly is bitwise reproducible although it still sums in LDS.
+      std::vector<int> order(r1 - r0);
+      for (int r = r0; r < r1; r++) order[r - r0] = r;
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return vcptr[x + 1] - vcptr[x] > vcptr[y + 1] - vcptr[y]; });
+      std::vector<int> wrows[4];
+      int load[4] = {0, 0, 0, 0};
+      for (int r : order) {
+        int w = 0;
+        for (int q = 1; q < 4; q++) if (load[q] < load[w]) w = q;
+        wrows[w].push_back(r);
+        load[w] += vcptr[r + 1] - vcptr[r];
+      }
+      for (int w = 0; w < 4; w++) {
+        std::sort(wrows[w].begin(), wrows[w].end());
+        for (int r : wrows[w]) {
+          const int *nb = &c->h_vcol[c->h_vptr[r]];
+          const int deg = c->h_vptr[r + 1] - c->h_vptr[r];
+          for (int k = vcptr[r]; k < vcptr[r + 1]; k++) {
+            const int e = vcell[k] >> 2;
+            unsigned long long sl = 0;
+            for (int b = 0; b < 4; b++) {
+              const int wv = c->h_cells[4 * (size_t)e + b];
+              const unsigned long long sidx = (unsigned long long)(c->h_vptr[r] - s0 + (int)(std::lower_bound(nb, nb + deg, wv) - nb));
+              sl |= sidx << (16 * b);
+            }
+            inc_cell.push_back(vcell[k]); inc_row.push_back(r - r0); inc_slots.push_back(sl);
           }
-          inc_cell.push_back(vcell[k]); inc_row.push_back(r - r0); inc_slots.push_back(sl);
         }
+        if (w < 3) blk_iptr.push_back((int)inc_cell.size());  // [4 blk + w + 1]: end of wavefront w's list
       }
       blk_row.push_back(r1); blk_iptr.push_back((int)inc_cell.size());
       r0 = r1;

@@ -154,7 +154,11 @@ struct cfdh_ctx {
   // cfdh_gen.hip assemble (also for etype 0 when created as CFDH_ELEM_P1_GENERIC); "vertex" then means node everywhere below
   int etype = 0, nloc = 3;
   bool gen = false;
-  dbuf<int> gslot;             // [nc][nloc * nloc] value slot of the local node pair (a, b) in the vertex-graph arrays
+  dbuf<int> gslot;             // [nc][nloc * nloc] position of the block of the local node pair (a, b) in the staging array gE
+  // two-phase assembly of the generic elements (cfdh_gen.hip): staged element blocks / residual rows ordered by destination and
+  // the extents of every block entry / node in them
+  dbuf<int> g_eptr, g_fptr, g_fdst;   // [nnzv + 1], [nv + 1], [nc][nloc]
+  dbuf<double> gE, gEF;               // [nc nloc^2][9], [nc nloc][3]
   dbuf<unsigned short> gflag;  // [nc] bit f: exterior facet f, bit 8 + f: backflow facet f
   // P2: the P1 subspace as the first coarse level of both hierarchies (p-multigrid step): prolongator [nodes x vertex nodes],
   // 1 at a vertex node, 1/2 + 1/2 at an edge node (host copy; internal numbering)
@@ -320,6 +324,7 @@ struct cfdh_ctx {
   // owned + ghost columns), the coarse right-hand side is all-reduced and levels >= 1 stay replicated
   struct DistL0 {
     bool on = false;
+    bool ghost_rhs = true;  // exchange the ghost layer of the right-hand side before the pre-smoothing (false: pre-smoothed iterate zero on the ghosts)
     int n1 = 0;
     CsrDev A;      // owned rows x local (owned + ghost) columns
     CsrDev P;      // local rows (owned + ghost) x coarse columns

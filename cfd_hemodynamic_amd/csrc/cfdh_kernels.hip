@@ -1704,11 +1704,12 @@ static int amg_cycle_cheb(cfdh_ctx *c, AmgHier &H, size_t lev, const double *b, 
 // ---- distributed finest level of the replicated pressure hierarchy (cfdh_ctx::DistL0)
 // b_loc = pressure slot of a halo-layout vector on owned + ghost vertices; xa = w D^-1 b on all of them
 __global__ __launch_bounds__(TPB) void dl0_pack_kernel(int nvo, int nv, int dim, const double *__restrict__ vec, const double *__restrict__ wdinv,
-                                                       double *__restrict__ b, double *__restrict__ xa) {
+                                                       double *__restrict__ b, double *__restrict__ xa, int ghosts) {
   const int i = blockIdx.x * TPB + threadIdx.x;
   if (i >= nv) return;
   // pressure slot: owned at dim nvo + i, ghost record (u..., p) of dim + 1 doubles behind the owned part
-  const double v = i < nvo ? vec[(size_t)dim * nvo + i] : vec[((size_t)dim + 1) * nvo + ((size_t)dim + 1) * (size_t)(i - nvo) + dim];
+  // ghosts == 0: the ghost layer of the right-hand side was not exchanged -- the pre-smoothed iterate is taken as zero there
+  const double v = i < nvo ? vec[(size_t)dim * nvo + i] : (ghosts ? vec[((size_t)dim + 1) * nvo + ((size_t)dim + 1) * (size_t)(i - nvo) + dim] : 0.0);
   b[i] = v;
   xa[i] = wdinv[i] * v;
 }
@@ -1717,7 +1718,7 @@ int k_dl0_down(cfdh_ctx *c, const double *halo_vec) {
   cfdh_ctx::DistL0 &d = c->dl0;
   AmgLevel *N = c->hLg.lev[1];
   const int nvo = c->nvo, nv = c->nv;
-  hipLaunchKernelGGL(dl0_pack_kernel, dim3((nv + TPB - 1) / TPB), dim3(TPB), 0, c->stream, nvo, nv, c->dim, halo_vec, d.wdinv.p, d.b.p, d.xa.p);
+  hipLaunchKernelGGL(dl0_pack_kernel, dim3((nv + TPB - 1) / TPB), dim3(TPB), 0, c->stream, nvo, nv, c->dim, halo_vec, d.wdinv.p, d.b.p, d.xa.p, d.ghost_rhs ? 1 : 0);
   dim3 block(TPB), grid((unsigned)((8ll * nvo + TPB - 1) / TPB)), gridS((unsigned)((nvo + TPB - 1) / TPB));
   if (d.A.nnz <= 12ll * nvo && nvo >= 16384)  // short regular rows: SELL-64 (as the replicated level 0 would use)
     hipLaunchKernelGGL((sell_jacobi_pre_kernel<double>), gridS, block, 0, c->stream, nvo, d.A.sptr.p, d.A.scol.p, d.A.svalw.p,

@@ -364,3 +364,26 @@ def test_projected_initial_guess_on_tetrahedra(monkeypatch):
     assert n0 == 0 and n4 >= 12 and its4 < its0
     # (3-D: |F0| of a step carries the outlet-row misfit, so snes_rtol is loose in absolute terms -- DESIGN.md, "tolerance trap")
     assert np.linalg.norm(u4 - u0) <= 1e-6 * np.linalg.norm(u0) and np.linalg.norm(p4 - p0) <= 1e-5 * np.linalg.norm(p0)
+
+
+def test_tet_assembly_is_bitwise_reproducible():
+    """Round 4: the rows of an assembly workgroup are dealt to its wavefronts and every LDS accumulator receives its contributions
+    from one wavefront in program order, so the tetrahedral assembly gives the same bits in every pass and every context (rounds
+    2-3 summed in LDS-arrival order: reproducible to 1e-12 only).  Bifurcation mesh, ~36 k vertices."""
+    from cfd_hemodynamic_amd.mesh3d import create_bifurcation
+    mesh, ft = create_bifurcation(4e-4)
+    nv = mesh.num_vertices
+    rng = np.random.default_rng(21)
+    xv = 0.3 * rng.standard_normal(4 * nv)
+    un = 0.3 * rng.standard_normal((nv, 3))
+    bcs = _bifurcation_bcs(mesh, ft)
+    out = []
+    for _ in range(2):
+        _, ctx = _pair(mesh, 0.01, 1.0, 1.0 / 76.9, (0.0, 0.0, 0.0), bcs)
+        ctx.set_state(u_prev=un.ravel(), p_prev=np.zeros(nv), u=xv[: 3 * nv], p=xv[3 * nv:])
+        for _rep in range(3):
+            ctx.assemble(True)
+            out.append((np.concatenate(ctx.get_residual()), ctx.get_csr().data.copy()))
+        ctx.close()
+    for F, A in out[1:]:
+        assert np.array_equal(F, out[0][0]) and np.array_equal(A, out[0][1])

@@ -216,3 +216,68 @@ def test_unit_square_pipe_on_quadrilaterals(tmp_path):
     from cfd_hemodynamic_amd.scenarios import unit_square_pipe as usp
     full = usp.create_rectangle((0.0, 0.0), (usp._L, usp._H), (usp._NX, usp._NY))
     assert (usp._L, usp._H, usp._NX, usp._NY) == (80.0, 1.5, 587, 11) and full.num_vertices == 7056
+
+
+@pytest.mark.parametrize("kind", ["P2", "Q1"])
+def test_generic_assembly_is_bitwise_reproducible(kind):
+    """Round 4: the element blocks are staged by destination and summed in a fixed order (no atomics), so two passes -- and two
+    contexts -- give identical bits in the residual and in every CSR value."""
+    rng = np.random.default_rng(11)
+    m = node_mesh(kind, 40, distort=0.05)
+    nv = m.num_vertices
+    prm = T.Params(0.02, 1.3, 0.04, (0.2, -0.1))
+    bnd = facet_node_set(m, np.arange(m.num_facets))[::2]
+    vals = rng.standard_normal((len(bnd), 2))
+    xv, un = 0.3 * rng.standard_normal(3 * nv), 0.3 * rng.standard_normal((nv, 2))
+    out = []
+    for _ in range(2):
+        ctx = _ctx(kind, m, prm)
+        ctx.add_dirichlet(0, bnd, vals)
+        ctx.set_state(u_prev=un.ravel(), p_prev=np.zeros(nv), u=xv[: 2 * nv], p=xv[2 * nv:])
+        for _rep in range(2):
+            ctx.assemble(True)
+            out.append((np.concatenate(ctx.get_residual()), ctx.get_csr().data.copy()))
+        ctx.close()
+    for F, A in out[1:]:
+        assert np.array_equal(F, out[0][0]) and np.array_equal(A, out[0][1])
+
+
+@pytest.mark.parametrize("kind,n", [("P2", 92), ("Q1", 184)])
+def test_time_steps_match_the_twin_at_size(kind, n):
+    """At-size step parity for the SURVEY 8f-4 elements (missing 6): >= 100 k DOF, two steps of the channel
+    problem (parabolic inlet, no-slip walls, p = 0 outlet) from rest, device Newton + FGMRES + Cahouet-Chabard/AMG at tight
+    tolerances against the twin's Newton with a DIRECT sparse solve (C element routine)."""
+    m = node_mesh(kind, n)
+    nv = m.num_vertices
+    assert 3 * nv >= 100000
+    prm = T.Params(0.02, 1.0, 0.02, (0.0, 0.0))
+    mid = m.facet_midpoints()
+    top, bottom = np.nonzero(np.isclose(mid[:, 1], m.x[:, 1].max()))[0], np.nonzero(np.isclose(mid[:, 1], 0.0))[0]
+    left, right = np.nonzero(np.isclose(mid[:, 0], 0.0))[0], np.nonzero(np.isclose(mid[:, 0], m.x[:, 0].max()))[0]
+    walls = facet_node_set(m, np.concatenate([top, bottom]))
+    inl = np.setdiff1d(facet_node_set(m, left), walls)
+    y = m.x[inl, 1] / m.x[:, 1].max()
+    outn = facet_node_set(m, right)
+    pb = problem(kind, m, prm)
+    ctx = _ctx(kind, m, prm)
+    for fld, nodes, vals in [(0, walls, np.zeros((len(walls), 2))), (0, inl, np.stack([4 * y * (1 - y), 0 * y], 1)), (1, outn, np.zeros(len(outn)))]:
+        (pb.add_bc_u if fld == 0 else pb.add_bc_p)(nodes, vals)
+        ctx.add_dirichlet(fld, nodes, vals)
+    o = ctx.default_options()
+    o.snes_rtol, o.snes_stol, o.ksp_rtol = 1e-12, 0.0, 1e-10
+    ctx.set_options(o)
+    z2, z1 = np.zeros(2 * nv), np.zeros(nv)
+    ctx.set_state(u_prev=z2, p_prev=z1, u=z2, p=z1)
+    x, un = np.zeros(3 * nv), np.zeros((nv, 2))
+    for step in range(2):
+        st = ctx.solve_step()
+        assert st.reason > 0
+        u, p = ctx.get_solution()
+        ctx.advance()
+        x, _ = pb.newton(x, un)
+        un = x[: 2 * nv].reshape(-1, 2).copy()
+        assert np.abs(u - x[: 2 * nv]).max() <= 1e-8 * np.abs(x[: 2 * nv]).max(), (kind, step)
+        assert np.abs(p - x[2 * nv:]).max() <= 1e-7 * np.abs(x[2 * nv:]).max(), (kind, step)
+    nu_, np_ = pb.l2_norms(x)
+    assert abs(ctx.functional(2) - nu_) <= 1e-9 * nu_ and abs(ctx.functional(3) - np_) <= 1e-8 * np_
+    ctx.close()

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Strong-scaling model of the partitioned step from ONE-GPU measurements.
+
+No multi-GPU node was available in rounds 1-4, so the N > 1 numbers below are a MODEL, labelled as such, built only from
+  * a rocprofv3 kernel trace of `bench.py --config <cfg>` on one MI355X, summarised per (kernel, grid size)
+    (tools/profile_bench.sh -> kernel_stats_by_grid.csv) together with the bench line of the same run, and
+  * the communication counts per FGMRES iteration and the iteration-count ratio measured with N ranks sharing the one test GPU
+    through the RCCL stand-in (tests/fake_rccl; bench.py --gpus N with CFDH_SHARE_GPU=1),
+  * two ASSUMED latencies per collective (15 and 30 us: grouped ncclSend/ncclRecv halo, small all-reduce) and an assumed ring
+    all-reduce bandwidth for the one large message (coarse pressure right-hand side).
+
+Per kernel group g (name, grid) with average duration t_g on one GPU and c_g launches per FGMRES iteration:
+  scalable   (its rows are partitioned):            t_g(N) = L + (t_g - L) / N,   L = launch floor (min(t_g, 4.5 us))
+  replicated (levels >= 1 of the pressure cycle):   t_g(N) = t_g
+and every launch carries the inter-kernel gap measured on one GPU (wall-clock of the timed region minus the kernel time of the same
+steps, per launch).  T_iter(N) = sum_g c_g (t_g(N) + gap) + comm(N); a step is its(N) iterations plus the non-iteration kernels
+(assembly, moments, norms: scalable).  comm(N) = n_halo * lat + n_small_allreduce * lat + [lat + 2 (N-1)/N * bytes / BW] for the
+coarse right-hand side.
+
+  python tools/scaling_model.py <kernel_stats_by_grid.csv> <bench_line.json> <label> [counts.json] > model fragment (JSON)
+"""
+import csv
+import json
+import re
+import sys
+
+LAT_US = (15.0, 30.0)
+AR_BW_GBS = 100.0          # assumed effective ring all-reduce bandwidth over xGMI for a MB-sized message
+FLOOR_US = 4.5
+ITER_KERNEL = "gs_update_normalize_kernel"   # launched once per FGMRES iteration (gs_update32_kernel where the fp32 copy is used)
+
+
+def classify(name):
+    """(class, in_iteration).  Classes: 'scalable' | 'replicated' (decided per grid later for the pressure hierarchy) | 'setup'."""
+    n = name
+    if re.search(r"mis_|agg_|spgemm|gj_step|fold_dense|sort_rows|bin_rows|transpose|densify|trace_shift|sb_kernel|sc_kernel|vg_|formats|sell_build|csr_to|count_|fill_|scan", n):
+        return "setup", False
+    it = bool(re.search(r"fused_|sell_cheb2|spmv_full_kernel|spmv3_full_kernel|spmv_a01|spmv3_blk|spmv_blk|multidot|gs_update|reduce_final|store32|scale_store32|sub_scalar|sum_partial|cc_combine|cc_scale|dense_mv|jacobi|csr_spmv", n))
+    return "scalable", it
+
+
+def main():
+    stats, line_path, label = sys.argv[1], sys.argv[2], sys.argv[3]
+    counts = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else {}
+    line = json.load(open(line_path))
+    rows = []
+    with open(stats) as f:
+        for r in csv.DictReader(f):
+            rows.append((r["Name"], int(float(r["Grid"])), int(float(r["Calls"])), float(r["AverageNs"]) / 1e3))
+    iters = sum(c for n, g, c, t in rows if n.startswith(ITER_KERNEL) or n.startswith("gs_update32_kernel"))
+    if iters == 0:
+        raise SystemExit("no %s launches in %s" % (ITER_KERNEL, stats))
+    # pressure hierarchy, levels >= 1: the single-right-hand-side instantiations of the fused cycle kernels at every grid but the
+    # largest one of that kernel (level 0 is distributed in a partitioned run)
+    biggest = {}
+    for n, g, c, t in rows:
+        biggest[n] = max(biggest.get(n, 0), g)
+    groups = []
+    for n, g, c, t in rows:
+        cls, in_it = classify(n)
+        single_rhs = bool(re.search(r"fused_(down|up_csr|up_dense|up_sell)_kernel<", n)) and "HIP_vector_type" not in n and "d3" not in n
+        if cls == "scalable" and single_rhs and (g < biggest[n] or "up_dense" in n or "<64, double, double>" in n or "<32, double, double>" in n):
+            cls = "replicated"
+        groups.append({"kernel": n[:70], "grid": g, "calls": c, "avg_us": t, "class": cls, "per_iteration": in_it})
+    launches = sum(g["calls"] for g in groups if g["class"] != "setup")
+    kern_ms = sum(g["calls"] * g["avg_us"] for g in groups if g["class"] != "setup") / 1e3
+    steps_profiled = line["steps"] + line["warmup"]
+    # inter-kernel gap from the timed region of the same run: wall per step minus kernel time per step, per launch
+    its_step = line["krylov_its_per_step"]
+    per_it = [g for g in groups if g["per_iteration"] and g["class"] != "setup"]
+    other = [g for g in groups if not g["per_iteration"] and g["class"] != "setup"]
+    t_it1 = sum(g["calls"] * g["avg_us"] for g in per_it) / iters
+    l_it = sum(g["calls"] for g in per_it) / iters
+    steps_total = max(1.0, iters / max(its_step, 1e-9))   # steps the trace covers, from the iteration count
+    t_other1 = sum(g["calls"] * g["avg_us"] for g in other) / steps_total
+    l_other = sum(g["calls"] for g in other) / steps_total
+    wall_us = 1e3 * line["ms_per_step"]
+    gap = max(0.0, (wall_us - (its_step * t_it1 + t_other1)) / (its_step * l_it + l_other))
+    n_halo = counts.get("halo_per_iteration", 4.0)
+    n_small = counts.get("small_allreduce_per_iteration", 1.0)
+    big_bytes = counts.get("coarse_rhs_bytes", 8.0 * line.get("coarse_rows", 0))
+    its_ratio = counts.get("iteration_ratio", {"1": 1.0, "2": 1.0, "4": 1.2, "8": 1.2})
+    out = {"label": label, "workload": line["config"]["workload"][:120], "one_gpu": {
+        "ms_per_step_measured": line["ms_per_step"], "krylov_its_per_step": its_step, "kernel_us_per_iteration": t_it1,
+        "launches_per_iteration": l_it, "non_iteration_kernel_us_per_step": t_other1, "gap_us_per_launch": gap,
+        "replicated_us_per_iteration": sum(g["calls"] * g["avg_us"] for g in per_it if g["class"] == "replicated") / iters,
+        "floor_bound_launches_per_iteration": sum(g["calls"] for g in per_it if g["avg_us"] <= 1.6 * FLOOR_US) / iters},
+        "assumptions": {"latency_us": list(LAT_US), "allreduce_bandwidth_GBps": AR_BW_GBS, "launch_floor_us": FLOOR_US,
+                        "halo_per_iteration": n_halo, "small_allreduce_per_iteration": n_small, "coarse_rhs_bytes": big_bytes,
+                        "iteration_ratio": its_ratio}, "prediction": {}}
+
+    def t_group(g, N):
+        if g["class"] == "replicated" or N == 1:
+            return g["avg_us"]
+        L = min(g["avg_us"], FLOOR_US)
+        return L + (g["avg_us"] - L) / N
+
+    for lat in LAT_US:
+        pred = {}
+        for N in (1, 2, 4, 8):
+            t_it = sum(g["calls"] * (t_group(g, N) + gap) for g in per_it) / iters
+            comm = 0.0 if N == 1 else (n_halo + n_small) * lat + (lat + 2.0 * (N - 1) / N * big_bytes / (AR_BW_GBS * 1e3))
+            t_oth = sum(g["calls"] * (t_group(g, N) + gap) for g in other) / steps_total
+            its = its_step * float(its_ratio.get(str(N), 1.2))
+            step_us = its * (t_it + comm) + t_oth + (0.0 if N == 1 else 12 * lat)  # ~12 reductions / exchanges per step outside the iterations
+            pred[str(N)] = {"us_per_iteration": t_it + comm, "comm_us_per_iteration": comm, "ms_per_step": step_us / 1e3}
+        for N in ("2", "4", "8"):
+            pred[N]["speedup"] = pred["1"]["ms_per_step"] / pred[N]["ms_per_step"]
+        out["prediction"]["latency_%dus" % lat] = pred
+    out["groups"] = sorted(per_it, key=lambda g: -g["calls"] * g["avg_us"])[:24]
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
