@@ -154,11 +154,15 @@ class Context:
         x = np.asarray(x, dtype=np.float64)
         cells = np.asarray(cells)
         self.etype = int(etype)
-        self.dim = 2 if self.etype else cells.shape[1] - 1  # triangles -> 2, tetrahedra -> 3
+        # generic elements: the geometric dimension follows from the coordinates (P2: 6 nodes -> triangles, 10 -> tetrahedra;
+        # Q1: 4 -> quadrilaterals, 8 -> hexahedra; P1 through the generic kernels: 3 / 4)
+        self.dim = (3 if x.shape[1] >= 3 and cells.shape[1] in (8, 10) or (self.etype == 3 and cells.shape[1] == 4) else 2) if self.etype \
+            else cells.shape[1] - 1  # triangles -> 2, tetrahedra -> 3
         if self.dim not in (2, 3) or x.shape[1] < self.dim:
             raise ValueError("cells must be triangles [nc,3] or tetrahedra [nc,4] with matching coordinates")
-        if self.etype and cells.shape[1] != {1: 6, 2: 4, 3: 3}[self.etype]:
-            raise ValueError("element type %d needs %d nodes per cell" % (self.etype, {1: 6, 2: 4, 3: 3}[self.etype]))
+        nodes = {(1, 2): 6, (2, 2): 4, (3, 2): 3, (1, 3): 10, (2, 3): 8, (3, 3): 4}
+        if self.etype and cells.shape[1] != nodes[(self.etype, self.dim)]:
+            raise ValueError("element type %d needs %d nodes per cell for gdim %d" % (self.etype, nodes[(self.etype, self.dim)], self.dim))
         self.x = np.ascontiguousarray(x[:, : self.dim]).copy()
         self.cells = np.ascontiguousarray(cells, dtype=np.int32)
         self.nv = len(self.x)

@@ -810,6 +810,15 @@ __global__ __launch_bounds__(TPB) void flux3_kernel(int nfac, int marker, int nv
 int k3_functional(cfdh_ctx *c, int kind, int marker, double *out) {
   const int nb = 256;
   c->mirror_src = nullptr;
+  if (c->gen && (kind == 2 || kind == 3 || kind == 7)) {  // hexahedra / P2 tetrahedra: the element's own quadrature (cfdh_gen3.hip)
+    CHK(kg3_functional_partials(c, kind, marker, nb));
+    hipLaunchKernelGGL(final3_kernel, dim3(2), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p);
+    HIPCHK(c, hipGetLastError());
+    double v[2];
+    CHK(read2(c, v, 2));
+    *out = kind == 7 ? v[0] : sqrt(kind == 2 ? v[0] : v[1]);
+    return 0;
+  }
   if (kind == 2 || kind == 3) {
     hipLaunchKernelGGL(l2_3_kernel, dim3(nb), dim3(TPB), 0, c->stream, c->nc, c->nvo, c->cells.p, c->cell_owned.p, c->coords.p, c->x.p, c->red_partial.p);
     hipLaunchKernelGGL(final3_kernel, dim3(2), dim3(TPB), 0, c->stream, nb, nb, c->red_partial.p, c->red_out.p);

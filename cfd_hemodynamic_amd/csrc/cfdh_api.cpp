@@ -43,7 +43,6 @@ static int create_ctx(cfdh_ctx **out, int device, int gdim, int etype, int64_t n
   *out = nullptr;
   if (gdim != 2 && gdim != 3) return cfdh_fail(nullptr, CFDH_E_ARG, "gdim must be 2 (P1 triangles) or 3 (P1 tetrahedra)");
   if (etype < 0 || etype > 3) return cfdh_fail(nullptr, CFDH_E_ARG, "unknown element type %d", etype);
-  if (etype != 0 && gdim != 2) return cfdh_fail(nullptr, CFDH_E_ARG, "P2 / Q1 elements are implemented for gdim 2");
   if (etype != 0 && nv_owned != nv) return cfdh_fail(nullptr, CFDH_E_ARG, "P2 / Q1 contexts are single-GPU: nv_owned must equal nv");
   if (!cells || !coords || (nfacets > 0 && (!facet_cells || !facet_local)))
     return cfdh_fail(nullptr, CFDH_E_ARG, "null mesh array");
@@ -76,9 +75,10 @@ static int create_ctx(cfdh_ctx **out, int device, int gdim, int etype, int64_t n
     rc = gdim == 3 ? k3_upload_quadrature(c) : k_upload_quadrature(c);
     if (rc) break;
     if (etype != 0) {
-      rc = kg_upload_tables(c);
+      rc = gdim == 3 ? kg3_upload_tables(c) : kg_upload_tables(c);
       if (rc) break;
-      rc = cfdh_build_mesh_gen(c, etype, nv, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker);
+      rc = gdim == 3 ? cfdh_build_mesh_gen3(c, etype, nv, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker)
+                     : cfdh_build_mesh_gen(c, etype, nv, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker);
       break;
     }
     rc = gdim == 3 ? cfdh_build_mesh3(c, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker)

@@ -150,7 +150,7 @@ struct cfdh_ctx {
 
   // geometric dimension: 2 (triangles, 3x3 vertex blocks) or 3 (tetrahedra, 4x4 vertex blocks; single GPU)
   int dim = 2;
-  // element: 0 P1 simplices (closed-form kernels), 1 P2 triangles, 2 Q1 parallelograms -- `gen`: the quadrature kernels of
+  // element: 0 P1 simplices (closed-form kernels), 1 P2 triangles / tetrahedra, 2 Q1 parallelograms / parallelepipeds -- `gen`: the quadrature kernels of
   // cfdh_gen.hip assemble (also for etype 0 when created as CFDH_ELEM_P1_GENERIC); "vertex" then means node everywhere below
   int etype = 0, nloc = 3;
   bool gen = false;
@@ -427,6 +427,15 @@ int cfdh_facet_nodes(const cfdh_ctx *c, int f, int out[3]);  // local nodes of l
 int kg_assemble(cfdh_ctx *c, const double *xstate, int mode);
 int kg_functional_partials(cfdh_ctx *c, int kind, int marker, int nb);  // per-block partial sums into red_partial
 int kg_wss(cfdh_ctx *c, double *out);
+
+// ---- nodal elements beyond P1 in 3-D: Q1 hexahedra, P2 tetrahedra (cfdh_gen3.hip) -----------------
+int kg3_upload_tables(cfdh_ctx *c);
+int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv, int64_t nc, const int32_t *cells, const double *coords, int64_t nfac,
+                         const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker);
+int cfdh_facet_nodes3(const cfdh_ctx *c, int f, int out[8]);  // local nodes of local facet f of a 3-D cell; returns their number
+int kg3_assemble(cfdh_ctx *c, const double *xstate, int mode);
+int kg3_functional_partials(cfdh_ctx *c, int kind, int marker, int nb);
+int kg3_wss(cfdh_ctx *c, double *out);
 
 // ---- kernels (cfdh_kernels.hip) ----------------------------------------------------
 void prof_begin(cfdh_ctx *c, int kind);

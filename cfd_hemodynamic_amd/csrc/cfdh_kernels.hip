@@ -614,7 +614,7 @@ __global__ __launch_bounds__(CFDH_MAX_INC, OCC) void asm_kernel(AsmArgs p) {
 }
 
 int k_assemble(cfdh_ctx *c, const double *xstate, int mode) {
-  if (c->gen) return kg_assemble(c, xstate, mode);
+  if (c->gen) return c->dim == 3 ? kg3_assemble(c, xstate, mode) : kg_assemble(c, xstate, mode);
   if (c->dim == 3) return k3_assemble(c, xstate, mode);
   AsmArgs a;
   a.coords = c->coords.p; a.mom = c->mom.p; a.x = xstate; a.un = c->xprev.p; a.un2 = c->xprev2.p; a.bcval = c->bcval.p; a.bcmult = c->bcmult.p;
@@ -2565,7 +2565,7 @@ __global__ __launch_bounds__(TPB) void wss_kernel(int nfac, int nvo, const int *
   atomicAdd(out + 2 * (size_t)v2, Tt[0]); atomicAdd(out + 2 * (size_t)v2 + 1, Tt[1]);
 }
 int k_wss(cfdh_ctx *c, double *out) {
-  if (c->gen) return kg_wss(c, out);
+  if (c->gen) return c->dim == 3 ? kg3_wss(c, out) : kg_wss(c, out);
   if (c->dim == 3) return k3_wss(c, out);
   HIPCHK(c, hipMemsetAsync(out, 0, sizeof(double) * 2 * (size_t)c->nv, c->stream));
   if (c->nfac > 0)

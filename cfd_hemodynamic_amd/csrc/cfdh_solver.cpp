@@ -95,8 +95,8 @@ static void mark_outflow_nodes(const cfdh_ctx *c, std::vector<unsigned char> &pb
   const int nvo = c->nvo;
   for (int k = 0; k < c->nfac; k++) {
     const int e = c->fac_cell[k], fl = c->fac_local[k];
-    int loc[4], nn = 0;
-    if (c->gen) nn = cfdh_facet_nodes(c, fl, loc);
+    int loc[8], nn = 0;
+    if (c->gen) nn = c->dim == 3 ? cfdh_facet_nodes3(c, fl, loc) : cfdh_facet_nodes(c, fl, loc);
     else for (int q = 0; q <= c->dim; q++) if (q != fl) loc[nn++] = q;
     bool fixed = true;
     for (int q = 0; q < nn; q++) fixed = fixed && (c->h_bcflag[c->h_cells[(size_t)c->nloc * e + loc[q]]] & umask) == umask;

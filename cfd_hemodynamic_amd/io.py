@@ -44,6 +44,11 @@ class VTUWriter:
             conn, ctype = conn[:, [0, 1, 3, 2]], 9          # DOLFINx tensor-product order -> VTK's cyclic order
         elif npc == 6:
             conn, ctype = conn[:, [0, 1, 2, 5, 3, 4]], 22   # edge nodes: VTK wants (0-1), (1-2), (2-0); ours are opposite vertex 0, 1, 2
+        elif npc == 8:
+            conn, ctype = conn[:, [0, 1, 3, 2, 4, 5, 7, 6]], 12   # VTK_HEXAHEDRON: bottom face cyclic, then the top face
+        elif npc == 10:
+            # VTK_QUADRATIC_TETRA: edges (0-1) (1-2) (0-2) (0-3) (1-3) (2-3); ours (Basix): (2,3) (1,3) (1,2) (0,3) (0,2) (0,1)
+            conn, ctype = conn[:, [0, 1, 2, 3, 9, 6, 8, 7, 5, 4]], 24
         arrays = [pts.ravel(), np.ascontiguousarray(conn).ravel(),
                   (npc * np.arange(1, nc + 1)).astype(np.int32), np.full(nc, ctype, dtype=np.uint8), data.ravel()]
         offs, blob = [], bytearray()

@@ -219,7 +219,7 @@ def locate_entities_boundary(mesh, dim, marker):
     X = mesh.geometry.x.T  # [3,nv]
     ok = np.asarray(marker(X), dtype=bool)
     fv = mesh.facet_vertices
-    sel = ok[fv[:, 0]] & ok[fv[:, 1]]
+    sel = ok[np.asarray(fv)].all(axis=1)   # edges, triangles, quadrilateral facets of hexahedra alike
     return np.nonzero(sel)[0].astype(np.int32)
 
 
