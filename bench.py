@@ -59,6 +59,13 @@ def kernel_source_sha16():
 def kernel_bytes(ctx):
     """Algorithmic HBM bytes per launch of the instrumented kernels (DESIGN.md section 'Kernels')."""
     nvo, nnzv, nc, spnnz = (ctx.info(k) for k in (0, 3, 2, 4))
+    if ctx.info(26) == 3 and ctx.info(28) in (1, 2):
+        # hexahedra / P2 tetrahedra (csrc/cfdh_gen3.hip): block values out (128 B per graph entry), per node coordinates, iterate, u_prev,
+        # Dirichlet data in (~110 B) and the residual out (32 B), connectivity per cell; the staged blocks (16 + 4 doubles per lane,
+        # written and read once) are part of the algorithm
+        nl = ctx.info(29)
+        return {0: ("gen3_asm_residual_jacobian", 128.0 * nnzv + 142.0 * nvo + (4.0 * nl + 2.0 * 160.0 * nl * nl) * nc),
+                1: ("spmv3_full_block4x4", 132.0 * nnzv + 68.0 * nvo)}
     if ctx.info(26) == 3:
         # tetrahedra: 4x4 vertex blocks (128 B of values + 4 B column per graph entry), 4 dofs per vertex
         kb = {
@@ -132,7 +139,21 @@ def make_scenario(args, solver_name, **kw):
     if cfg == "p2":
         # `--simulation stenosis --solver stabilized_schur_backflow --p_grade 2` (P2/P2, do-nothing outlet)
         from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
-        return StenosisSimulation("stabilized_schur_backflow", args.dt, 1.0, ny=args.ny, v_max=args.v_max, p_grade=2, beta_backflow=0.2, quiet=True, **kw)
+        oracle = solver_name.startswith("_oracle")  # the CPU double takes the variant as keywords (tests/oracle_solver.py)
+        return StenosisSimulation(solver_name if oracle else "stabilized_schur_backflow", args.dt, 1.0, ny=args.ny, v_max=args.v_max, p_grade=2,
+                                  beta_backflow=0.2, quiet=True, **(dict(kw, backflow=True) if oracle else kw))
+    if cfg == "q1h":
+        # unit_cube_pipe on hexahedral cells (Q1/Q1), the reference's 213 x 4 x 4 box refined to --nx x --ny x --ny
+        from cfd_hemodynamic_amd.scenarios.unit_cube_pipe import UnitCubePipeSimulation
+        return UnitCubePipeSimulation(solver_name, args.dt, 1.0, p_inlet=8.85, p_outlet=0.0, nx=args.nx, ny=args.ny, nz=args.ny, quiet=True, **kw)
+    if cfg == "p2t":
+        # `--solver stabilized_schur_backflow --p_grade 2` on the tetrahedral bifurcation (P2/P2, do-nothing outlets)
+        from cfd_hemodynamic_amd.scenarios.simple_bifurcation import MicrovasculatureSimulation
+        oracle = solver_name.startswith("_oracle")
+        kw = dict(kw)
+        kw["options"] = dict(kw.get("options", {}), remove_p_mean=0)
+        return MicrovasculatureSimulation(solver_name if oracle else "stabilized_schur_backflow", args.dt, 1.0, v_inlet=args.v_max, res=args.res3, p_grade=2,
+                                          v_max=args.v_max, beta_backflow=0.2, quiet=True, **(dict(kw, backflow=True) if oracle else kw))
     if cfg == "q1":
         # unit_square_pipe on quadrilateral cells (Q1/Q1), refined to --nx x --ny cells
         from cfd_hemodynamic_amd.scenarios.unit_square_pipe import UnitSquarePipeSimulation
@@ -151,6 +172,8 @@ def workload_text(args, sc):
                   "res=%g, pulsatile inlet v_max (1 + 0.5 sin 2 pi t) with a (1 - cos(pi t / %g)) / 2 start-up ramp, v_max=%g" % (args.res, args.ramp, args.v_max),
             "p2": "stenosis (reference geometry) with stabilized_schur_backflow --p_grade 2: P2/P2 triangles on ny=%d cells across, inlet v_max=%g mm/s, do-nothing outlet + backflow stabilisation" % (args.ny, args.v_max),
             "q1": "unit_square_pipe (80 x 1.5 mm channel, p_inlet 7.47 / p_outlet 0, no-slip walls) on %d x %d quadrilateral cells, Q1/Q1" % (args.nx, args.ny),
+            "q1h": "unit_cube_pipe (80 x 1.5 x 1.5 mm duct, p_inlet 8.85 / p_outlet 0, no-slip walls) on %d x %d x %d hexahedral cells, Q1/Q1" % (args.nx, args.ny, args.ny),
+            "p2t": "simple_bifurcation with stabilized_schur_backflow --p_grade 2: P2/P2 tetrahedra on the voxel-tet mesh res=%g, inlet u_y = %g (1 - (r/r_in)^2), do-nothing outlets + backflow stabilisation" % (args.res3, args.v_max),
             "c5b": "simple_bifurcation (3-D, tetrahedra; Re=%s, inlet u_y = %g (1 - (r/r_in)^2), p = 0 at both outlets; remove_p_mean=0), voxel-tet mesh res=%g" % (
                 ("%.1f" % sc.Re) if args.config == "c5b" else "-", args.v_max, args.res3)}[args.config]
     return "%s: %d nodes, %d DOF (equal-order), dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)" % (
@@ -217,7 +240,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5", "c5b", "p2", "q1"],
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5", "c5b", "p2", "q1", "q1h", "p2t"],
                     help="c3 (default) = the headline config; p2 / q1: the SURVEY 8f-4 element types (P2/P2 stenosis with the backflow plugin, "
                          "Q1/Q1 unit_square_pipe), no CPU leg")
     ap.add_argument("--res3", type=float, default=2.0e-4, help="c5b: voxel size of the 3-D bifurcation (2e-4: 256 k vertices, 1.03 M DOF; 1e-4: 1.95 M vertices, 7.8 M DOF)")
@@ -244,15 +267,17 @@ def main():
     if args.dt is None:
         args.dt = 0.001 if args.config == "c5" else 0.01
     if args.v_max is None:
-        args.v_max = {"c5": 0.05, "c5b": 1.5, "p2": 20.0}.get(args.config, 100.0)
+        args.v_max = {"c5": 0.05, "c5b": 1.5, "p2": 20.0, "p2t": 1.5}.get(args.config, 100.0)
     if args.config == "p2" and args.ny == 115:
         args.ny = 40      # 82 k vertices -> 330 k P2 nodes, ~1 M DOF
     if args.config == "q1" and (args.nx, args.ny) == (288, 115):
         args.nx, args.ny = 5870 // 2, 110 // 2   # the reference's 587 x 11 cells refined 5 x: 2935 x 55 -> 164 k nodes, 0.49 M DOF
-    if args.config in ("p2", "q1"):
-        args.no_cpu_baseline = True
+    if args.config == "q1h" and (args.nx, args.ny) == (288, 115):
+        args.nx, args.ny = 213 * 5, 4 * 2   # the reference's 213 x 4 x 4 cells: 5 x along the duct, 2 x across -> 86 k nodes, 345 k DOF
+    if args.config == "p2t" and args.res3 == 2.0e-4:
+        args.res3 = 4.0e-4                  # 36 k vertices -> ~270 k P2 nodes, ~1.1 M DOF
     if args.parity_steps is None:
-        args.parity_steps = {"c5": 0, "c5b": 1}.get(args.config, 2)
+        args.parity_steps = {"c5": 0, "c5b": 1, "p2t": 1, "q1h": 1}.get(args.config, 2)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -445,7 +470,8 @@ def main():
 
     label = {"c3": "dfg_1 ~1M DOF", "c2": "lid_driven2D ~250k DOF", "c4": "stenosis moderate ~2M DOF",
              "c5": "stenosis_with_tree ~8M DOF pulsatile", "c5b": "simple_bifurcation 3-D tets", "p2": "stenosis P2/P2 ~1M DOF (backflow plugin)",
-             "q1": "unit_square_pipe Q1/Q1 quadrilaterals"}[args.config]
+             "q1": "unit_square_pipe Q1/Q1 quadrilaterals", "q1h": "unit_cube_pipe Q1/Q1 hexahedra",
+             "p2t": "simple_bifurcation P2/P2 tetrahedra (backflow plugin)"}[args.config]
     kits = max(sum(its_krylov), 1)
     out = {
         "metric": "time-steps/sec, %s (%s)" % (label, args.solver),
@@ -517,7 +543,7 @@ def main():
     if args.config == "c5b":
         qi, q1, q2 = sc.flow_rates()
         out["results"].update({"inflow": qi, "outflow_1": q1, "outflow_2": q2})
-    if world == 1 and rank == 0 and int(sc.solver.options.ksp_guess) > 0 and args.config in ("c2", "c3", "c4", "c5b", "q1"):
+    if world == 1 and rank == 0 and int(sc.solver.options.ksp_guess) > 0 and args.config in ("c2", "c3", "c4", "c5b", "q1", "q1h"):
         # The same timed region with the linear solver configured like the reference's KSP: zero initial guess in every solve (and
         # the fp64 basis throughout) -- so that the line carries both numbers and the share of `value` that is due to the projected
         # guess can be read off.  A fresh scenario from t = 0, the same warm-up and step counts, the same clock.

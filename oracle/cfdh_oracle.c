@@ -57,7 +57,13 @@ typedef struct orc_ctx {
   /* D = geometric dimension: 2 (triangles, this file's element routine) or 3 (tetrahedra: cfdh_oracle3.c supplies the element
    * tensors, everything from the assembly on is written for D + 1 unknowns per vertex).  NL = D + 1 vertices per cell. */
   int D, NL;
-  int *cells;   /* [nc][NL] */
+  /* NC = nodes per cell: D + 1 for the P1 simplices, 6 / 4 / 10 / 8 for the generic elements (etg != 0: P2 triangles 1, Q1
+   * parallelograms 2, P2 tetrahedra 4, Q1 hexahedra 5 -- the element codes of np_twin_gen.py / np_twin_gen3.py), whose element
+   * tensors come from cfdh_oracle_gen.c / cfdh_oracle_gen3.c; NL = D + 1 stays the number of unknowns per node */
+  int NC, etg;
+  int64_t *cells64;   /* [nc][NC] for the generic element routines */
+  uint16_t *gflag;    /* [nc] generic elements: bit f exterior facet f, bit 8 + f backflow facet f */
+  int *cells;   /* [nc][NC] */
   double *x;    /* [nv][D] */
   uint8_t *fflag; /* [nc] bit f: facet opposite local vertex f is exterior; bit 3+f: it is a backflow (outlet) facet */
   int *fcell, *flocal;
@@ -342,17 +348,36 @@ void orc_element(double dt, double rho, double mu, double muf, const double *f, 
 
 static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b); }
 
+typedef struct { double dt, rho, mu, muf, f[2], theta, a0, a1, a2, beta; int32_t ds_terms, pad; } orcg_params_t;
+typedef struct { double dt, rho, mu, muf, f[3], theta, a0, a1, a2, beta; int32_t ds_terms, pad; } orcg3_params_t;
+void orcg_element_tensors(int et, int64_t nc, const int64_t *cells, const double *x, const double *u, const double *un, const double *un2,
+                          const double *p, const orcg_params_t *P, const uint16_t *flags, int want_jac, double *Fe, double *Je);
+void orcg3_element_tensors(int et, int64_t nc, const int64_t *cells, const double *x, const double *u, const double *un, const double *un2,
+                           const double *p, const orcg3_params_t *P, const uint16_t *flags, int want_jac, double *Fe, double *Je);
+/* per-cell stiffness [nc][NC*NC] and diagonal of the consistent mass [nc][NC] of a generic element, cell measures (Cahouet-Chabard set-up) */
+void orcg_stiff_mass(int et, int64_t nc, const int64_t *cells, const double *x, double *K, double *Md, double *meas);
+void orcg3_stiff_mass(int et, int64_t nc, const int64_t *cells, const double *x, double *K, double *Md, double *meas);
+int orcg_facet_nodes(int et, int f, int *out);   /* local nodes of local facet f (2-D elements); returns their number */
+int orcg3_facet_nodes(int et, int f, int *out);  /* ... 3-D elements */
 int orc3_element_tensors(int nc, const double *x, const int *cells, const double *u, const double *un, const double *un2,
                          const double *p, const unsigned char *facet_flags, double dt, double rho, double mu, double muf,
                          const double *f, double theta, double a0, double a1, double a2, int ds_terms, double beta_bf,
                          double *Fe, double *Je);
 
-orc_ctx *orc_create_d(int D, int nv, int nc, const int *cells, const double *x, int nf, const int *fcell, const int *flocal) {
+static orc_ctx *create_common(int D, int etg, int nv, int nc, const int *cells, const double *x, int nf, const int *fcell, const int *flocal) {
   orc_ctx *c = (orc_ctx *)calloc(1, sizeof *c);
-  const int NL = D + 1, ND = NL * NL;  /* ND: element dofs, (D + 1) per vertex */
-  c->D = D; c->NL = NL;
-  c->nv = nv; c->nc = nc; c->nf = nf; c->ndof = NL * nv;
+  const int NU = D + 1;  /* unknowns per node */
+  const int NL = etg == 0 ? D + 1 : (etg == 1 ? 6 : (etg == 2 ? 4 : (etg == 4 ? 10 : 8)));  /* nodes per cell, from here to the end of this function */
+  const int ND = NU * NL;  /* element dofs */
+  c->D = D; c->NL = NU; c->NC = NL; c->etg = etg;
+  c->nv = nv; c->nc = nc; c->nf = nf; c->ndof = NU * nv;
   c->cells = (int *)malloc(sizeof(int) * NL * nc); memcpy(c->cells, cells, sizeof(int) * NL * nc);
+  if (etg) {
+    c->cells64 = (int64_t *)malloc(sizeof(int64_t) * NL * (size_t)nc);
+    for (size_t k = 0; k < (size_t)NL * nc; k++) c->cells64[k] = cells[k];
+    c->gflag = (uint16_t *)calloc(nc, sizeof(uint16_t));
+    for (int k = 0; k < nf; k++) c->gflag[fcell[k]] |= (uint16_t)(1u << flocal[k]);
+  }
   c->x = (double *)malloc(sizeof(double) * D * nv); memcpy(c->x, x, sizeof(double) * D * nv);
   c->fflag = (uint8_t *)calloc(nc, 1);
   c->fcell = (int *)malloc(sizeof(int) * (nf + 1)); c->flocal = (int *)malloc(sizeof(int) * (nf + 1));
@@ -417,7 +442,7 @@ orc_ctx *orc_create_d(int D, int nv, int nc, const int *cells, const double *x, 
   c->rowptr[0] = 0;
   for (int r = 0; r < c->ndof; r++) {
     int v = r < nu ? r / D : r - nu;
-    c->rowptr[r + 1] = c->rowptr[r] + NL * (c->vptr[v + 1] - c->vptr[v]);
+    c->rowptr[r + 1] = c->rowptr[r] + NU * (c->vptr[v + 1] - c->vptr[v]);
   }
   c->nnz = c->rowptr[c->ndof];
   c->col = (int *)malloc(sizeof(int) * c->nnz);
@@ -447,6 +472,15 @@ orc_ctx *orc_create_d(int D, int nv, int nc, const int *cells, const double *x, 
   return c;
 }
 
+orc_ctx *orc_create_d(int D, int nv, int nc, const int *cells, const double *x, int nf, const int *fcell, const int *flocal) {
+  return create_common(D, 0, nv, nc, cells, x, nf, fcell, flocal);
+}
+/* nodal equal-order elements beyond P1: etg 1 P2 triangles, 2 Q1 parallelograms, 4 P2 tetrahedra, 5 Q1 hexahedra;
+ * cells [nc][nodes per cell] in the DOLFINx local order, x = node coordinates.  pc_kind 2 only. */
+orc_ctx *orc_create_gen(int D, int etg, int nv, int nc, const int *cells, const double *x, int nf, const int *fcell, const int *flocal) {
+  if (!((D == 2 && (etg == 1 || etg == 2)) || (D == 3 && (etg == 4 || etg == 5)))) return NULL;
+  return create_common(D, etg, nv, nc, cells, x, nf, fcell, flocal);
+}
 orc_ctx *orc_create(int nv, int nc, const int *cells, const double *x, int nf, const int *fcell, const int *flocal) {
   return orc_create_d(2, nv, nc, cells, x, nf, fcell, flocal);
 }
@@ -456,6 +490,7 @@ static void free_csr(csr_t *m) { free(m->rowptr); free(m->col); free(m->val); fr
 
 void orc_destroy(orc_ctx *c) {
   if (!c) return;
+  free(c->cells64); free(c->gflag);
   free(c->cells); free(c->x); free(c->fflag); free(c->fcell); free(c->flocal); free(c->isbc); free(c->bcval);
   free(c->bcmult); free(c->un); free(c->un2); free(c->Mom); free(c->Fe); free(c->Je); free(c->vcptr); free(c->vcell);
   free(c->vptr); free(c->vadj); free(c->rowptr); free(c->col); free(c->val); free(c->cellpos);
@@ -479,6 +514,10 @@ void orc_set_boundary_terms(orc_ctx *c, int ds_terms, double beta, int nbf, cons
   const unsigned ext = c->D == 3 ? 15u : 7u, bf0 = c->D == 3 ? 16u : 8u;
   for (int e = 0; e < c->nc; e++) c->fflag[e] &= ext;
   for (int k = 0; k < nbf; k++) c->fflag[c->fcell[bf_facets[k]]] |= (uint8_t)(bf0 << c->flocal[bf_facets[k]]);
+  if (c->gflag) {
+    for (int e = 0; e < c->nc; e++) c->gflag[e] &= 0xffu;
+    for (int k = 0; k < nbf; k++) c->gflag[c->fcell[bf_facets[k]]] |= (uint16_t)(256u << c->flocal[bf_facets[k]]);
+  }
 }
 /* u_prev2 of stabilized_schur_bdf2.py:72,324 */
 void orc_set_un2(orc_ctx *c, const double *un2) { memcpy(c->un2, un2, sizeof(double) * c->D * c->nv); }
@@ -511,7 +550,7 @@ void orc_add_bc(orc_ctx *c, int field, int n, const int *nodes, const double *va
 /* u_prev for the step; refreshes the tau moments (they depend on u_prev only) */
 void orc_set_un(orc_ctx *c, const double *un) {
   memcpy(c->un, un, sizeof(double) * c->D * c->nv);
-  if (c->D == 3) return;  /* the tetrahedral element routine integrates tau itself */
+  if (c->D == 3 || c->etg) return;  /* the tetrahedral and the generic element routines integrate tau themselves */
   double nu = c->mu / c->rho;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < c->nc; e++) {
@@ -532,25 +571,33 @@ void orc_set_un(orc_ctx *c, const double *un) {
  * Dirichlet semantics of assemble_vector_block(F, F_form, J_form, bcs, x0=x, alpha=-1)
  * and assemble_matrix_block(J, J_form, bcs): stabilized_schur.py:144-175. */
 void orc_assemble(orc_ctx *c, const double *xv, int want_jac, double *F) {
-  const int D = c->D, NL = c->NL, ND = NL * NL, PO = D * NL;  /* PO: offset of the pressure dofs in the element vector */
+  const int D = c->D, NL = c->NL, NC = c->NC, ND = NL * NC, PO = D * NC;  /* PO: offset of the pressure dofs in the element vector */
   const int nv = c->nv, nu = D * nv, nc = c->nc;
   int any_lift = 0;
   for (int d = 0; d < c->ndof && !any_lift; d++)
     if (c->isbc[d] && c->bcval[d] != xv[d]) any_lift = 1;
   const int need_j = want_jac || any_lift;
-  if (D == 3) /* element tensors of all cells by the tetrahedral restatement (cfdh_oracle3.c) */
+  if (c->etg) { /* generic elements: element tensors of all cells by cfdh_oracle_gen.c / cfdh_oracle_gen3.c */
+    if (D == 2) {
+      orcg_params_t P = {c->dt, c->rho, c->mu, c->muf, {c->f[0], c->f[1]}, c->theta, c->a0, c->a1, c->a2, c->beta_bf, c->ds_terms, 0};
+      orcg_element_tensors(c->etg, nc, c->cells64, c->x, xv, c->un, c->a2 != 0.0 ? c->un2 : NULL, xv + nu, &P, c->gflag, need_j, c->Fe, need_j ? c->Je : NULL);
+    } else {
+      orcg3_params_t P = {c->dt, c->rho, c->mu, c->muf, {c->f[0], c->f[1], c->f[2]}, c->theta, c->a0, c->a1, c->a2, c->beta_bf, c->ds_terms, 0};
+      orcg3_element_tensors(c->etg, nc, c->cells64, c->x, xv, c->un, c->a2 != 0.0 ? c->un2 : NULL, xv + nu, &P, c->gflag, need_j, c->Fe, need_j ? c->Je : NULL);
+    }
+  } else if (D == 3) /* element tensors of all cells by the tetrahedral restatement (cfdh_oracle3.c) */
     orc3_element_tensors(nc, c->x, c->cells, xv, c->un, c->a2 != 0.0 ? c->un2 : NULL, xv + nu, c->fflag, c->dt, c->rho, c->mu, c->muf, c->f,
                          c->theta, c->a0, c->a1, c->a2, c->ds_terms, c->beta_bf, c->Fe, need_j ? c->Je : NULL);
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < nc; e++) {
-    int ld[16];
-    for (int a = 0; a < NL; a++) {
-      int v = c->cells[NL * e + a];
+    int ld[40];
+    for (int a = 0; a < NC; a++) {
+      int v = c->cells[NC * e + a];
       for (int i = 0; i < D; i++) ld[D * a + i] = D * v + i;
       ld[PO + a] = nu + v;
     }
     double *Fe = c->Fe + ND * (size_t)e, *Je = c->Je + (size_t)ND * ND * e;
-    if (D == 2) {
+    if (D == 2 && !c->etg) {
       double xe[3][2], ue[3][2], une[3][2], un2e[3][2], pe[3];
       for (int a = 0; a < 3; a++) {
         int v = c->cells[3 * e + a];
@@ -594,15 +641,15 @@ void orc_assemble(orc_ctx *c, const double *xv, int want_jac, double *F) {
       if (want_jac) memset(rr[t], 0, sizeof(double) * NL * deg);
     }
     for (int k = c->vcptr[v]; k < c->vcptr[v + 1]; k++) {
-      int e = c->vcell[k] / NL, a = c->vcell[k] % NL;
+      int e = c->vcell[k] / NC, a = c->vcell[k] % NC;
       const double *Fe = c->Fe + ND * (size_t)e, *Je = c->Je + (size_t)ND * ND * e;
       int er[4];  /* element rows of vertex a: velocity components, pressure */
       for (int t = 0; t < D; t++) er[t] = D * a + t;
       er[D] = PO + a;
       for (int t = 0; t < NL; t++) fv[t] += Fe[er[t]];
       if (want_jac)
-        for (int b = 0; b < NL; b++) {
-          int kb = c->cellpos[NL * NL * e + NL * a + b];
+        for (int b = 0; b < NC; b++) {
+          int kb = c->cellpos[NC * NC * e + NC * a + b];
           for (int t = 0; t < NL; t++) {
             for (int j = 0; j < D; j++) rr[t][D * kb + j] += Je[er[t] * ND + D * b + j];
             rr[t][D * deg + kb] += Je[er[t] * ND + PO + b];
@@ -1024,6 +1071,29 @@ static void amg_vcycle(amg_hier *H, const orc_opts *o, int lev, const double *b,
 static int cc_setup(orc_ctx *c, const orc_opts *o) {
   const int D = c->D, NL = c->NL;
   const int nv = c->nv, nu = D * nv;
+  if (!c->Lval && c->etg) {
+    /* generic elements: stiffness of the element by its own quadrature on the node graph; lumped mass = diagonal of the consistent
+     * mass scaled to the total measure (row sums vanish at P2 vertices) -- as csrc/cfdh_gen.hip / cfdh_gen3.hip build them */
+    const int NC = c->NC;
+    c->Lval = (double *)calloc(c->vptr[nv], sizeof(double));
+    c->Ml = (double *)calloc(nv, sizeof(double));
+    double *K = (double *)malloc(sizeof(double) * NC * NC * (size_t)c->nc), *Md = (double *)malloc(sizeof(double) * NC * (size_t)c->nc);
+    double *meas = (double *)malloc(sizeof(double) * c->nc);
+    if (D == 2) orcg_stiff_mass(c->etg, c->nc, c->cells64, c->x, K, Md, meas);
+    else orcg3_stiff_mass(c->etg, c->nc, c->cells64, c->x, K, Md, meas);
+    double msum = 0.0, dsum = 0.0;
+    for (int e = 0; e < c->nc; e++) {
+      msum += meas[e];
+      for (int a = 0; a < NC; a++) {
+        const int va = c->cells[NC * e + a];
+        c->Ml[va] += Md[(size_t)NC * e + a];
+        dsum += Md[(size_t)NC * e + a];
+        for (int b = 0; b < NC; b++) c->Lval[c->vptr[va] + c->cellpos[NC * NC * e + NC * a + b]] += K[((size_t)NC * e + a) * NC + b];
+      }
+    }
+    for (int i = 0; i < nv; i++) c->Ml[i] *= msum / dsum;
+    free(K); free(Md); free(meas);
+  }
   if (!c->Lval && D == 3) { /* tetrahedra: grad lambda from the inverse of [x1-x0 | x2-x0 | x3-x0], volume |det| / 6 */
     c->Lval = (double *)calloc(c->vptr[nv], sizeof(double));
     c->Ml = (double *)calloc(nv, sizeof(double));
@@ -1095,14 +1165,15 @@ static int cc_setup(orc_ctx *c, const orc_opts *o) {
   if (!c->ds_terms)
     for (int k = 0; k < c->nf; k++) {
       int e = c->fcell[k], fl = c->flocal[k];
-      int fixed = 1;
-      for (int q = 0; q < NL; q++) {
-        if (q == fl) continue;
-        int v = c->cells[NL * e + q];
+      int fixed = 1, loc[8], nn = 0;
+      if (c->etg) nn = D == 2 ? orcg_facet_nodes(c->etg, fl, loc) : orcg3_facet_nodes(c->etg, fl, loc);
+      else for (int q = 0; q < NL; q++) if (q != fl) loc[nn++] = q;
+      for (int q = 0; q < nn; q++) {
+        int v = c->cells[c->NC * e + loc[q]];
         for (int i = 0; i < D; i++) fixed = fixed && c->isbc[D * v + i];
       }
       if (fixed) continue;
-      for (int q = 0; q < NL; q++) if (q != fl) pbc[c->cells[NL * e + q]] |= 2;
+      for (int q = 0; q < nn; q++) pbc[c->cells[c->NC * e + loc[q]]] |= 2;
     }
   for (int i = 0; i < nv; i++) if (c->ccPbc && c->ccPbc[i] != pbc[i]) changed = 1;
   if (changed) {

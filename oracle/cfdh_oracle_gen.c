@@ -258,3 +258,38 @@ void orcg_element_tensors(int et, int64_t nc, const int64_t *cells, const double
     }
   }
 }
+
+/* per-cell element stiffness K [nc][nl*nl], diagonal of the consistent mass Md [nc][nl] and cell measure (host side of the
+ * Cahouet-Chabard preconditioner in the C driver of cfdh_oracle.c; same quantities as csrc/cfdh_gen.hip::cfdh_build_mesh_gen) */
+void orcg_stiff_mass(int et, int64_t nc, const int64_t *cells, const double *x, double *K, double *Md, double *meas) {
+  const int nl = nloc_of(et);
+  double xi[MAXQ][2], wq[MAXQ];
+  const int nq = cell_rule(et, xi, wq);
+  double phiq[MAXQ][MAXL], dphiq[MAXQ][MAXL][2];
+  for (int q = 0; q < nq; q++) tabulate(et, xi[q][0], xi[q][1], phiq[q], dphiq[q]);
+  for (int64_t c = 0; c < nc; c++) {
+    const int64_t *cl = cells + c * nl;
+    const double J00 = x[2 * cl[1]] - x[2 * cl[0]], J01 = x[2 * cl[2]] - x[2 * cl[0]], J10 = x[2 * cl[1] + 1] - x[2 * cl[0] + 1], J11 = x[2 * cl[2] + 1] - x[2 * cl[0] + 1];
+    const double det = J00 * J11 - J01 * J10, adet = fabs(det);
+    const double Ji[2][2] = {{J11 / det, -J01 / det}, {-J10 / det, J00 / det}};
+    double *Kc = K + c * nl * nl, *Mc = Md + c * nl;
+    for (int r = 0; r < nl * nl; r++) Kc[r] = 0.0;
+    for (int a = 0; a < nl; a++) Mc[a] = 0.0;
+    for (int q = 0; q < nq; q++) {
+      double g[MAXL][2];
+      for (int a = 0; a < nl; a++)
+        for (int i = 0; i < 2; i++) g[a][i] = dphiq[q][a][0] * Ji[0][i] + dphiq[q][a][1] * Ji[1][i];
+      for (int a = 0; a < nl; a++) {
+        Mc[a] += adet * wq[q] * phiq[q][a] * phiq[q][a];
+        for (int b = 0; b < nl; b++) Kc[a * nl + b] += adet * wq[q] * (g[a][0] * g[b][0] + g[a][1] * g[b][1]);
+      }
+    }
+    meas[c] = adet * (et == 2 ? 1.0 : 0.5);
+  }
+}
+int orcg_facet_nodes(int et, int f, int *out) {
+  if (et == 2) { out[0] = QUAD_FACETS[f][0]; out[1] = QUAD_FACETS[f][1]; return 2; }
+  out[0] = TRI_FACETS[f][0]; out[1] = TRI_FACETS[f][1];
+  if (et == 1) { out[2] = 3 + f; return 3; }
+  return 2;
+}

@@ -307,3 +307,59 @@ void orcg3_element_tensors(int et, int64_t nc, const int64_t *cells, const doubl
   }
   free(phiq); free(dphiq); free(hq); free(wq);
 }
+
+/* per-cell element stiffness K [nc][nl*nl], diagonal of the consistent mass Md [nc][nl] and cell measure (host side of the
+ * Cahouet-Chabard preconditioner in the C driver of cfdh_oracle.c; same quantities as csrc/cfdh_gen3.hip::cfdh_build_mesh_gen3) */
+void orcg3_stiff_mass(int et, int64_t nc, const int64_t *cells, const double *x, double *K, double *Md, double *meas) {
+  const int nl = nloc_of(et);
+  double (*phiq)[MAXL] = malloc(sizeof(double) * MAXQ * MAXL);
+  double (*dphiq)[MAXL][3] = malloc(sizeof(double) * MAXQ * MAXL * 3);
+  double (*hq)[MAXL][3][3] = malloc(sizeof(double) * MAXL * 9);
+  double *wq = malloc(sizeof(double) * MAXQ);
+  for (int q = 0; q < 343; q++) {
+    double pt[3];
+    if (et == 5) {
+      const int i = q / 49, j = (q / 7) % 7, k = q % 7;
+      pt[0] = CFDH_GL7_X[i]; pt[1] = CFDH_GL7_X[j]; pt[2] = CFDH_GL7_X[k];
+      wq[q] = CFDH_GL7_W[i] * CFDH_GL7_W[j] * CFDH_GL7_W[k];
+    } else {
+      pt[0] = CFDH3_QL[q][1]; pt[1] = CFDH3_QL[q][2]; pt[2] = CFDH3_QL[q][3];
+      wq[q] = CFDH3_QW[q] / 6.0;
+    }
+    tabulate(et, pt, phiq[q], dphiq[q], hq[0]);
+  }
+  const int c3 = et == 5 ? 4 : 3;
+  for (int64_t c = 0; c < nc; c++) {
+    const int64_t *cl = cells + c * nl;
+    double Jm3[3][3], Ji[3][3];
+    for (int i = 0; i < 3; i++) { Jm3[i][0] = x[3 * cl[1] + i] - x[3 * cl[0] + i]; Jm3[i][1] = x[3 * cl[2] + i] - x[3 * cl[0] + i]; Jm3[i][2] = x[3 * cl[c3] + i] - x[3 * cl[0] + i]; }
+    const double det = Jm3[0][0] * (Jm3[1][1] * Jm3[2][2] - Jm3[1][2] * Jm3[2][1]) - Jm3[0][1] * (Jm3[1][0] * Jm3[2][2] - Jm3[1][2] * Jm3[2][0]) +
+                       Jm3[0][2] * (Jm3[1][0] * Jm3[2][1] - Jm3[1][1] * Jm3[2][0]);
+    const double adet = fabs(det);
+    Ji[0][0] = (Jm3[1][1] * Jm3[2][2] - Jm3[1][2] * Jm3[2][1]) / det; Ji[0][1] = (Jm3[0][2] * Jm3[2][1] - Jm3[0][1] * Jm3[2][2]) / det; Ji[0][2] = (Jm3[0][1] * Jm3[1][2] - Jm3[0][2] * Jm3[1][1]) / det;
+    Ji[1][0] = (Jm3[1][2] * Jm3[2][0] - Jm3[1][0] * Jm3[2][2]) / det; Ji[1][1] = (Jm3[0][0] * Jm3[2][2] - Jm3[0][2] * Jm3[2][0]) / det; Ji[1][2] = (Jm3[0][2] * Jm3[1][0] - Jm3[0][0] * Jm3[1][2]) / det;
+    Ji[2][0] = (Jm3[1][0] * Jm3[2][1] - Jm3[1][1] * Jm3[2][0]) / det; Ji[2][1] = (Jm3[0][1] * Jm3[2][0] - Jm3[0][0] * Jm3[2][1]) / det; Ji[2][2] = (Jm3[0][0] * Jm3[1][1] - Jm3[0][1] * Jm3[1][0]) / det;
+    double *Kc = K + c * nl * nl, *Mc = Md + c * nl;
+    for (int r = 0; r < nl * nl; r++) Kc[r] = 0.0;
+    for (int a = 0; a < nl; a++) Mc[a] = 0.0;
+    for (int q = 0; q < 343; q++) {
+      double g[MAXL][3];
+      for (int a = 0; a < nl; a++)
+        for (int i = 0; i < 3; i++) g[a][i] = dphiq[q][a][0] * Ji[0][i] + dphiq[q][a][1] * Ji[1][i] + dphiq[q][a][2] * Ji[2][i];
+      for (int a = 0; a < nl; a++) {
+        Mc[a] += adet * wq[q] * phiq[q][a] * phiq[q][a];
+        for (int b = 0; b < nl; b++) Kc[a * nl + b] += adet * wq[q] * (g[a][0] * g[b][0] + g[a][1] * g[b][1] + g[a][2] * g[b][2]);
+      }
+    }
+    meas[c] = adet * (et == 5 ? 1.0 : 1.0 / 6.0);
+  }
+  free(phiq); free(dphiq); free(hq); free(wq);
+}
+int orcg3_facet_nodes(int et, int f, int *out) {
+  if (et == 5) { for (int k = 0; k < 4; k++) out[k] = HEX_FACETS[f][k]; return 4; }
+  for (int k = 0; k < 3; k++) out[k] = TET_FACETS[f][k];
+  if (et != 4) return 3;
+  int n = 3;
+  for (int e = 0; e < 6; e++) if (TET_EDGES[e][0] != f && TET_EDGES[e][1] != f) out[n++] = 4 + e;
+  return n;
+}

@@ -91,19 +91,32 @@ def default_opts(**kw):
 class Oracle:
     """Plain-array problem: x [nv,2], cells [nc,3] (or x [nv,3], cells [nc,4]: tetrahedra), exterior facets (cell, local)."""
 
-    def __init__(self, x, cells, facet_cells, facet_local, dt, rho, mu, f=(0.0, 0.0), mu_facet=None):
+    def __init__(self, x, cells, facet_cells, facet_local, dt, rho, mu, f=(0.0, 0.0), mu_facet=None, etg=0):
+        """etg != 0: a nodal element beyond P1 (the element codes of np_twin_gen.py / np_twin_gen3.py: 1 P2 triangles, 2 Q1
+        parallelograms, 4 P2 tetrahedra, 5 Q1 hexahedra) -- x are node coordinates, cells list the nodes in the DOLFINx local order;
+        Newton / FGMRES / Cahouet-Chabard + AMG of cfdh_oracle.c over the element routines of cfdh_oracle_gen*.c (pc_kind 2 only)."""
         L = lib()
         self.x = np.ascontiguousarray(x, dtype=np.float64)
         self.cells = np.ascontiguousarray(cells, dtype=np.int32)
         self.fc = np.ascontiguousarray(facet_cells, dtype=np.int32)
         self.fl = np.ascontiguousarray(facet_local, dtype=np.int32)
         self.nv, self.nc = len(self.x), len(self.cells)
-        self.dim = self.cells.shape[1] - 1   # triangles: 2; tetrahedra: 3 (element tensors from cfdh_oracle3.c, pc_kind 2 only)
+        self.etg = int(etg)
+        # triangles: 2; tetrahedra: 3 (element tensors from cfdh_oracle3.c, pc_kind 2 only); generic elements: from the coordinates
+        self.dim = self.x.shape[1] if self.etg else self.cells.shape[1] - 1
         assert self.x.shape[1] == self.dim
         self.ndof = (self.dim + 1) * self.nv
+        sig = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_create_d.restype = C.c_void_p
-        L.orc_create_d.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        self.h = L.orc_create_d(self.dim, self.nv, self.nc, _ip(self.cells), _dp(self.x), len(self.fc), _ip(self.fc), _ip(self.fl))
+        L.orc_create_d.argtypes = sig
+        L.orc_create_gen.restype = C.c_void_p
+        L.orc_create_gen.argtypes = [C.c_int] + sig
+        if self.etg:
+            self.h = L.orc_create_gen(self.dim, self.etg, self.nv, self.nc, _ip(self.cells), _dp(self.x), len(self.fc), _ip(self.fc), _ip(self.fl))
+            if not self.h:
+                raise ValueError("orc_create_gen: element code %d does not exist for gdim %d" % (self.etg, self.dim))
+        else:
+            self.h = L.orc_create_d(self.dim, self.nv, self.nc, _ip(self.cells), _dp(self.x), len(self.fc), _ip(self.fc), _ip(self.fl))
         ff = np.zeros(3)
         ff[: len(np.atleast_1d(f))] = np.asarray(f, dtype=np.float64)
         L.orc_set_params(self.h, dt, rho, mu, mu if mu_facet is None else mu_facet, _dp(ff))

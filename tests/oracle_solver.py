@@ -11,15 +11,23 @@ class Solver(SolverBase):
     def __init__(self, mesh, dt, rho, mu, f, initial_velocity=None, **kwargs):
         super().__init__(mesh, dt, rho, mu, f)
         self.gdim = mesh.geometry.dim  # 2: triangles; 3: tetrahedra (C driver with the element tensors of cfdh_oracle3.c, pc_kind 2)
-        self.initVelocitySpace("Lagrange", mesh.topology.cell_name(), 1, shape=(self.gdim,))
-        self.initPressureSpace("Lagrange", mesh.topology.cell_name(), 1)
+        # Lagrange degree (`p_grade` of the backflow plugin) and cell type select the element as in the product plugin: P2 on
+        # triangles / tetrahedra, Q1 on quadrilaterals / hexahedra run the C driver over cfdh_oracle_gen*.c
+        degree = int(kwargs.get("p_grade", kwargs.get("_degree", 1)))
+        self.initVelocitySpace("Lagrange", mesh.topology.cell_name(), degree, shape=(self.gdim,))
+        self.initPressureSpace("Lagrange", mesh.topology.cell_name(), degree)
         if initial_velocity:
             self.u_prev.interpolate(initial_velocity)
-        self.O = orc.Oracle(mesh.x, mesh.cells, mesh.facet_cells, mesh.facet_local, dt, rho, mu, f)
-        self.opts = orc.default_opts(pc_kind=int(kwargs.get("pc_kind", 2 if self.gdim == 3 else 1)))
+        dm = self._dm
+        lib_etype = int(getattr(dm, "etype", 0))
+        self.etg = {(0, 2): 0, (0, 3): 0, (1, 2): 1, (2, 2): 2, (1, 3): 4, (2, 3): 5}[(lib_etype, self.gdim)]
+        self.O = orc.Oracle(dm.x, dm.cells, dm.facet_cells, dm.facet_local, dt, rho, mu, f, etg=self.etg)
+        # the backflow plugin's boundary terms (stabilized_schur_backflow.py:107,158-176): no ds pair, backflow term on the outlet facets
+        self._backflow = float(kwargs.get("beta_backflow", 0.2)) if kwargs.get("backflow") else None
+        self.opts = orc.default_opts(pc_kind=int(kwargs.get("pc_kind", 2 if (self.gdim == 3 or self.etg) else 1)))
         for k, v in dict(kwargs.get("options", {})).items():
             setattr(self.opts, k, v)
-        self.nv = mesh.num_vertices
+        self.nv = dm.num_vertices
         self.last_stats = None
         self.calls = 0
         # bdf2=True: the time discretisation of stabilized_schur_bdf2.py (BDF1 on the first step, BDF2 afterwards)
@@ -27,6 +35,10 @@ class Solver(SolverBase):
         self._un2 = np.zeros(self.gdim * self.nv)
 
     def setup(self, bcu, bcp, facet_tags=None, tags=None):
+        if self._backflow is not None:   # backflow variant: do-nothing outlet, no pressure condition
+            out = np.nonzero(np.asarray(self._dm.facet_marker) == int((tags or {}).get("outlet", -1)))[0]
+            self.O.set_boundary_terms(False, out, float(self._backflow))
+            bcp = []
         self._bcs = [(0, bc.getBC(self.V)) for bc in bcu] + [(1, bc.getBC(self.Q)) for bc in bcp]
         self.x_n = np.concatenate([self.u_prev.x.array, self.p_prev.x.array])
 
@@ -56,6 +68,16 @@ class Solver(SolverBase):
 
     def functional(self, kind, marker=0):
         """Same contract as the product Solver.functional (cfdh_functional kinds 0-3)."""
+        if self.etg:
+            if kind not in (2, 3):
+                raise NotImplementedError("generic-element test double: L2 norms only")
+            if self.gdim == 2:
+                from oracle import np_twin as T2, np_twin_gen as G
+                pb = G.Problem(self.etg, self._dm.x, self._dm.cells, self._dm.facet_cells, self._dm.facet_local, T2.Params(1.0, 1.0, 1.0, (0.0, 0.0)))
+            else:
+                from oracle import np_twin_gen3 as G3, np_twin_nd as TN
+                pb = G3.Problem(self.etg, self._dm.x, self._dm.cells, self._dm.facet_cells, self._dm.facet_local, TN.Params(1.0, 1.0, 1.0, (0.0, 0.0, 0.0)))
+            return float(pb.l2_norms(self.x_n)[kind - 2])
         if self.gdim == 3:
             if kind not in (2, 3):
                 raise NotImplementedError("tetrahedral test double: L2 norms only")

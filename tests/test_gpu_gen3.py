@@ -203,7 +203,7 @@ def test_backflow_plugin_with_p_grade_2_on_tetrahedra():
     meshes of scenario_factory.py:47-49): P2/P2 on the coarse bifurcation, do-nothing outlets with backflow stabilisation; two steps
     of the scenario loop against the twin."""
     from cfd_hemodynamic_amd.scenarios.simple_bifurcation import MicrovasculatureSimulation
-    sc = MicrovasculatureSimulation("stabilized_schur_backflow", 0.01, 0.015, v_inlet=1.5, res=1.6e-3, quiet=True, p_grade=2, beta_backflow=0.2,
+    sc = MicrovasculatureSimulation("stabilized_schur_backflow", 0.01, 0.015, v_inlet=1.5, res=1.6e-3, quiet=True, v_max=1.5, p_grade=2, beta_backflow=0.2,
                                     options=dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10, remove_p_mean=0))
     dm = sc.solver.V.mesh
     nv = dm.num_vertices
