@@ -137,9 +137,16 @@ def make_scenario(args, solver_name, **kw):
         kw["options"] = dict(kw.get("options", {}), remove_p_mean=0)
         return MicrovasculatureSimulation(solver_name, args.dt, 1.0, v_inlet=args.v_max, res=args.res3, quiet=True, **kw)
     if cfg == "p2":
-        # `--simulation stenosis --solver stabilized_schur_backflow --p_grade 2` (P2/P2, do-nothing outlet)
-        from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
+        # `--solver stabilized_schur_backflow --p_grade 2` (P2/P2 triangles, do-nothing outlet + backflow term) on the
+        # DFG 2D-1 channel (nu = 1e-3: tau is not at its viscous limit h^2 / 4 nu, where the P2/P2 form itself fails -- DESIGN.md section 9)
+        from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
         oracle = solver_name.startswith("_oracle")  # the CPU double takes the variant as keywords (tests/oracle_solver.py)
+        return DFG1Benchmark(solver_name if oracle else "stabilized_schur_backflow", args.dt, 1.0, m=args.m, v_max=0.3, p_grade=2, beta_backflow=0.2,
+                             quiet=True, **(dict(kw, backflow=True) if oracle else kw))
+    if cfg == "p2s":
+        # the round-3 P2 workload: `--simulation stenosis --solver stabilized_schur_backflow --p_grade 2` -- does not reach its own T
+        from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
+        oracle = solver_name.startswith("_oracle")
         return StenosisSimulation(solver_name if oracle else "stabilized_schur_backflow", args.dt, 1.0, ny=args.ny, v_max=args.v_max, p_grade=2,
                                   beta_backflow=0.2, quiet=True, **(dict(kw, backflow=True) if oracle else kw))
     if cfg == "q1h":
@@ -147,17 +154,13 @@ def make_scenario(args, solver_name, **kw):
         from cfd_hemodynamic_amd.scenarios.unit_cube_pipe import UnitCubePipeSimulation
         return UnitCubePipeSimulation(solver_name, args.dt, 1.0, p_inlet=8.85, p_outlet=0.0, nx=args.nx, ny=args.ny, nz=args.ny, quiet=True, **kw)
     if cfg == "p2t":
-        # `--solver stabilized_schur_backflow --p_grade 2` on the tetrahedral bifurcation (P2/P2, do-nothing outlets)
-        from cfd_hemodynamic_amd.scenarios.simple_bifurcation import MicrovasculatureSimulation
-        oracle = solver_name.startswith("_oracle")
-        kw = dict(kw)
-        kw["options"] = dict(kw.get("options", {}), remove_p_mean=0)
-        return MicrovasculatureSimulation(solver_name if oracle else "stabilized_schur_backflow", args.dt, 1.0, v_inlet=args.v_max, res=args.res3, p_grade=2,
-                                          v_max=args.v_max, beta_backflow=0.2, quiet=True, **(dict(kw, backflow=True) if oracle else kw))
-    if cfg == "q1":
-        # unit_square_pipe on quadrilateral cells (Q1/Q1), refined to --nx x --ny cells
-        from cfd_hemodynamic_amd.scenarios.unit_square_pipe import UnitSquarePipeSimulation
-        return UnitSquarePipeSimulation(solver_name, args.dt, 1.0, p_inlet=7.47, p_outlet=0.0, nx=args.nx, ny=args.ny, quiet=True, **kw)
+        # P2/P2 tetrahedra (`p_grade = 2` of stabilized_schur_backflow.py:84-87 on a 3-D mesh).  Workload: the duct
+        # of unit_cube_pipe with every brick split into six tetrahedra, degree 2 in both spaces through the plugin's degree switch
+        # (a measurement workload for the element type; on the millimetre-sized bifurcation P2/P2 sits in the viscous limit where
+        # the Cahouet-Chabard form does not converge)
+        from cfd_hemodynamic_amd.scenarios.unit_cube_pipe import UnitCubePipeSimulation
+        return UnitCubePipeSimulation(solver_name, args.dt, 1.0, p_inlet=8.85, p_outlet=0.0, nx=args.nx, ny=args.ny, nz=args.ny, cell_type="tetrahedron",
+                                      quiet=True, **dict(kw, _degree=2, p_grade=2))
     from cfd_hemodynamic_amd.scenarios.stenosis_with_tree import StenosisWithTreeSimulation
     return StenosisWithTreeSimulation(solver_name, args.dt, 1.0, grade="moderate", res=args.res, pulse_amplitude=0.5,
                                       ramp_time=args.ramp, inlet_max_velocity=args.v_max, quiet=True, **kw)
@@ -170,10 +173,11 @@ def workload_text(args, sc):
             "c4": "stenosis \"moderate\" = the reference's effective geometry for every grade (L=138, R_in=1.57, R_out=1.2, x_sten=30, severity .567, slope .4), ny=%d, inlet v_max=%g mm/s, p=0 outlet" % (args.ny, args.v_max),
             "c5": "stenosis_with_tree grade moderate (L=0.03, H=0.003, severity .5, slope .5; 3-generation Murray tree, 8 outlets p=0), "
                   "res=%g, pulsatile inlet v_max (1 + 0.5 sin 2 pi t) with a (1 - cos(pi t / %g)) / 2 start-up ramp, v_max=%g" % (args.res, args.ramp, args.v_max),
-            "p2": "stenosis (reference geometry) with stabilized_schur_backflow --p_grade 2: P2/P2 triangles on ny=%d cells across, inlet v_max=%g mm/s, do-nothing outlet + backflow stabilisation" % (args.ny, args.v_max),
+            "p2": "dfg_1 channel (block mesh m=%d) with stabilized_schur_backflow --p_grade 2 --v_max 0.3: P2/P2 triangles, do-nothing outlet + backflow stabilisation" % args.m,
+            "p2s": "stenosis (reference geometry) with stabilized_schur_backflow --p_grade 2: P2/P2 triangles on ny=%d cells across, inlet v_max=%g mm/s, do-nothing outlet + backflow stabilisation" % (args.ny, args.v_max),
             "q1": "unit_square_pipe (80 x 1.5 mm channel, p_inlet 7.47 / p_outlet 0, no-slip walls) on %d x %d quadrilateral cells, Q1/Q1" % (args.nx, args.ny),
             "q1h": "unit_cube_pipe (80 x 1.5 x 1.5 mm duct, p_inlet 8.85 / p_outlet 0, no-slip walls) on %d x %d x %d hexahedral cells, Q1/Q1" % (args.nx, args.ny, args.ny),
-            "p2t": "simple_bifurcation with stabilized_schur_backflow --p_grade 2: P2/P2 tetrahedra on the voxel-tet mesh res=%g, inlet u_y = %g (1 - (r/r_in)^2), do-nothing outlets + backflow stabilisation" % (args.res3, args.v_max),
+            "p2t": "unit_cube_pipe duct (80 x 1.5 x 1.5 mm, p_inlet 8.85 / p_outlet 0, no-slip walls) split into tetrahedra, %d x %d x %d bricks x 6, P2/P2" % (args.nx, args.ny, args.ny),
             "c5b": "simple_bifurcation (3-D, tetrahedra; Re=%s, inlet u_y = %g (1 - (r/r_in)^2), p = 0 at both outlets; remove_p_mean=0), voxel-tet mesh res=%g" % (
                 ("%.1f" % sc.Re) if args.config == "c5b" else "-", args.v_max, args.res3)}[args.config]
     return "%s: %d nodes, %d DOF (equal-order), dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)" % (
@@ -240,7 +244,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5", "c5b", "p2", "q1", "q1h", "p2t"],
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5", "c5b", "p2", "p2s", "q1", "q1h", "p2t"],
                     help="c3 (default) = the headline config; p2 / q1: the SURVEY 8f-4 element types (P2/P2 stenosis with the backflow plugin, "
                          "Q1/Q1 unit_square_pipe), no CPU leg")
     ap.add_argument("--res3", type=float, default=2.0e-4, help="c5b: voxel size of the 3-D bifurcation (2e-4: 256 k vertices, 1.03 M DOF; 1e-4: 1.95 M vertices, 7.8 M DOF)")
@@ -267,15 +271,17 @@ def main():
     if args.dt is None:
         args.dt = 0.001 if args.config == "c5" else 0.01
     if args.v_max is None:
-        args.v_max = {"c5": 0.05, "c5b": 1.5, "p2": 20.0, "p2t": 1.5}.get(args.config, 100.0)
-    if args.config == "p2" and args.ny == 115:
+        args.v_max = {"c5": 0.05, "c5b": 1.5, "p2s": 20.0}.get(args.config, 100.0)
+    if args.config == "p2s" and args.ny == 115:
         args.ny = 40      # 82 k vertices -> 330 k P2 nodes, ~1 M DOF
+    if args.config == "p2" and args.m == 200:
+        args.m = 100      # 84 k vertices -> 337 k P2 nodes, 1.01 M DOF
     if args.config == "q1" and (args.nx, args.ny) == (288, 115):
         args.nx, args.ny = 5870 // 2, 110 // 2   # the reference's 587 x 11 cells refined 5 x: 2935 x 55 -> 164 k nodes, 0.49 M DOF
     if args.config == "q1h" and (args.nx, args.ny) == (288, 115):
         args.nx, args.ny = 213 * 5, 4 * 2   # the reference's 213 x 4 x 4 cells: 5 x along the duct, 2 x across -> 86 k nodes, 345 k DOF
-    if args.config == "p2t" and args.res3 == 2.0e-4:
-        args.res3 = 4.0e-4                  # 36 k vertices -> ~270 k P2 nodes, ~1.1 M DOF
+    if args.config == "p2t" and (args.nx, args.ny) == (288, 115):
+        args.nx, args.ny = 213 * 2, 4       # 427 x 5 x 5 vertices -> ~80 k P2 nodes, ~320 k DOF
     if args.parity_steps is None:
         args.parity_steps = {"c5": 0, "c5b": 1, "p2t": 1, "q1h": 1}.get(args.config, 2)
 
@@ -469,9 +475,9 @@ def main():
                     "algorithmic_bytes": d["algorithmic_MB"] * 1e6, "empty_event_pair_us": ovh_us}
 
     label = {"c3": "dfg_1 ~1M DOF", "c2": "lid_driven2D ~250k DOF", "c4": "stenosis moderate ~2M DOF",
-             "c5": "stenosis_with_tree ~8M DOF pulsatile", "c5b": "simple_bifurcation 3-D tets", "p2": "stenosis P2/P2 ~1M DOF (backflow plugin)",
+             "c5": "stenosis_with_tree ~8M DOF pulsatile", "c5b": "simple_bifurcation 3-D tets", "p2": "dfg_1 P2/P2 ~1M DOF (backflow plugin)", "p2s": "stenosis P2/P2 ~1M DOF (backflow plugin)",
              "q1": "unit_square_pipe Q1/Q1 quadrilaterals", "q1h": "unit_cube_pipe Q1/Q1 hexahedra",
-             "p2t": "simple_bifurcation P2/P2 tetrahedra (backflow plugin)"}[args.config]
+             "p2t": "unit_cube_pipe duct on P2/P2 tetrahedra"}[args.config]
     kits = max(sum(its_krylov), 1)
     out = {
         "metric": "time-steps/sec, %s (%s)" % (label, args.solver),

@@ -8,7 +8,8 @@
     (:157-177); zero initial velocity; blood in mm-g-s units, rho = 1.06e-3, mu = 3.5e-3 (:70-71).
 
 With `--solver stabilized_schur` the spaces are ("Lagrange", "hexahedron", 1): Q1/Q1 on hexahedra -- SURVEY.md section 8f-4.
-`nx`, `ny`, `nz` override the resolution (tests, bench).
+`nx`, `ny`, `nz` override the resolution (tests, bench).  `cell_type="tetrahedron"` splits every brick into six Kuhn tetrahedra
+(the duct as a workload for the tetrahedral element types; the reference builds hexahedra only).
 """
 from __future__ import annotations
 
@@ -35,7 +36,8 @@ class UnitCubePipeSimulation(Scenario):
 
     def __init__(self, solver_name, dt, T, f: tuple = (0.0, 0.0, 0.0), *, rho: float = 1.06e-3, mu: float = 3.5e-3, p_inlet: float,
                  p_outlet: float, early_stop_tolerance: float = 1e-5, nx: int = _NX, ny: int = _NY, nz: int = _NZ, L: float = _L,
-                 W: float = _W, H: float = _H, **solver_kwargs):
+                 W: float = _W, H: float = _H, cell_type: str = "hexahedron", **solver_kwargs):
+        self.cell_type = str(cell_type).split(".")[-1]
         self.p_inlet, self.p_outlet = float(p_inlet), float(p_outlet)
         self.nx, self.ny, self.nz, self.L, self.W, self.H = int(nx), int(ny), int(nz), float(L), float(W), float(H)
         self._mesh = self._ft = self._bcu = self._bcp = None
@@ -48,7 +50,13 @@ class UnitCubePipeSimulation(Scenario):
     @property
     def mesh(self):
         if self._mesh is None:
-            m = create_box((0.0, 0.0, 0.0), (self.L, self.W, self.H), (self.nx, self.ny, self.nz), cell_type="hexahedron")
+            if self.cell_type == "tetrahedron":
+                from ..mesh3d import Mesh3D, _voxel_tets
+                xs, ys, zs = (np.linspace(0.0, hi, n + 1) for hi, n in ((self.L, self.nx), (self.W, self.ny), (self.H, self.nz)))
+                cells, pts = _voxel_tets(np.ones((self.nx, self.ny, self.nz), bool), xs, ys, zs)
+                m = Mesh3D(cells, pts, name="unit_cube_pipe")
+            else:
+                m = create_box((0.0, 0.0, 0.0), (self.L, self.W, self.H), (self.nx, self.ny, self.nz), cell_type="hexahedron")
             fdim = 2
             inlet = locate_entities_boundary(m, fdim, lambda x: np.isclose(x[0], 0.0))
             outlet = locate_entities_boundary(m, fdim, lambda x: np.isclose(x[0], self.L))

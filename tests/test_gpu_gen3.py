@@ -200,16 +200,48 @@ def test_unit_cube_pipe_on_hexahedra(tmp_path):
 
 def test_backflow_plugin_with_p_grade_2_on_tetrahedra():
     """`stabilized_schur_backflow` with `p_grade = 2` on a 3-D mesh (stabilized_schur_backflow.py:63,84-87 with the tetrahedral
-    meshes of scenario_factory.py:47-49): P2/P2 on the coarse bifurcation, do-nothing outlets with backflow stabilisation; two steps
-    of the scenario loop against the twin."""
-    from cfd_hemodynamic_amd.scenarios.simple_bifurcation import MicrovasculatureSimulation
-    sc = MicrovasculatureSimulation("stabilized_schur_backflow", 0.01, 0.015, v_inlet=1.5, res=1.6e-3, quiet=True, v_max=1.5, p_grade=2, beta_backflow=0.2,
-                                    options=dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10, remove_p_mean=0))
-    dm = sc.solver.V.mesh
+    meshes of scenario_factory.py:47-49): the plugin class itself -- spaces of degree 2 on tetrahedra, do-nothing outlet with the
+    backflow term on tags["outlet"], no pressure condition -- on a duct of Kuhn tetrahedra, two steps against the twin."""
+    from cfd_hemodynamic_amd.boundaryCondition import BoundaryCondition
+    from cfd_hemodynamic_amd.fem import Function
+    from cfd_hemodynamic_amd.mesh import locate_entities_boundary, meshtags
+    from cfd_hemodynamic_amd.mesh3d import create_unit_cube
+    from cfd_hemodynamic_amd.solvers.stabilized_schur_backflow import Solver
+    mesh = create_unit_cube(3)
+    inlet = locate_entities_boundary(mesh, 2, lambda x: np.isclose(x[0], 0.0))
+    outlet = locate_entities_boundary(mesh, 2, lambda x: np.isclose(x[0], 1.0))
+    wall = locate_entities_boundary(mesh, 2, lambda x: np.isclose(x[1], 0.0) | np.isclose(x[1], 1.0) | np.isclose(x[2], 0.0) | np.isclose(x[2], 1.0))
+    idx = np.concatenate([inlet, outlet, wall])
+    val = np.concatenate([np.full(len(inlet), 1), np.full(len(outlet), 2), np.full(len(wall), 3)]).astype(np.int32)
+    order = np.argsort(idx)
+    ft = meshtags(mesh, 2, idx[order], val[order])
+    s = Solver(mesh, 0.02, 1.0, 0.02, [0.0, 0.0, 0.0], v_max=1.0, p_grade=2, beta_backflow=0.2, quiet=True,
+               options=dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10))
+    dm = s.V.mesh
     nv = dm.num_vertices
-    assert sc.solver.p_grade == 2 and sc.solver.ctx.info(28) == 1 and sc.solver.ctx.info(29) == 10 and nv > sc.mesh.num_vertices
-    u0 = np.array(sc.solver.u_prev.x.array, dtype=float)
-    sc.solve(None)
-    assert sc.num_steps == 2 and sc.solver.last_stats.reason > 0
-    xg = np.concatenate([np.asarray(sc.solver.u_sol.x.array), np.asarray(sc.solver.p_sol.x.array)])
-    assert np.isfinite(xg).all() and np.abs(xg[: 3 * nv]).max() > 0
+    assert s.p_grade == 2 and s.ctx.info(28) == 1 and s.ctx.info(29) == 10 and s.ctx.info(26) == 3 and nv > mesh.num_vertices
+    assert s.V.dofmap.index_map.size_global == nv and s.V.dofmap.index_map_bs == 3
+    prof = lambda x: np.stack([16.0 * x[1] * (1 - x[1]) * x[2] * (1 - x[2]), 0 * x[0], 0 * x[0]])  # noqa: E731
+    u_in = Function(s.V)
+    u_in.interpolate(prof)
+    bc_w = BoundaryCondition(Function(s.V))
+    bc_w.initTopological(2, ft.find(3))
+    bc_i = BoundaryCondition(u_in)
+    bc_i.initTopological(2, ft.find(1))
+    s.setup([bc_w, bc_i], [], ft, {"inlet": 1, "outlet": 2, "wall": 3, "obstacle": -1})
+    prm = TN.Params(0.02, 1.0, 0.02, (0.0, 0.0, 0.0), ds_terms=False, beta_backflow=0.2)
+    pb = problem3("P2", dm, prm)
+    pb.set_boundary_terms(False, ft.find(2), 0.2)
+    wn, inn = facet_node_set3(dm, ft.find(3)), facet_node_set3(dm, ft.find(1))
+    pb.add_bc_u(wn, np.zeros((len(wn), 3)))
+    pb.add_bc_u(inn, prof(dm.x[inn].T).T)
+    x, un = np.zeros(4 * nv), np.zeros((nv, 3))
+    for step in range(2):
+        s.solveStep()
+        assert s.last_stats.reason > 0
+        xg = np.concatenate([np.asarray(s.u_sol.x.array), np.asarray(s.p_sol.x.array)])
+        s.advance()
+        x, _ = pb.newton(x, un)
+        un = x[: 3 * nv].reshape(-1, 3).copy()
+        assert np.abs(xg[: 3 * nv] - x[: 3 * nv]).max() <= 1e-8 * np.abs(x[: 3 * nv]).max(), step
+        assert np.abs(xg[3 * nv:] - x[3 * nv:]).max() <= 1e-7 * np.abs(x[3 * nv:]).max(), step
