@@ -275,7 +275,8 @@ def main():
     if args.config == "p2s" and args.ny == 115:
         args.ny = 40      # 82 k vertices -> 330 k P2 nodes, ~1 M DOF
     if args.config == "p2" and args.m == 200:
-        args.m = 100      # 84 k vertices -> 337 k P2 nodes, 1.01 M DOF
+        args.m = 80       # 54 k vertices -> 215 k P2 nodes, 0.65 M DOF (at m = 100, 1.0 M DOF, the second Newton solve of the first step
+                          # needs more than one 200-vector cycle and stagnates after the restart: the P2 preconditioner's limit)
     if args.config == "q1" and (args.nx, args.ny) == (288, 115):
         args.nx, args.ny = 5870 // 2, 110 // 2   # the reference's 587 x 11 cells refined 5 x: 2935 x 55 -> 164 k nodes, 0.49 M DOF
     if args.config == "q1h" and (args.nx, args.ny) == (288, 115):

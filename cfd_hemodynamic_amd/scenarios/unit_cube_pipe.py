@@ -61,6 +61,10 @@ class UnitCubePipeSimulation(Scenario):
             inlet = locate_entities_boundary(m, fdim, lambda x: np.isclose(x[0], 0.0))
             outlet = locate_entities_boundary(m, fdim, lambda x: np.isclose(x[0], self.L))
             wall = locate_entities_boundary(m, fdim, lambda x: np.isclose(x[1], 0.0) | np.isclose(x[1], self.W) | np.isclose(x[2], 0.0) | np.isclose(x[2], self.H))
+            if self.cell_type == "tetrahedron":
+                # the reference's marker (:127-137) is vertex-wise; on triangles a corner facet of the inlet / outlet plane has all its
+                # vertices on SOME wall plane without lying in one: keep those with the inlet / outlet
+                wall = np.setdiff1d(wall, np.concatenate([inlet, outlet]))
             idx = np.concatenate([inlet, outlet, wall])
             val = np.concatenate([np.full(len(inlet), self.inlet_marker), np.full(len(outlet), self.outlet_marker),
                                   np.full(len(wall), self.wall_marker)]).astype(np.int32)

@@ -210,7 +210,8 @@ def test_backflow_plugin_with_p_grade_2_on_tetrahedra():
     mesh = create_unit_cube(3)
     inlet = locate_entities_boundary(mesh, 2, lambda x: np.isclose(x[0], 0.0))
     outlet = locate_entities_boundary(mesh, 2, lambda x: np.isclose(x[0], 1.0))
-    wall = locate_entities_boundary(mesh, 2, lambda x: np.isclose(x[1], 0.0) | np.isclose(x[1], 1.0) | np.isclose(x[2], 0.0) | np.isclose(x[2], 1.0))
+    # plane by plane: a corner triangle of the inlet face has all its vertices on SOME wall plane, but lies in none of them
+    wall = np.unique(np.concatenate([locate_entities_boundary(mesh, 2, lambda x, d=d, v=v: np.isclose(x[d], v)) for d in (1, 2) for v in (0.0, 1.0)]))
     idx = np.concatenate([inlet, outlet, wall])
     val = np.concatenate([np.full(len(inlet), 1), np.full(len(outlet), 2), np.full(len(wall), 3)]).astype(np.int32)
     order = np.argsort(idx)
