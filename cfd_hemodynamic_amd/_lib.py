@@ -41,7 +41,7 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp)
 
 # every symbol include/cfdh.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "cfdh_create", "cfdh_create_elem", "cfdh_set_facet_markers", "cfdh_destroy", "cfdh_last_error", "cfdh_abi_version", "cfdh_set_params", "cfdh_default_options",
+    "cfdh_create", "cfdh_create_elem", "cfdh_create_elem_part", "cfdh_set_facet_markers", "cfdh_destroy", "cfdh_last_error", "cfdh_abi_version", "cfdh_set_params", "cfdh_default_options",
     "cfdh_set_options", "cfdh_clear_dirichlet", "cfdh_add_dirichlet", "cfdh_update_dirichlet", "cfdh_set_state", "cfdh_get_solution",
     "cfdh_get_previous", "cfdh_get_residual", "cfdh_advance", "cfdh_advance_field", "cfdh_set_time_scheme", "cfdh_set_previous2", "cfdh_get_previous2",
     "cfdh_shift_history", "cfdh_set_boundary_terms", "cfdh_assemble", "cfdh_get_csr", "cfdh_spmv", "cfdh_solve_step",
@@ -77,6 +77,7 @@ def lib():
     vp = C.c_void_p
     L.cfdh_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, ip, dp, C.c_int64, ip, ip, ip]
     L.cfdh_create_elem.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, ip, dp, C.c_int64, ip, ip, ip]
+    L.cfdh_create_elem_part.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, ip, dp, C.c_int64, ip, ip, ip]
     L.cfdh_set_facet_markers.argtypes = [vp, C.c_int64, ip]
     L.cfdh_destroy.argtypes = [vp]
     L.cfdh_destroy.restype = None
@@ -172,8 +173,12 @@ class Context:
         fm = np.ascontiguousarray(facet_marker, dtype=np.int32)
         h = C.c_void_p()
         if self.etype:
-            rc = L.cfdh_create_elem(C.byref(h), int(device), self.dim, self.etype, self.nv, len(self.cells), _ip(self.cells), _dp(self.x),
-                                    len(fc), _ip(fc), _ip(fl), _ip(fm))
+            if self.nvo != self.nv:   # one part of a partitioned run (owned nodes first, ghosts after)
+                rc = L.cfdh_create_elem_part(C.byref(h), int(device), self.dim, self.etype, self.nv, self.nvo, len(self.cells), _ip(self.cells),
+                                             _dp(self.x), len(fc), _ip(fc), _ip(fl), _ip(fm))
+            else:
+                rc = L.cfdh_create_elem(C.byref(h), int(device), self.dim, self.etype, self.nv, len(self.cells), _ip(self.cells), _dp(self.x),
+                                        len(fc), _ip(fc), _ip(fl), _ip(fm))
         else:
             rc = L.cfdh_create(C.byref(h), int(device), self.dim, self.nv, self.nvo, len(self.cells), _ip(self.cells), _dp(self.x),
                                len(fc), _ip(fc), _ip(fl), _ip(fm))

@@ -43,7 +43,7 @@ static int create_ctx(cfdh_ctx **out, int device, int gdim, int etype, int64_t n
   *out = nullptr;
   if (gdim != 2 && gdim != 3) return cfdh_fail(nullptr, CFDH_E_ARG, "gdim must be 2 (P1 triangles) or 3 (P1 tetrahedra)");
   if (etype < 0 || etype > 3) return cfdh_fail(nullptr, CFDH_E_ARG, "unknown element type %d", etype);
-  if (etype != 0 && nv_owned != nv) return cfdh_fail(nullptr, CFDH_E_ARG, "P2 / Q1 contexts are single-GPU: nv_owned must equal nv");
+  if (etype != 0 && gdim == 3 && nv_owned != nv) return cfdh_fail(nullptr, CFDH_E_ARG, "3-D P2 / Q1 contexts are single-GPU: nv_owned must equal nv");
   if (!cells || !coords || (nfacets > 0 && (!facet_cells || !facet_local)))
     return cfdh_fail(nullptr, CFDH_E_ARG, "null mesh array");
   int ndev = 0;
@@ -78,7 +78,7 @@ static int create_ctx(cfdh_ctx **out, int device, int gdim, int etype, int64_t n
       rc = gdim == 3 ? kg3_upload_tables(c) : kg_upload_tables(c);
       if (rc) break;
       rc = gdim == 3 ? cfdh_build_mesh_gen3(c, etype, nv, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker)
-                     : cfdh_build_mesh_gen(c, etype, nv, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker);
+                     : cfdh_build_mesh_gen(c, etype, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker);
       break;
     }
     rc = gdim == 3 ? cfdh_build_mesh3(c, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker)
@@ -102,6 +102,11 @@ int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_own
 int cfdh_create_elem(cfdh_ctx **out, int device, int gdim, int elem, int64_t nn, int64_t nc, const int32_t *cells, const double *node_coords,
                      int64_t nfacets, const int32_t *facet_cells, const int32_t *facet_local, const int32_t *facet_marker) {
   return create_ctx(out, device, gdim, elem, nn, nn, nc, cells, node_coords, nfacets, facet_cells, facet_local, facet_marker);
+}
+
+int cfdh_create_elem_part(cfdh_ctx **out, int device, int gdim, int elem, int64_t nn, int64_t nn_owned, int64_t nc, const int32_t *cells,
+                          const double *node_coords, int64_t nfacets, const int32_t *facet_cells, const int32_t *facet_local, const int32_t *facet_marker) {
+  return create_ctx(out, device, gdim, elem, nn, nn_owned, nc, cells, node_coords, nfacets, facet_cells, facet_local, facet_marker);
 }
 
 void cfdh_destroy(cfdh_ctx *c) {
@@ -484,8 +489,9 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
   if (nvg <= 0 || ncg <= 0 || !cells || !coords || !owned_global || (n_pbc > 0 && !pbc_nodes))
     return cfdh_fail(c, CFDH_E_ARG, "bad global pressure space arguments");
   const int n = (int)nvg;
-  const int D = c->dim, NLc = D + 1;  // global cells [ncg][D + 1], coords [nvg][D]
-  for (int64_t k = 0; k < NLc * ncg; k++) if (cells[k] < 0 || cells[k] >= n) return cfdh_fail(c, CFDH_E_ARG, "global cell vertex out of range");
+  const int D = c->dim, NLc = D + 1;  // vertex records of the halo vectors: D + 1 doubles
+  const int NCc = c->gen ? c->nloc : D + 1;  // global cells [ncg][nodes per cell], coords [nvg][D]
+  for (int64_t k = 0; k < (int64_t)NCc * ncg; k++) if (cells[k] < 0 || cells[k] >= n) return cfdh_fail(c, CFDH_E_ARG, "global cell vertex out of range");
   std::vector<unsigned char> pbc(n, 0);
   for (int64_t k = 0; k < n_pbc; k++) {
     if (pbc_nodes[k] < 0 || pbc_nodes[k] >= n) return cfdh_fail(c, CFDH_E_ARG, "global Dirichlet node out of range");
@@ -493,7 +499,19 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
   }
   // global P1 stiffness as (row, col, value) triplets -> CSR with Dirichlet rows/cols removed
   std::vector<std::vector<std::pair<int, double>>> rows(n);
-  for (int64_t e = 0; e < ncg && D == 3; e++) {
+  if (c->gen) {  // P2 / Q1: the element's own stiffness by quadrature (csrc/cfdh_gen.hip), as h_Lval holds it for the local part
+    if (D != 2) return cfdh_fail(c, CFDH_E_ARG, "partitioned P2 / Q1 runs exist for gdim 2");
+    std::vector<double> K((size_t)NCc * NCc);
+    for (int64_t e = 0; e < ncg; e++) {
+      const int32_t *v = cells + (size_t)NCc * e;
+      CHK(cfdh_gen_element_stiffness(c, v, coords, K.data()));
+      for (int a = 0; a < NCc; a++) {
+        if (pbc[v[a]]) continue;
+        for (int b = 0; b < NCc; b++) if (!pbc[v[b]]) rows[v[a]].push_back({v[b], K[(size_t)a * NCc + b]});
+      }
+    }
+  }
+  for (int64_t e = 0; e < ncg && D == 3 && !c->gen; e++) {
     // tetrahedra: rows of the inverse of [x1-x0 | x2-x0 | x3-x0] are grad lambda_1..3, volume |det| / 6
     const int32_t *v = cells + 4 * e;
     double d[3][3], cr[3][3], g[4][3];
@@ -516,7 +534,7 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
       }
     }
   }
-  for (int64_t e = 0; e < ncg && D == 2; e++) {
+  for (int64_t e = 0; e < ncg && D == 2 && !c->gen; e++) {
     const int32_t *v = cells + 3 * e;
     const double x0 = coords[2 * v[0]], y0 = coords[2 * v[0] + 1], x1 = coords[2 * v[1]], y1 = coords[2 * v[1] + 1],
                  x2 = coords[2 * v[2]], y2 = coords[2 * v[2] + 1];

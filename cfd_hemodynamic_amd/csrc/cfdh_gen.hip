@@ -145,6 +145,11 @@ __device__ __forceinline__ void tau_pair(double s, double h, double dt, double n
   tauL = vn * h * z * 0.5;
 }
 
+// offsets of a node's velocity / pressure in the state layout [u owned 2 nvo | p owned nvo | (u_x, u_y, p) per ghost] (round 4:
+// P2 / Q1 contexts take part in partitioned runs; with nvo == nv these are 2 v and 2 nvo + v)
+__device__ __forceinline__ size_t guo(int v, int nvo) { return v < nvo ? 2 * (size_t)v : 3 * (size_t)nvo + 3 * (size_t)(v - nvo); }
+__device__ __forceinline__ size_t gpo(int v, int nvo) { return v < nvo ? 2 * (size_t)nvo + v : 3 * (size_t)nvo + 3 * (size_t)(v - nvo) + 2; }
+
 // per-cell nodal data in LDS
 template <int NL>
 struct CellData {
@@ -175,13 +180,13 @@ __global__ __launch_bounds__(TPB) void gen_asm_kernel(GenArgs P) {
     D.bc[a] = bf;
     for (int i = 0; i < 2; i++) {
       D.X[a][i] = P.coords[2 * (size_t)v + i];
-      const double u = P.x[2 * (size_t)v + i], un = P.xprev[2 * (size_t)v + i];
+      const double u = P.x[guo(v, nvo) + i], un = P.xprev[guo(v, nvo) + i];
       D.un[a][i] = un;
       D.ub[a][i] = P.theta * u + (1.0 - P.theta) * un;
-      D.wn[a][i] = (P.a0 * u + P.a1 * un + (P.a2 != 0.0 ? P.a2 * P.xprev2[2 * (size_t)v + i] : 0.0)) / P.dt;
+      D.wn[a][i] = (P.a0 * u + P.a1 * un + (P.a2 != 0.0 ? P.a2 * P.xprev2[guo(v, nvo) + i] : 0.0)) / P.dt;
       D.lift[a][i] = (bf >> i) & 1 ? P.bcval[3 * (size_t)v + i] - u : 0.0;
     }
-    const double pv = P.x[2 * (size_t)nvo + v];
+    const double pv = P.x[gpo(v, nvo)];
     D.p[a] = pv;
     D.lift[a][2] = (bf >> 2) & 1 ? P.bcval[3 * (size_t)v + 2] - pv : 0.0;
   }
@@ -360,8 +365,10 @@ __global__ __launch_bounds__(TPB) void gen_asm_kernel(GenArgs P) {
     Fa[2] += Jpu[b][0] * l0 + Jpu[b][1] * l1 + Jpp[b] * l2;
   }
   // constrained rows / columns contribute zeros (their rows are written by gen_bc_rows_kernel)
+  const int fd = P.fdst[(size_t)cell * NL + a];
+  if (fd < 0) return;  // row of a ghost node: assembled by its owner (one-cell overlap of the partition)
   {
-    double *ef = P.EF + 3 * (size_t)P.fdst[(size_t)cell * NL + a];
+    double *ef = P.EF + 3 * (size_t)fd;
     ef[0] = (bca & 1u) ? 0.0 : Fa[0];
     ef[1] = (bca & 2u) ? 0.0 : Fa[1];
     ef[2] = (bca & 4u) ? 0.0 : Fa[2];
@@ -446,18 +453,19 @@ __device__ __forceinline__ double block_sum_d(double v, double *sh) {
 
 // int u.u and int p^2 with the element's own mass matrix (scenario.py:315-324)
 template <int ET>
-__global__ __launch_bounds__(TPB) void gen_l2_kernel(int nc, int nvo, const int *__restrict__ cells, const double *__restrict__ coords,
-                                                     const double *__restrict__ x, double *__restrict__ partial) {
+__global__ __launch_bounds__(TPB) void gen_l2_kernel(int nc, int nvo, const int *__restrict__ cells, const unsigned char *__restrict__ cell_owned,
+                                                     const double *__restrict__ coords, const double *__restrict__ x, double *__restrict__ partial) {
   constexpr int NL = ET == 0 ? 3 : (ET == 1 ? 6 : 4);
   __shared__ double sh[4];
   double au = 0, ap = 0;
   const GenTab &T = d_tab[ET];
   for (int e = blockIdx.x * TPB + threadIdx.x; e < nc; e += gridDim.x * TPB) {
+    if (!cell_owned[e]) continue;  // every cell is integrated by exactly one rank
     double X[3][2], u[NL][2], p[NL];
     for (int a = 0; a < NL; a++) {
       const int v = cells[(size_t)e * NL + a];
       if (a < 3) { X[a][0] = coords[2 * (size_t)v]; X[a][1] = coords[2 * (size_t)v + 1]; }
-      u[a][0] = x[2 * (size_t)v]; u[a][1] = x[2 * (size_t)v + 1]; p[a] = x[2 * (size_t)nvo + v];
+      u[a][0] = x[guo(v, nvo)]; u[a][1] = x[guo(v, nvo) + 1]; p[a] = x[gpo(v, nvo)];
     }
     const double adet = fabs((X[1][0] - X[0][0]) * (X[2][1] - X[0][1]) - (X[1][1] - X[0][1]) * (X[2][0] - X[0][0]));
     for (int q = 0; q < GEN_NQ; q++) {
@@ -476,20 +484,21 @@ __global__ __launch_bounds__(TPB) void gen_l2_kernel(int nc, int nvo, const int 
 template <int ET>
 __global__ __launch_bounds__(TPB) void gen_facet_functional_kernel(int nfac, int marker, int kind, int nvo, const int *__restrict__ fcell,
                                                                    const int *__restrict__ flocal, const int *__restrict__ fmarker,
-                                                                   const int *__restrict__ cells, const double *__restrict__ coords,
-                                                                   const double *__restrict__ x, double mu, double *__restrict__ partial) {
+                                                                   const int *__restrict__ cells, const unsigned char *__restrict__ cell_owned,
+                                                                   const double *__restrict__ coords, const double *__restrict__ x, double mu,
+                                                                   double *__restrict__ partial) {
   constexpr int NL = ET == 0 ? 3 : (ET == 1 ? 6 : 4);
   constexpr int NV = ET == 2 ? 4 : 3, NQF = ET == 1 ? 4 : 2;
   __shared__ double sh[4];
   double a0 = 0, a1 = 0;
   for (int k = blockIdx.x * TPB + threadIdx.x; k < nfac; k += gridDim.x * TPB) {
-    if (fmarker[k] != marker) continue;
+    if (fmarker[k] != marker || !cell_owned[fcell[k]]) continue;
     const int e = fcell[k], f = flocal[k];
     double X[NL][2], u[NL][2], p[NL];
     for (int a = 0; a < NL; a++) {
       const int v = cells[(size_t)e * NL + a];
       X[a][0] = coords[2 * (size_t)v]; X[a][1] = coords[2 * (size_t)v + 1];
-      u[a][0] = x[2 * (size_t)v]; u[a][1] = x[2 * (size_t)v + 1]; p[a] = x[2 * (size_t)nvo + v];
+      u[a][0] = x[guo(v, nvo)]; u[a][1] = x[guo(v, nvo) + 1]; p[a] = x[gpo(v, nvo)];
     }
     const double J00 = X[1][0] - X[0][0], J01 = X[2][0] - X[0][0], J10 = X[1][1] - X[0][1], J11 = X[2][1] - X[0][1];
     const double idet = 1.0 / (J00 * J11 - J01 * J10);
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(TPB) void gen_wss_kernel(int nfac, int nvo, const i
   for (int a = 0; a < NL; a++) {
     vs[a] = cells[(size_t)e * NL + a];
     X[a][0] = coords[2 * (size_t)vs[a]]; X[a][1] = coords[2 * (size_t)vs[a] + 1];
-    u[a][0] = x[2 * (size_t)vs[a]]; u[a][1] = x[2 * (size_t)vs[a] + 1];
+    u[a][0] = x[guo(vs[a], nvo)]; u[a][1] = x[guo(vs[a], nvo) + 1];
   }
   const double J00 = X[1][0] - X[0][0], J01 = X[2][0] - X[0][0], J10 = X[1][1] - X[0][1], J11 = X[2][1] - X[0][1];
   const double idet = 1.0 / (J00 * J11 - J01 * J10);
@@ -611,9 +620,10 @@ int cfdh_facet_nodes(const cfdh_ctx *c, int f, int out[3]) {
 
 // Mesh upload for the generic element path: Morton numbering of the nodes, node graph, value slots of every local node pair,
 // stiffness / diagonal mass of the element on the graph (Cahouet-Chabard preconditioner), state and work vectors.
-int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, const int32_t *cells, const double *coords, int64_t nfac64,
+int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv64, int64_t nvo64, int64_t nc64, const int32_t *cells, const double *coords, int64_t nfac64,
                         const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker) {
-  const int nv = (int)nv64, nc = (int)nc64, nfac = (int)nfac64;
+  const int nv = (int)nv64, nvo = (int)nvo64, nc = (int)nc64, nfac = (int)nfac64;
+  if (nvo <= 0 || nvo > nv) return cfdh_fail(c, CFDH_E_ARG, "bad owned node count");
   const int et = etype == 3 ? 0 : etype;  // 3: P1 triangles through the generic kernels (cross-check of the closed-form path)
   const int NL = gen_nloc(et), NF = et == 2 ? 4 : 3;
   if (nv <= 0 || nc <= 0) return cfdh_fail(c, CFDH_E_ARG, "bad mesh sizes");
@@ -623,25 +633,28 @@ int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, cons
   for (int k = 0; k < nfac; k++)
     if (fcell[k] < 0 || fcell[k] >= nc || flocal[k] < 0 || flocal[k] >= NF) return cfdh_fail(c, CFDH_E_ARG, "facet (cell, local) out of range");
   c->etype = et; c->nloc = NL; c->gen = true;
-  c->nv = c->nvo = nv; c->ng = 0;
-  c->NO = c->NL = 3 * nv;
-  // ---- node numbering along a Morton curve
+  // partitioned runs (round 4): nodes [0, nvo) are owned, the rest are the ghost nodes of the one-cell overlap in the order of the
+  // halo plan; rows are assembled for owned nodes only; vectors carry the ghost tail [(u_x, u_y, p) per ghost]
+  c->nv = nv; c->nvo = nvo; c->ng = nv - nvo;
+  c->NO = 3 * nvo; c->NL = 3 * nvo + 3 * c->ng;
+  // ---- node numbering: owned nodes along a Morton curve, ghosts unchanged
   c->perm.resize(nv); c->iperm.resize(nv);
   {
-    std::vector<int> order(nv);
+    std::vector<int> order(nvo);
     std::iota(order.begin(), order.end(), 0);
     double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
     for (int v = 0; v < nv; v++)
       for (int i = 0; i < 2; i++) { lo[i] = std::min(lo[i], coords[2 * v + i]); hi[i] = std::max(hi[i], coords[2 * v + i]); }
     const double ext = std::max(hi[0] - lo[0], hi[1] - lo[1]);
     if (!(ext > 0)) return cfdh_fail(c, CFDH_E_ARG, "degenerate coordinates");
-    std::vector<uint32_t> key(nv);
-    for (int v = 0; v < nv; v++) {
+    std::vector<uint32_t> key(nvo);
+    for (int v = 0; v < nvo; v++) {
       const uint32_t qx = (uint32_t)std::min(65535.0, (coords[2 * v] - lo[0]) / ext * 65535.0), qy = (uint32_t)std::min(65535.0, (coords[2 * v + 1] - lo[1]) / ext * 65535.0);
       key[v] = part1by1(qx) | (part1by1(qy) << 1);
     }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
-    for (int k = 0; k < nv; k++) { c->iperm[k] = order[k]; c->perm[order[k]] = k; }
+    for (int k = 0; k < nvo; k++) { c->iperm[k] = order[k]; c->perm[order[k]] = k; }
+    for (int v = nvo; v < nv; v++) { c->iperm[v] = v; c->perm[v] = v; }
   }
   c->h_coords.resize(2 * (size_t)nv);
   for (int k = 0; k < nv; k++) { c->h_coords[2 * k] = coords[2 * c->iperm[k]]; c->h_coords[2 * k + 1] = coords[2 * c->iperm[k] + 1]; }
@@ -684,12 +697,12 @@ int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, cons
     for (int e = 0; e < nc; e++)
       for (int a = 0; a < NL; a++) { const int v = c->h_cells[(size_t)NL * e + a]; ncell[ncptr[v] + fill[v]++] = e; }
   }
-  c->h_vptr.assign(nv + 1, 0);
-  c->h_vcol.clear(); c->h_vcol.reserve((size_t)14 * nv);
-  c->h_vdiag.resize(nv);
+  c->h_vptr.assign(nvo + 1, 0);
+  c->h_vcol.clear(); c->h_vcol.reserve((size_t)14 * nvo);
+  c->h_vdiag.resize(nvo);
   {
     std::vector<int> tmp;
-    for (int v = 0; v < nv; v++) {
+    for (int v = 0; v < nvo; v++) {
       if (ncptr[v + 1] == ncptr[v]) return cfdh_fail(c, CFDH_E_ARG, "node %d belongs to no cell", c->iperm[v]);
       tmp.clear();
       for (int k = ncptr[v]; k < ncptr[v + 1]; k++)
@@ -729,10 +742,14 @@ int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, cons
     }
     msum += adet * (et == 2 ? 1.0 : 0.5);
     for (int a = 0; a < NL; a++) {
-      const int *nb = &c->h_vcol[c->h_vptr[v[a]]];
-      const int deg = c->h_vptr[v[a] + 1] - c->h_vptr[v[a]];
       mdiag[v[a]] += Md[a];
       dsum += Md[a];
+      if (v[a] >= nvo) {  // row of a ghost node: assembled by its owner
+        for (int b = 0; b < NL; b++) slot[((size_t)e * NL + a) * NL + b] = -1;
+        continue;
+      }
+      const int *nb = &c->h_vcol[c->h_vptr[v[a]]];
+      const int deg = c->h_vptr[v[a] + 1] - c->h_vptr[v[a]];
       for (int b = 0; b < NL; b++) {
         const int k = c->h_vptr[v[a]] + (int)(std::lower_bound(nb, nb + deg, v[b]) - nb);
         slot[((size_t)e * NL + a) * NL + b] = k;
@@ -765,18 +782,18 @@ int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, cons
     }
   }
   // staging order of the assembly (see the header): contributions to one block entry / one node adjacent, in cell order
-  std::vector<int> eptr((size_t)c->nnzv + 1, 0), fptr((size_t)nv + 1, 0), fdst((size_t)nc * NL);
-  for (size_t t = 0; t < slot.size(); t++) eptr[slot[t] + 1]++;
+  std::vector<int> eptr((size_t)c->nnzv + 1, 0), fptr((size_t)nvo + 1, 0), fdst((size_t)nc * NL, -1);
+  for (size_t t = 0; t < slot.size(); t++) if (slot[t] >= 0) eptr[slot[t] + 1]++;
   for (int k = 0; k < c->nnzv; k++) eptr[k + 1] += eptr[k];
   {
     std::vector<int> fill(eptr.begin(), eptr.end() - 1);
-    for (size_t t = 0; t < slot.size(); t++) slot[t] = fill[slot[t]]++;  // (cells ascending: t runs over e first)
+    for (size_t t = 0; t < slot.size(); t++) if (slot[t] >= 0) slot[t] = fill[slot[t]]++;  // (cells ascending: t runs over e first)
   }
-  for (size_t t = 0; t < (size_t)nc * NL; t++) fptr[c->h_cells[t] + 1]++;
-  for (int v = 0; v < nv; v++) fptr[v + 1] += fptr[v];
+  for (size_t t = 0; t < (size_t)nc * NL; t++) if (c->h_cells[t] < nvo) fptr[c->h_cells[t] + 1]++;
+  for (int v = 0; v < nvo; v++) fptr[v + 1] += fptr[v];
   {
     std::vector<int> fill(fptr.begin(), fptr.end() - 1);
-    for (size_t t = 0; t < (size_t)nc * NL; t++) fdst[t] = fill[c->h_cells[t]]++;
+    for (size_t t = 0; t < (size_t)nc * NL; t++) if (c->h_cells[t] < nvo) fdst[t] = fill[c->h_cells[t]]++;
   }
   // diagonal mass scaled to the total measure (HRZ lumping: row sums vanish at P2 vertices); preconditioner only
   for (int v = 0; v < nv; v++) c->h_Ml[v] = mdiag[v] * (msum / dsum);
@@ -798,6 +815,7 @@ int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, cons
   HIPCHK(c, c->A10.alloc(2 * (size_t)c->nnzv));
   HIPCHK(c, c->A11.alloc((size_t)c->nnzv));
   std::vector<unsigned char> cown(nc, 1);
+  for (int e = 0; e < nc; e++) cown[e] = cells[(size_t)NL * e] < nvo ? 1 : 0;  // the rank that owns a cell's first node integrates it in global functionals
   HIPCHK(c, c->cell_owned.upload(cown, s));
   std::vector<double> rnd(2 * (size_t)nv);
   {
@@ -833,6 +851,28 @@ int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, cons
   HIPCHK(c, c->pp0.alloc(nv)); HIPCHK(c, c->pp1.alloc(nv));
   c->mom_valid = true;  // no tau-moment pass: tau is evaluated inside the quadrature loop
   HIPCHK(c, hipStreamSynchronize(s));
+  return 0;
+}
+
+// stiffness K [nloc][nloc] of one cell of the context's element type (nodes v in the caller's numbering, coordinates [..][2]):
+// the global pressure Laplacian of a partitioned run (cfdh_set_global_pressure_space)
+int cfdh_gen_element_stiffness(const cfdh_ctx *c, const int32_t *v, const double *X, double *K) {
+  static GenTab T[3];
+  static bool init = false;
+  if (!init) { fill_tab<0>(T[0]); fill_tab<1>(T[1]); fill_tab<2>(T[2]); init = true; }
+  const int et = c->etype, NL = c->nloc;
+  const double J00 = X[2 * v[1]] - X[2 * v[0]], J01 = X[2 * v[2]] - X[2 * v[0]], J10 = X[2 * v[1] + 1] - X[2 * v[0] + 1], J11 = X[2 * v[2] + 1] - X[2 * v[0] + 1];
+  const double det = J00 * J11 - J01 * J10, adet = std::fabs(det);
+  if (!(adet > 0)) return CFDH_E_ARG;
+  const double Ji[2][2] = {{J11 / det, -J01 / det}, {-J10 / det, J00 / det}};
+  for (int k = 0; k < NL * NL; k++) K[k] = 0.0;
+  for (int q = 0; q < GEN_NQ; q++) {
+    double g[GEN_MAXL][2];
+    for (int a = 0; a < NL; a++)
+      for (int i = 0; i < 2; i++) g[a][i] = T[et].dphi[q][a][0] * Ji[0][i] + T[et].dphi[q][a][1] * Ji[1][i];
+    for (int a = 0; a < NL; a++)
+      for (int b = 0; b < NL; b++) K[a * NL + b] += adet * T[et].w[q] * (g[a][0] * g[b][0] + g[a][1] * g[b][1]);
+  }
   return 0;
 }
 
@@ -878,8 +918,8 @@ int kg_functional_partials(cfdh_ctx *c, int kind, int marker, int nb) {
     else if (c->etype == 2) hipLaunchKernelGGL((KERNEL<2>), grid, block, 0, c->stream, __VA_ARGS__);    \
     else hipLaunchKernelGGL((KERNEL<0>), grid, block, 0, c->stream, __VA_ARGS__);                       \
   } while (0)
-  if (kind == 2 || kind == 3) ET_DISPATCH(gen_l2_kernel, c->nc, c->nvo, c->cells.p, c->coords.p, c->x.p, c->red_partial.p);
-  else ET_DISPATCH(gen_facet_functional_kernel, c->nfac, marker, kind, c->nvo, c->d_fac_cell.p, c->d_fac_local.p, c->d_fac_marker.p, c->cells.p,
+  if (kind == 2 || kind == 3) ET_DISPATCH(gen_l2_kernel, c->nc, c->nvo, c->cells.p, c->cell_owned.p, c->coords.p, c->x.p, c->red_partial.p);
+  else ET_DISPATCH(gen_facet_functional_kernel, c->nfac, marker, kind, c->nvo, c->d_fac_cell.p, c->d_fac_local.p, c->d_fac_marker.p, c->cells.p, c->cell_owned.p,
                    c->coords.p, c->x.p, c->mu, c->red_partial.p);
   HIPCHK(c, hipGetLastError());
   return 0;

@@ -421,8 +421,9 @@ int k3_wss(cfdh_ctx *c, double *out);
 
 // ---- nodal elements beyond P1 (cfdh_gen.hip) ------------------------------------------
 int kg_upload_tables(cfdh_ctx *c);
-int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv, int64_t nc, const int32_t *cells, const double *coords, int64_t nfac,
+int cfdh_build_mesh_gen(cfdh_ctx *c, int etype, int64_t nv, int64_t nv_owned, int64_t nc, const int32_t *cells, const double *coords, int64_t nfac,
                         const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker);
+int cfdh_gen_element_stiffness(const cfdh_ctx *c, const int32_t *v, const double *X, double *K);
 int cfdh_facet_nodes(const cfdh_ctx *c, int f, int out[3]);  // local nodes of local facet f; returns their number
 int kg_assemble(cfdh_ctx *c, const double *xstate, int mode);
 int kg_functional_partials(cfdh_ctx *c, int kind, int marker, int nb);  // per-block partial sums into red_partial

@@ -467,6 +467,11 @@ int cfdh_pc_update(cfdh_ctx *c, bool refresh_amg) {
   return 0;
 }
 
+static bool ras_ghost_rhs() {
+  static const bool on = !(getenv("CFDH_RAS_GHOST_RHS") && getenv("CFDH_RAS_GHOST_RHS")[0] == '0');
+  return on;
+}
+
 // The application is a sequence of stages separated by the exchanges of a partitioned run:
 //   stage 0: y_u = V(A00~) r_u                                   | halo(y_u)
 //   stage 1: t_p = r_p - A10 y_u ; zH = Cheb3(H) t_p ; y = M_l zH | all-reduce of the global pressure rhs
@@ -549,7 +554,12 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
         if (c->opt.schur_full) {
           if (multi) CHK(k_spmv_block_ghost(c, 2, c->pcw.p, c->pu0.p, ru));  // t_u = r_u - A01 z_p (with ghosts)
           else CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));
-          if (multi && c->ras) CHK(v_copy(c, nu, c->pu0.p, c->pcw.p));       // t_u into the halo scratch vector; cycle in stage 4
+          if (multi && c->ras) {
+            CHK(v_copy(c, nu, c->pu0.p, c->pcw.p));       // t_u into the halo scratch vector; cycle in stage 4
+            // experiment (CFDH_RAS_GHOST_RHS=0): no exchange of the overlap residual -- the right-hand side of the overlapping
+            // cycle is zero on the ghost layer
+            if (!ras_ghost_rhs()) CHK(v_zero(c, c->NL - c->NO, c->pcw.p + c->NO));
+          }
           else {
             CHK(k_amg_vcycle(c, c->hA, c->pu0.p, zu));
             static const int acycles = getenv("CFDH_A_CYCLES") ? atoi(getenv("CFDH_A_CYCLES")) : 1;
@@ -607,7 +617,7 @@ static int pc_exchange(cfdh_ctx *c, int stage) {
       return comm_allreduce_dev(c, c->gp_rhs.p, c->gp_n, 0);
     case 10: return comm_allreduce_dev(c, c->hLg.lev[1]->b.p, c->dl0.n1, 0);  // coarse right-hand side of the replicated levels
     case 2: return c->opt.schur_full ? comm_halo(c, c->pcw.p) : 0;
-    case 3: return (c->ras && c->opt.schur_full) ? comm_halo(c, c->pcw.p) : 0;  // residual of the overlap layer
+    case 3: return (c->ras && c->opt.schur_full && ras_ghost_rhs()) ? comm_halo(c, c->pcw.p) : 0;  // residual of the overlap layer
     default: return 0;
   }
 }

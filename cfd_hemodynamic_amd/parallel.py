@@ -243,6 +243,14 @@ class PartComm:
         bad = None
         if not (np.array_equal(gu.reshape(-1, d), f[:, None] * comp[None, :]) and np.array_equal(gp, 3.0 * f)):
             bad = "halo exchange delivered wrong ghost values"
+        if int(getattr(mesh, "etype", 0)) != 0:
+            # P2 / Q1 node meshes: the reduction is checked with the max-norm of u (a global maximum over the ranks)
+            ref = float(np.abs(comp).max() * (1.0 + 1e-6 * (mesh.num_vertices - 1)))
+            got = ctx.functional(4)
+            if bad is None and not abs(got - ref) <= 1e-12 * ref:
+                bad = "all-reduce (max) gave %r, expected %r" % (got, ref)
+            worst = self.allreduce(0.0 if bad is None else 1.0, "max")
+            return bad if bad else ("defect on another rank" if worst > 0 else None)
         # ||u||_L2 over the whole mesh through the library's all-reduce vs the host value:
         # int_K f^2 = |K| (sum_a f_a^2 + sum_{a<b} f_a f_b) * 2 / ((d+1)(d+2))
         fg = 1.0 + 1e-6 * np.arange(mesh.num_vertices)

@@ -48,9 +48,19 @@ class Solver(SolverBase):
         self._comm = kwargs.get("comm", None)
         device = int(kwargs.get("device", 0))
         self._part = None
-        if etype != 0:
-            if self._comm is not None and self._comm.size > 1:
-                raise NotImplementedError("P2 / Q1 elements run on one GPU")
+        if etype != 0 and self._comm is not None and self._comm.size > 1:
+            # P2 / Q1 in a partitioned run (round 4, gdim 2): the NODE mesh is partitioned exactly like a vertex mesh -- owned nodes,
+            # every cell touching one, the remaining nodes of those cells as ghosts (cfdh_create_elem_part)
+            if mesh.geometry.dim != 2:
+                raise NotImplementedError("3-D P2 / Q1 elements run on one GPU")
+            from ..mesh import PartCommView
+            mesh.comm = PartCommView(self._comm)
+            part = self._comm.make_part(dm)
+            self._part = part
+            self.ctx = _lib.Context(part.x, part.cells, part.facet_cells, part.facet_local, part.facet_marker, nv_owned=part.nvo, device=device,
+                                    etype=etype)
+            self._comm.attach(self.ctx)
+        elif etype != 0:
             self.ctx = _lib.Context(dm.x, dm.cells, dm.facet_cells, dm.facet_local, dm.facet_marker, device=device, etype=etype)
         elif self._comm is not None and self._comm.size > 1:
             from ..mesh import PartCommView
@@ -108,7 +118,7 @@ class Solver(SolverBase):
             dst_u[:] = lu
             dst_p[:] = lp
         else:
-            nvg = self.mesh.num_vertices
+            nvg = self._dm.num_vertices  # nodes of the function space (= mesh vertices for P1 / Q1)
             dst_u[:] = self._comm.allgather_owned(lu, self.mesh.geometry.dim, nvg)
             dst_p[:] = self._comm.allgather_owned(lp, 1, nvg)
 
@@ -131,7 +141,7 @@ class Solver(SolverBase):
             self._dev_newer["wss"] = False
             w = self.ctx.wall_shear_stress(download=True)
             a = self.shear_stress.x._array
-            a[:] = w if self._part is None else self._comm.allgather_owned(w, self.mesh.geometry.dim, self.mesh.num_vertices)
+            a[:] = w if self._part is None else self._comm.allgather_owned(w, self.mesh.geometry.dim, self._dm.num_vertices)
 
     def assemble_wss(self):
         """solverBase.py:185-195 on the device (cfdh_wall_shear_stress); the host array behind
@@ -186,10 +196,10 @@ class Solver(SolverBase):
             # RCCL cannot be rehearsed on the one-GPU development box); host-staged exchange as the safety net
             if not getattr(self, "_comm_checked", False):
                 self._comm_checked = True
-                bad = self._comm.selfcheck(self.ctx, self.mesh)
+                bad = self._comm.selfcheck(self.ctx, self._dm)
                 if bad and self._comm.backend == "rccl":
                     self._comm.fall_back_to_host(self.ctx, bad)
-                    bad = self._comm.selfcheck(self.ctx, self.mesh)
+                    bad = self._comm.selfcheck(self.ctx, self._dm)
                 if bad:
                     raise RuntimeError("communicator self-check failed: " + bad)
             # the pressure part of the preconditioner is solved globally (replicated) on every rank
@@ -197,13 +207,13 @@ class Solver(SolverBase):
             if not getattr(self, "_ds_terms", True):
                 # do-nothing boundary: the vertices of the exterior facets that are not no-slip/inflow facets are
                 # the Dirichlet set of the preconditioner's pressure Laplacian (as build_cc_host does per rank)
-                fixed = np.zeros(self.mesh.num_vertices, dtype=bool)
+                fixed = np.zeros(self._dm.num_vertices, dtype=bool)
                 for bc in self.bcu_d:
                     fixed[bc.dofs] = True
-                fv = self.mesh.facet_vertices
+                fv = self._dm.facet_vertices
                 open_f = ~np.all(fixed[fv], axis=1)
                 pnodes = np.unique(np.concatenate([pnodes, fv[open_f].ravel()])).astype(np.int32)
-            self.ctx.set_global_pressure_space(self.mesh.x, self.mesh.cells, self._part.owned_global, pnodes)
+            self.ctx.set_global_pressure_space(self._dm.x, self._dm.cells, self._part.owned_global, pnodes)
         # x_n = (u_prev, p_prev): initial guess of the first step (stabilized_schur.py:216-223)
         self._sync_previous()
         up, pp = self._loc_u(self._u_prev.x._array), self._loc_p(self._p_prev.x._array)

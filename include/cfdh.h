@@ -134,12 +134,22 @@ int cfdh_create(cfdh_ctx **out, int device, int gdim, int64_t nv, int64_t nv_own
  * cells [nc][nloc] list NODE ids in the DOLFINx/Basix local order -- P2 triangle: vertices 0,1,2 then the edge nodes opposite
  * to them (nloc 6); Q1 quadrilateral: (0,0),(1,0),(0,1),(1,1) (nloc 4); node_coords [nn][2].  Local facets: triangle f =
  * opposite vertex f; quadrilateral 0:(0,1) 1:(0,2) 2:(1,3) 3:(2,3).  Every node carries (u_x, u_y, p): all other calls take
- * node ids / per-node arrays where they say vertex.  Single GPU.  CFDH_ELEM_P1_GENERIC runs P1 triangles through the
+ * node ids / per-node arrays where they say vertex.  gdim 3 (round 4): CFDH_ELEM_Q1 = hexahedral cells as unit_cube_pipe.py:103-109
+ * builds them (parallelepipeds; nloc 8, vertex v = i + 2 j + 4 k, local facets 0:(0,1,2,3) 1:(0,1,4,5) 2:(0,2,4,6) 3:(1,3,5,7)
+ * 4:(2,3,6,7) 5:(4,5,6,7)), CFDH_ELEM_P2 = P2/P2 tetrahedra (nloc 10: vertices, then the edge nodes in Basix edge order (2,3) (1,3) (1,2)
+ * (0,3) (0,2) (0,1); facet f opposite vertex f); node_coords [nn][3].  This entry point creates a whole mesh on one GPU (parts of a
+ * partitioned run: cfdh_create_elem_part).  CFDH_ELEM_P1_GENERIC runs P1 triangles / tetrahedra through the
  * quadrature kernels of the P2/Q1 path (a cross-check of the closed-form P1 kernels). */
 enum { CFDH_ELEM_P1 = 0, CFDH_ELEM_P2_TRIANGLE = 1, CFDH_ELEM_Q1_QUADRILATERAL = 2, CFDH_ELEM_P1_GENERIC = 3 };
 int cfdh_create_elem(cfdh_ctx **out, int device, int gdim, int elem, int64_t nn, int64_t nc, const int32_t *cells,
                      const double *node_coords, int64_t nfacets, const int32_t *facet_cells, const int32_t *facet_local,
                      const int32_t *facet_marker);
+/* The same for one part of a partitioned run (gdim 2; SURVEY.md 8e for the 8f-4 elements: the reference runs every solver under
+ * mpirun, /root/reference/src/simulation_hpc.sh:14-19): nodes [0, nn_owned) are owned, the rest are the ghost nodes of the
+ * one-cell overlap, numbered contiguously per neighbour as cfdh_set_halo expects; cells = all cells touching an owned node. */
+int cfdh_create_elem_part(cfdh_ctx **out, int device, int gdim, int elem, int64_t nn, int64_t nn_owned, int64_t nc, const int32_t *cells,
+                          const double *node_coords, int64_t nfacets, const int32_t *facet_cells, const int32_t *facet_local,
+                          const int32_t *facet_marker);
 /* (Re)assign the markers of the exterior facets after cfdh_create: the reference hands `facet_tags` / `tags` to
  * Solver.setup(), not to the constructor (/root/reference/src/scenario.py:137-149;
  * stabilized_schur_backflow.py:158-163 builds ds_out from them there).  markers[nfacets] in the facet order of

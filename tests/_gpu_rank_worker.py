@@ -53,6 +53,13 @@ def main():
         from cfd_hemodynamic_amd.scenarios.stenosis import StenosisSimulation
         sc = StenosisSimulation("stabilized_schur_backflow", 0.01, 0.035, ny=12, L=30.0, x_sten=10.0, v_max=60.0, quiet=True,
                                 beta_backflow=0.2, device=0, comm=comm, options=tight)
+    elif case == "q1_pipe":  # quadrilateral cells (Q1/Q1), pressure-driven channel, pressure Dirichlet at both ends
+        from cfd_hemodynamic_amd.scenarios.unit_square_pipe import UnitSquarePipeSimulation
+        sc = UnitSquarePipeSimulation("stabilized_schur", 0.01, 0.035, p_inlet=7.47, p_outlet=0.0, nx=96, ny=10, L=14.0, quiet=True, device=0, comm=comm,
+                                      options=tight)
+    elif case == "p2_dfg":  # `--solver stabilized_schur_backflow --p_grade 2` (P2/P2), do-nothing outlet + backflow term
+        sc = DFG1Benchmark("stabilized_schur_backflow", 0.01, 0.035, m=int(os.environ.get("CFDH_TEST_M", "10")), quiet=True, v_max=0.3, p_grade=2,
+                           beta_backflow=0.2, device=0, comm=comm, options=tight)
     else:
         sc = DFG1Benchmark(os.environ.get("CFDH_TEST_SOLVER", "stabilized_schur"), 0.01, float(os.environ.get("CFDH_TEST_T", "0.05")),
                            m=int(os.environ.get("CFDH_TEST_M", "16")), quiet=True, device=0, comm=comm, options=tight)

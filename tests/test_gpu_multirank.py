@@ -246,6 +246,36 @@ def test_rccl_path_at_quarter_million_dof_with_4_and_5_ranks(tmp_path, world):
     assert 2.9 <= halo / its <= 3.6 and 2.9 <= ar / its <= 3.6 and sync / its <= 3.2, (halo / its, ar / its, sync / its)
 
 
+@pytest.mark.parametrize("case,world,backend", [("q1_pipe", 2, "host"), ("q1_pipe", 3, "rccl"), ("p2_dfg", 2, "rccl"), ("p2_dfg", 3, "host")])
+def test_generic_elements_partitioned_over_ranks(tmp_path, case, world, backend):
+    """Round 4: P2/P2 triangles and Q1/Q1 quadrilaterals in a partitioned run -- the NODE mesh is partitioned like a
+    vertex mesh (owned nodes, every cell touching one, ghost nodes; cfdh_create_elem_part), halo exchange and reductions as for P1,
+    the replicated global pressure space assembled from the element's own stiffness.  Solution equal to one rank's to 1e-9 / 1e-8,
+    both transports (host-staged, RCCL code path through the shared-memory stand-in)."""
+    tight = dict(snes_rtol=1e-12, snes_stol=0.0, ksp_rtol=1e-10)
+    if case == "q1_pipe":
+        from cfd_hemodynamic_amd.scenarios.unit_square_pipe import UnitSquarePipeSimulation
+        ref = UnitSquarePipeSimulation("stabilized_schur", 0.01, 0.035, p_inlet=7.47, p_outlet=0.0, nx=96, ny=10, L=14.0, quiet=True, options=tight)
+    else:
+        from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
+        ref = DFG1Benchmark("stabilized_schur_backflow", 0.01, 0.035, m=10, quiet=True, v_max=0.3, p_grade=2, beta_backflow=0.2, options=tight)
+    ref.solve(None)
+    ref_krylov = sum(st.krylov_its for _, st in ref.step_stats)
+    u0, p0 = np.asarray(ref.solver.u_sol.x.array).copy(), np.asarray(ref.solver.p_sol.x.array).copy()
+    env = dict(CFDH_TEST_CASE=case, CFDH_TEST_BACKEND=backend)
+    if backend == "rccl":
+        fake = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
+        if not os.path.exists(fake):
+            subprocess.check_call(["make", "-C", os.path.join(HERE, "fake_rccl"), "-s"])
+        env["CFDH_RCCL_LIB"] = fake
+    r = _run(world, str(tmp_path / ("%s_%d.npz" % (case, world))), timeout=600, **env)
+    assert str(r["backend"]) == backend and int(r["steps"]) == ref.num_steps
+    assert np.linalg.norm(r["u"] - u0) <= 1e-9 * np.linalg.norm(u0)
+    assert np.linalg.norm(r["p"] - p0) <= 1e-8 * np.linalg.norm(p0)
+    assert abs(float(r["norm_v"]) - ref.norm_v) <= 1e-9 * ref.norm_v
+    assert int(r["krylov"]) <= 1.6 * ref_krylov, (int(r["krylov"]), ref_krylov)
+
+
 def test_communication_per_iteration_at_the_reference_tolerances(tmp_path):
     """The same 4-rank run at PETSc-default tolerances (what the timed loops run): iterations are launched ahead of the host's
     bookkeeping and nothing takes the second Gram-Schmidt pass, so one FGMRES iteration costs 3 halo exchanges, 2 all-reduces
