@@ -43,7 +43,6 @@ static int create_ctx(cfdh_ctx **out, int device, int gdim, int etype, int64_t n
   *out = nullptr;
   if (gdim != 2 && gdim != 3) return cfdh_fail(nullptr, CFDH_E_ARG, "gdim must be 2 (P1 triangles) or 3 (P1 tetrahedra)");
   if (etype < 0 || etype > 3) return cfdh_fail(nullptr, CFDH_E_ARG, "unknown element type %d", etype);
-  if (etype != 0 && gdim == 3 && nv_owned != nv) return cfdh_fail(nullptr, CFDH_E_ARG, "3-D P2 / Q1 contexts are single-GPU: nv_owned must equal nv");
   if (!cells || !coords || (nfacets > 0 && (!facet_cells || !facet_local)))
     return cfdh_fail(nullptr, CFDH_E_ARG, "null mesh array");
   int ndev = 0;
@@ -77,7 +76,7 @@ static int create_ctx(cfdh_ctx **out, int device, int gdim, int etype, int64_t n
     if (etype != 0) {
       rc = gdim == 3 ? kg3_upload_tables(c) : kg_upload_tables(c);
       if (rc) break;
-      rc = gdim == 3 ? cfdh_build_mesh_gen3(c, etype, nv, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker)
+      rc = gdim == 3 ? cfdh_build_mesh_gen3(c, etype, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker)
                      : cfdh_build_mesh_gen(c, etype, nv, nv_owned, nc, cells, coords, nfacets, facet_cells, facet_local, facet_marker);
       break;
     }
@@ -500,11 +499,10 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
   // global P1 stiffness as (row, col, value) triplets -> CSR with Dirichlet rows/cols removed
   std::vector<std::vector<std::pair<int, double>>> rows(n);
   if (c->gen) {  // P2 / Q1: the element's own stiffness by quadrature (csrc/cfdh_gen.hip), as h_Lval holds it for the local part
-    if (D != 2) return cfdh_fail(c, CFDH_E_ARG, "partitioned P2 / Q1 runs exist for gdim 2");
     std::vector<double> K((size_t)NCc * NCc);
     for (int64_t e = 0; e < ncg; e++) {
       const int32_t *v = cells + (size_t)NCc * e;
-      CHK(cfdh_gen_element_stiffness(c, v, coords, K.data()));
+      CHK(D == 3 ? cfdh_gen3_element_stiffness(c, v, coords, K.data()) : cfdh_gen_element_stiffness(c, v, coords, K.data()));
       for (int a = 0; a < NCc; a++) {
         if (pbc[v[a]]) continue;
         for (int b = 0; b < NCc; b++) if (!pbc[v[b]]) rows[v[a]].push_back({v[b], K[(size_t)a * NCc + b]});

@@ -186,7 +186,6 @@ int comm_halo(cfdh_ctx *c, double *vec) {
 extern "C" int cfdh_set_halo(cfdh_ctx *c, int nnbr, const int32_t *nbr_rank, const int64_t *send_ptr, const int32_t *send_idx,
                              const int64_t *recv_ptr, const int32_t *recv_idx) {
   if (!c || nnbr < 0) return cfdh_fail(c, CFDH_E_ARG, "bad halo arguments");
-  if (c->gen && c->dim == 3 && nnbr > 0) return cfdh_fail(c, CFDH_E_ARG, "3-D P2 / Q1 contexts are single-GPU");
   c->nnbr = nnbr;
   c->nbr_rank.assign(nbr_rank, nbr_rank + nnbr);
   c->send_ptr.assign(send_ptr, send_ptr + nnbr + 1);

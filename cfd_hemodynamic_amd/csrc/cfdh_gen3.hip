@@ -182,6 +182,10 @@ __device__ inline void facet_point(int f, int q, double pt[3], double &w) {
   }
 }
 
+// offsets of a node's velocity / pressure in the state layout [u owned 3 nvo | p owned nvo | (u_x, u_y, u_z, p) per ghost]
+__device__ __forceinline__ size_t g3uo(int v, int nvo) { return v < nvo ? 3 * (size_t)v : 4 * (size_t)nvo + 4 * (size_t)(v - nvo); }
+__device__ __forceinline__ size_t g3po(int v, int nvo) { return v < nvo ? 3 * (size_t)nvo + v : 4 * (size_t)nvo + 4 * (size_t)(v - nvo) + 3; }
+
 struct Gen3Args {
   int nc, nvo, mode;  // mode 1: F + J, 2: F only (lifting included)
   const int *cells;
@@ -225,13 +229,13 @@ __global__ __launch_bounds__(g3_wgs(ET)) void gen3_asm_kernel(Gen3Args P) {
     D.bc[t] = bf;
     for (int i = 0; i < 3; i++) {
       D.X[t][i] = P.coords[3 * (size_t)v + i];
-      const double u = P.x[3 * (size_t)v + i], un = P.xprev[3 * (size_t)v + i];
+      const double u = P.x[g3uo(v, nvo) + i], un = P.xprev[g3uo(v, nvo) + i];
       D.un[t][i] = un;
       D.ub[t][i] = P.theta * u + (1.0 - P.theta) * un;
-      D.wn[t][i] = (P.a0 * u + P.a1 * un + (P.a2 != 0.0 ? P.a2 * P.xprev2[3 * (size_t)v + i] : 0.0)) / P.dt;
+      D.wn[t][i] = (P.a0 * u + P.a1 * un + (P.a2 != 0.0 ? P.a2 * P.xprev2[g3uo(v, nvo) + i] : 0.0)) / P.dt;
       D.lift[t][i] = (bf >> i) & 1 ? P.bcval[4 * (size_t)v + i] - u : 0.0;
     }
-    const double pv = P.x[3 * (size_t)nvo + v];
+    const double pv = P.x[g3po(v, nvo)];
     D.p[t] = pv;
     D.lift[t][3] = (bf >> 3) & 1 ? P.bcval[4 * (size_t)v + 3] - pv : 0.0;
   }
@@ -410,7 +414,9 @@ __global__ __launch_bounds__(g3_wgs(ET)) void gen3_asm_kernel(Gen3Args P) {
   double Fl[4];
   for (int i = 0; i < 3; i++) Fl[i] = (b == 0 ? Fa[i] : 0.0) + Juu[i][0] * l0 + Juu[i][1] * l1 + Juu[i][2] * l2 + Jup[i] * l3;
   Fl[3] = (b == 0 ? Fa[3] : 0.0) + Jpu[0] * l0 + Jpu[1] * l1 + Jpu[2] * l2 + Jpp * l3;
-  double *ef = P.EF + 4 * (size_t)P.fdst[(size_t)cell * NL * NL + t];
+  const int fd = P.fdst[(size_t)cell * NL * NL + t];
+  if (fd < 0) return;  // row of a ghost node: assembled by its owner (one-cell overlap of the partition)
+  double *ef = P.EF + 4 * (size_t)fd;
   for (int i = 0; i < 4; i++) ef[i] = ((bca >> i) & 1u) ? 0.0 : Fl[i];
   if (P.mode != 1) return;
   double *eb = P.E + 16 * (size_t)P.slot[(size_t)cell * NL * NL + t];
@@ -483,18 +489,19 @@ __device__ __forceinline__ double block_sum3(double v, double *sh) {
 
 // int u.u and int p^2 with the element's own mass matrix (scenario.py:315-324)
 template <int ET>
-__global__ __launch_bounds__(TPB) void gen3_l2_kernel(int nc, int nvo, const int *__restrict__ cells, const double *__restrict__ coords,
-                                                      const double *__restrict__ x, double *__restrict__ partial) {
+__global__ __launch_bounds__(TPB) void gen3_l2_kernel(int nc, int nvo, const int *__restrict__ cells, const unsigned char *__restrict__ cell_owned,
+                                                      const double *__restrict__ coords, const double *__restrict__ x, double *__restrict__ partial) {
   constexpr int NL = g3_nloc(ET), NV = ET == 2 ? 8 : 4;
   __shared__ double sh[4];
   double au = 0, ap = 0;
   for (int e = blockIdx.x * TPB + threadIdx.x; e < nc; e += gridDim.x * TPB) {
+    if (!cell_owned[e]) continue;  // every cell is integrated by exactly one rank
     double X[NV][3], u[NL][3], p[NL];
     for (int a = 0; a < NL; a++) {
       const int v = cells[(size_t)e * NL + a];
       if (a < NV) for (int i = 0; i < 3; i++) X[a][i] = coords[3 * (size_t)v + i];
-      for (int i = 0; i < 3; i++) u[a][i] = x[3 * (size_t)v + i];
-      p[a] = x[3 * (size_t)nvo + v];
+      for (int i = 0; i < 3; i++) u[a][i] = x[g3uo(v, nvo) + i];
+      p[a] = x[g3po(v, nvo)];
     }
     double Ji[3][3], adet, h;
     geom3<ET>(X, Ji, adet, h);
@@ -517,19 +524,19 @@ __global__ __launch_bounds__(TPB) void gen3_l2_kernel(int nc, int nvo, const int
 // kind 7: flux int u.n over the facets with the given marker (outward normal)
 template <int ET>
 __global__ __launch_bounds__(TPB) void gen3_flux_kernel(int nfac, int marker, int nvo, const int *__restrict__ fcell, const int *__restrict__ flocal,
-                                                        const int *__restrict__ fmarker, const int *__restrict__ cells, const double *__restrict__ coords,
-                                                        const double *__restrict__ x, double *__restrict__ partial) {
+                                                        const int *__restrict__ fmarker, const int *__restrict__ cells, const unsigned char *__restrict__ cell_owned,
+                                                        const double *__restrict__ coords, const double *__restrict__ x, double *__restrict__ partial) {
   constexpr int NL = g3_nloc(ET), NV = ET == 2 ? 8 : 4;
   __shared__ double sh[4];
   double a0 = 0;
   for (int k = blockIdx.x * TPB + threadIdx.x; k < nfac; k += gridDim.x * TPB) {
-    if (fmarker[k] != marker) continue;
+    if (fmarker[k] != marker || !cell_owned[fcell[k]]) continue;
     const int e = fcell[k], f = flocal[k];
     double X[NV][3], u[NL][3];
     for (int a = 0; a < NL; a++) {
       const int v = cells[(size_t)e * NL + a];
       if (a < NV) for (int i = 0; i < 3; i++) X[a][i] = coords[3 * (size_t)v + i];
-      for (int i = 0; i < 3; i++) u[a][i] = x[3 * (size_t)v + i];
+      for (int i = 0; i < 3; i++) u[a][i] = x[g3uo(v, nvo) + i];
     }
     double n[3], area;
     facet_geom3<ET>(X, f, n, area);
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(TPB) void gen3_wss_kernel(int nfac, int nvo, const 
   for (int a = 0; a < NL; a++) {
     vs[a] = cells[(size_t)e * NL + a];
     if (a < NV) for (int i = 0; i < 3; i++) X[a][i] = coords[3 * (size_t)vs[a] + i];
-    for (int i = 0; i < 3; i++) u[a][i] = x[3 * (size_t)vs[a] + i];
+    for (int i = 0; i < 3; i++) u[a][i] = x[g3uo(vs[a], nvo) + i];
   }
   double Ji[3][3], adet, h, n[3], area;
   geom3<ET>(X, Ji, adet, h);
@@ -639,9 +646,10 @@ int cfdh_facet_nodes3(const cfdh_ctx *c, int f, int out[8]) {
 // Mesh upload for the 3-D generic element path (the 3-D counterpart of cfdh_build_mesh_gen): Morton numbering of the nodes,
 // node graph, staging order of the element blocks, stiffness / diagonal mass of the element on the graph (preconditioner),
 // the P1 subspace of a P2 space (p-multigrid step), state and work vectors.
-int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, const int32_t *cells, const double *coords, int64_t nfac64,
+int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv64, int64_t nvo64, int64_t nc64, const int32_t *cells, const double *coords, int64_t nfac64,
                          const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker) {
-  const int nv = (int)nv64, nc = (int)nc64, nfac = (int)nfac64;
+  const int nv = (int)nv64, nvo = (int)nvo64, nc = (int)nc64, nfac = (int)nfac64;
+  if (nvo <= 0 || nvo > nv) return cfdh_fail(c, CFDH_E_ARG, "bad owned node count");
   const int et = etype == 3 ? 0 : etype;
   const int NL = g3_nloc(et), NF = et == 2 ? 6 : 4, NV = et == 2 ? 8 : 4;
   if (nv <= 0 || nc <= 0) return cfdh_fail(c, CFDH_E_ARG, "bad mesh sizes");
@@ -652,25 +660,27 @@ int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, con
     if (fcell[k] < 0 || fcell[k] >= nc || flocal[k] < 0 || flocal[k] >= NF) return cfdh_fail(c, CFDH_E_ARG, "facet (cell, local) out of range");
   c->dim = 3;
   c->etype = et; c->nloc = NL; c->gen = true;
-  c->nv = c->nvo = nv; c->ng = 0;
-  c->NO = c->NL = 4 * nv;
+  // partitioned runs: nodes [0, nvo) owned, ghosts after (halo-plan order); rows for owned nodes only; ghost tail of 4 doubles per node
+  c->nv = nv; c->nvo = nvo; c->ng = nv - nvo;
+  c->NO = 4 * nvo; c->NL = 4 * nvo + 4 * c->ng;
   c->perm.resize(nv); c->iperm.resize(nv);
   {
-    std::vector<int> order(nv);
+    std::vector<int> order(nvo);
     std::iota(order.begin(), order.end(), 0);
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int v = 0; v < nv; v++)
       for (int i = 0; i < 3; i++) { lo[i] = std::min(lo[i], coords[3 * v + i]); hi[i] = std::max(hi[i], coords[3 * v + i]); }
     const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
     if (!(ext > 0)) return cfdh_fail(c, CFDH_E_ARG, "degenerate coordinates");
-    std::vector<uint32_t> key(nv);
-    for (int v = 0; v < nv; v++) {
+    std::vector<uint32_t> key(nvo);
+    for (int v = 0; v < nvo; v++) {
       uint32_t qd[3];
       for (int i = 0; i < 3; i++) qd[i] = (uint32_t)std::min(1023.0, (coords[3 * v + i] - lo[i]) / ext * 1023.0);
       key[v] = part1by2(qd[0]) | (part1by2(qd[1]) << 1) | (part1by2(qd[2]) << 2);
     }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
-    for (int k = 0; k < nv; k++) { c->iperm[k] = order[k]; c->perm[order[k]] = k; }
+    for (int k = 0; k < nvo; k++) { c->iperm[k] = order[k]; c->perm[order[k]] = k; }
+    for (int v = nvo; v < nv; v++) { c->iperm[v] = v; c->perm[v] = v; }
   }
   c->h_coords.resize(3 * (size_t)nv);
   for (int k = 0; k < nv; k++) for (int i = 0; i < 3; i++) c->h_coords[3 * (size_t)k + i] = coords[3 * (size_t)c->iperm[k] + i];
@@ -718,12 +728,12 @@ int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, con
     for (int e = 0; e < nc; e++)
       for (int a = 0; a < NL; a++) { const int v = c->h_cells[(size_t)NL * e + a]; ncell[ncptr[v] + fill[v]++] = e; }
   }
-  c->h_vptr.assign(nv + 1, 0);
-  c->h_vcol.clear(); c->h_vcol.reserve((size_t)30 * nv);
-  c->h_vdiag.resize(nv);
+  c->h_vptr.assign(nvo + 1, 0);
+  c->h_vcol.clear(); c->h_vcol.reserve((size_t)30 * nvo);
+  c->h_vdiag.resize(nvo);
   {
     std::vector<int> tmp;
-    for (int v = 0; v < nv; v++) {
+    for (int v = 0; v < nvo; v++) {
       if (ncptr[v + 1] == ncptr[v]) return cfdh_fail(c, CFDH_E_ARG, "node %d belongs to no cell", c->iperm[v]);
       tmp.clear();
       for (int k = ncptr[v]; k < ncptr[v + 1]; k++)
@@ -780,10 +790,14 @@ int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, con
       for (int l = 0; l < 3; l++) M[k][l] = Ji[k][0] * Ji[l][0] + Ji[k][1] * Ji[l][1] + Ji[k][2] * Ji[l][2];
     msum += adet * (et == 2 ? 1.0 : 1.0 / 6.0);
     for (int a = 0; a < NL; a++) {
-      const int *nb = &c->h_vcol[c->h_vptr[v[a]]];
-      const int deg = c->h_vptr[v[a] + 1] - c->h_vptr[v[a]];
       mdiag[v[a]] += adet * Mref[a];
       dsum += adet * Mref[a];
+      if (v[a] >= nvo) {  // row of a ghost node: assembled by its owner
+        for (int b = 0; b < NL; b++) slot[((size_t)e * NL + a) * NL + b] = -1;
+        continue;
+      }
+      const int *nb = &c->h_vcol[c->h_vptr[v[a]]];
+      const int deg = c->h_vptr[v[a] + 1] - c->h_vptr[v[a]];
       for (int b = 0; b < NL; b++) {
         const int k = c->h_vptr[v[a]] + (int)(std::lower_bound(nb, nb + deg, v[b]) - nb);
         slot[((size_t)e * NL + a) * NL + b] = k;
@@ -819,21 +833,22 @@ int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, con
     }
   }
   // staging order of the assembly: contributions to one block entry / one node adjacent, in (cell, lane) order
-  std::vector<int> eptr((size_t)c->nnzv + 1, 0), fptr((size_t)nv + 1, 0), fdst((size_t)nc * NL * NL);
-  for (size_t t = 0; t < slot.size(); t++) eptr[slot[t] + 1]++;
+  std::vector<int> eptr((size_t)c->nnzv + 1, 0), fptr((size_t)nvo + 1, 0), fdst((size_t)nc * NL * NL, -1);
+  for (size_t t = 0; t < slot.size(); t++) if (slot[t] >= 0) eptr[slot[t] + 1]++;
   for (int k = 0; k < c->nnzv; k++) eptr[k + 1] += eptr[k];
   {
     std::vector<int> fill(eptr.begin(), eptr.end() - 1);
-    for (size_t t = 0; t < slot.size(); t++) slot[t] = fill[slot[t]]++;
+    for (size_t t = 0; t < slot.size(); t++) if (slot[t] >= 0) slot[t] = fill[slot[t]]++;
   }
   for (int e = 0; e < nc; e++)
-    for (int a = 0; a < NL; a++) fptr[c->h_cells[(size_t)NL * e + a] + 1] += NL;
-  for (int v = 0; v < nv; v++) fptr[v + 1] += fptr[v];
+    for (int a = 0; a < NL; a++) if (c->h_cells[(size_t)NL * e + a] < nvo) fptr[c->h_cells[(size_t)NL * e + a] + 1] += NL;
+  for (int v = 0; v < nvo; v++) fptr[v + 1] += fptr[v];
   {
     std::vector<int> fill(fptr.begin(), fptr.end() - 1);
     for (int e = 0; e < nc; e++)
       for (int a = 0; a < NL; a++)
-        for (int b = 0; b < NL; b++) fdst[((size_t)e * NL + a) * NL + b] = fill[c->h_cells[(size_t)NL * e + a]]++;
+        if (c->h_cells[(size_t)NL * e + a] < nvo)
+          for (int b = 0; b < NL; b++) fdst[((size_t)e * NL + a) * NL + b] = fill[c->h_cells[(size_t)NL * e + a]]++;
   }
   for (int v = 0; v < nv; v++) c->h_Ml[v] = mdiag[v] * (msum / dsum);
   // ---- uploads and allocations
@@ -854,6 +869,7 @@ int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, con
   HIPCHK(c, c->A10.alloc(3 * (size_t)c->nnzv));
   HIPCHK(c, c->A11.alloc((size_t)c->nnzv));
   std::vector<unsigned char> cown(nc, 1);
+  for (int e = 0; e < nc; e++) cown[e] = cells[(size_t)NL * e] < nvo ? 1 : 0;
   HIPCHK(c, c->cell_owned.upload(cown, s));
   std::vector<double> rnd(3 * (size_t)nv);
   {
@@ -889,6 +905,31 @@ int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv64, int64_t nc64, con
   HIPCHK(c, c->pp0.alloc(nv)); HIPCHK(c, c->pp1.alloc(nv));
   c->mom_valid = true;  // no tau-moment pass: tau is evaluated inside the quadrature loop
   HIPCHK(c, hipStreamSynchronize(s));
+  return 0;
+}
+
+// stiffness K [nloc][nloc] of one 3-D cell of the context's element type (global pressure Laplacian of a partitioned run)
+int cfdh_gen3_element_stiffness(const cfdh_ctx *c, const int32_t *v, const double *X, double *K) {
+  const int et = c->etype, NL = c->nloc, NV = et == 2 ? 8 : 4;
+  double Xe[8][3], Ji[3][3], adet, h;
+  for (int a = 0; a < NV; a++) for (int i = 0; i < 3; i++) Xe[a][i] = X[3 * (size_t)v[a] + i];
+  if (et == 2) geom3<2>(Xe, Ji, adet, h); else geom3<0>(Xe, Ji, adet, h);
+  if (!(adet > 0)) return CFDH_E_ARG;
+  for (int k = 0; k < NL * NL; k++) K[k] = 0.0;
+  for (int q = 0; q < G3_NQ; q++) {
+    double pt[3], w, g[10][3];
+    if (et == 2) {
+      const int i = q / 49, j = (q / 7) % 7, k = q % 7;
+      pt[0] = CFDH_GL7_X[i]; pt[1] = CFDH_GL7_X[j]; pt[2] = CFDH_GL7_X[k]; w = CFDH_GL7_W[i] * CFDH_GL7_W[j] * CFDH_GL7_W[k];
+    } else { pt[0] = CFDH3_QL[q][1]; pt[1] = CFDH3_QL[q][2]; pt[2] = CFDH3_QL[q][3]; w = CFDH3_QW[q] / 6.0; }
+    for (int a = 0; a < NL; a++) {
+      double ph, dr[3];
+      if (et == 2) basis3<2>(a, pt, ph, dr); else if (et == 1) basis3<1>(a, pt, ph, dr); else basis3<0>(a, pt, ph, dr);
+      for (int i = 0; i < 3; i++) g[a][i] = dr[0] * Ji[0][i] + dr[1] * Ji[1][i] + dr[2] * Ji[2][i];
+    }
+    for (int a = 0; a < NL; a++)
+      for (int b = 0; b < NL; b++) K[a * NL + b] += adet * w * (g[a][0] * g[b][0] + g[a][1] * g[b][1] + g[a][2] * g[b][2]);
+  }
   return 0;
 }
 
@@ -934,9 +975,9 @@ int kg3_functional_partials(cfdh_ctx *c, int kind, int marker, int nb) {
     else if (c->etype == 2) hipLaunchKernelGGL((KERNEL<2>), grid, block, 0, c->stream, __VA_ARGS__);    \
     else hipLaunchKernelGGL((KERNEL<0>), grid, block, 0, c->stream, __VA_ARGS__);                       \
   } while (0)
-  if (kind == 2 || kind == 3) ET3_DISPATCH(gen3_l2_kernel, c->nc, c->nvo, c->cells.p, c->coords.p, c->x.p, c->red_partial.p);
+  if (kind == 2 || kind == 3) ET3_DISPATCH(gen3_l2_kernel, c->nc, c->nvo, c->cells.p, c->cell_owned.p, c->coords.p, c->x.p, c->red_partial.p);
   else if (kind == 7) ET3_DISPATCH(gen3_flux_kernel, c->nfac, marker, c->nvo, c->d_fac_cell.p, c->d_fac_local.p, c->d_fac_marker.p, c->cells.p,
-                                   c->coords.p, c->x.p, c->red_partial.p);
+                                   c->cell_owned.p, c->coords.p, c->x.p, c->red_partial.p);
   else return cfdh_fail(c, CFDH_E_ARG, "functional kind %d is not available for 3-D P2 / Q1 contexts", kind);
   HIPCHK(c, hipGetLastError());
   return 0;

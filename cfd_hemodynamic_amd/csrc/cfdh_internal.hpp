@@ -431,8 +431,9 @@ int kg_wss(cfdh_ctx *c, double *out);
 
 // ---- nodal elements beyond P1 in 3-D: Q1 hexahedra, P2 tetrahedra (cfdh_gen3.hip) -----------------
 int kg3_upload_tables(cfdh_ctx *c);
-int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv, int64_t nc, const int32_t *cells, const double *coords, int64_t nfac,
+int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv, int64_t nv_owned, int64_t nc, const int32_t *cells, const double *coords, int64_t nfac,
                          const int32_t *fcell, const int32_t *flocal, const int32_t *fmarker);
+int cfdh_gen3_element_stiffness(const cfdh_ctx *c, const int32_t *v, const double *X, double *K);
 int cfdh_facet_nodes3(const cfdh_ctx *c, int f, int out[8]);  // local nodes of local facet f of a 3-D cell; returns their number
 int kg3_assemble(cfdh_ctx *c, const double *xstate, int mode);
 int kg3_functional_partials(cfdh_ctx *c, int kind, int marker, int nb);

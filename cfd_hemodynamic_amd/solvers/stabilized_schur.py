@@ -49,10 +49,8 @@ class Solver(SolverBase):
         device = int(kwargs.get("device", 0))
         self._part = None
         if etype != 0 and self._comm is not None and self._comm.size > 1:
-            # P2 / Q1 in a partitioned run (round 4, gdim 2): the NODE mesh is partitioned exactly like a vertex mesh -- owned nodes,
+            # P2 / Q1 in a partitioned run (round 4, gdim 2 and 3): the NODE mesh is partitioned exactly like a vertex mesh -- owned nodes,
             # every cell touching one, the remaining nodes of those cells as ghosts (cfdh_create_elem_part)
-            if mesh.geometry.dim != 2:
-                raise NotImplementedError("3-D P2 / Q1 elements run on one GPU")
             from ..mesh import PartCommView
             mesh.comm = PartCommView(self._comm)
             part = self._comm.make_part(dm)

@@ -144,7 +144,7 @@ enum { CFDH_ELEM_P1 = 0, CFDH_ELEM_P2_TRIANGLE = 1, CFDH_ELEM_Q1_QUADRILATERAL =
 int cfdh_create_elem(cfdh_ctx **out, int device, int gdim, int elem, int64_t nn, int64_t nc, const int32_t *cells,
                      const double *node_coords, int64_t nfacets, const int32_t *facet_cells, const int32_t *facet_local,
                      const int32_t *facet_marker);
-/* The same for one part of a partitioned run (gdim 2; SURVEY.md 8e for the 8f-4 elements: the reference runs every solver under
+/* The same for one part of a partitioned run (SURVEY.md 8e for the 8f-4 elements: the reference runs every solver under
  * mpirun, /root/reference/src/simulation_hpc.sh:14-19): nodes [0, nn_owned) are owned, the rest are the ghost nodes of the
  * one-cell overlap, numbered contiguously per neighbour as cfdh_set_halo expects; cells = all cells touching an owned node. */
 int cfdh_create_elem_part(cfdh_ctx **out, int device, int gdim, int elem, int64_t nn, int64_t nn_owned, int64_t nc, const int32_t *cells,

@@ -60,6 +60,10 @@ def main():
     elif case == "p2_dfg":  # `--solver stabilized_schur_backflow --p_grade 2` (P2/P2), do-nothing outlet + backflow term
         sc = DFG1Benchmark("stabilized_schur_backflow", 0.01, 0.035, m=int(os.environ.get("CFDH_TEST_M", "10")), quiet=True, v_max=0.3, p_grade=2,
                            beta_backflow=0.2, device=0, comm=comm, options=tight)
+    elif case in ("q1_hex", "p2_tet"):  # SURVEY 8f-4 in 3-D: hexahedral cells (Q1/Q1) / P2/P2 tetrahedra on the reference's duct
+        from cfd_hemodynamic_amd.scenarios.unit_cube_pipe import UnitCubePipeSimulation
+        kw = dict(nx=24, ny=4, nz=4, L=9.0) if case == "q1_hex" else dict(nx=10, ny=2, nz=2, L=7.5, cell_type="tetrahedron", p_grade=2)
+        sc = UnitCubePipeSimulation("stabilized_schur", 0.01, 0.035, p_inlet=4.0, p_outlet=0.0, quiet=True, device=0, comm=comm, options=tight, **kw)
     else:
         sc = DFG1Benchmark(os.environ.get("CFDH_TEST_SOLVER", "stabilized_schur"), 0.01, float(os.environ.get("CFDH_TEST_T", "0.05")),
                            m=int(os.environ.get("CFDH_TEST_M", "16")), quiet=True, device=0, comm=comm, options=tight)

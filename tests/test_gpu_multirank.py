@@ -246,9 +246,10 @@ def test_rccl_path_at_quarter_million_dof_with_4_and_5_ranks(tmp_path, world):
     assert 2.9 <= halo / its <= 3.6 and 2.9 <= ar / its <= 3.6 and sync / its <= 3.2, (halo / its, ar / its, sync / its)
 
 
-@pytest.mark.parametrize("case,world,backend", [("q1_pipe", 2, "host"), ("q1_pipe", 3, "rccl"), ("p2_dfg", 2, "rccl"), ("p2_dfg", 3, "host")])
+@pytest.mark.parametrize("case,world,backend", [("q1_pipe", 2, "host"), ("q1_pipe", 3, "rccl"), ("p2_dfg", 2, "rccl"), ("p2_dfg", 3, "host"),
+                                                ("q1_hex", 3, "rccl"), ("q1_hex", 2, "host"), ("p2_tet", 2, "rccl"), ("p2_tet", 3, "host")])
 def test_generic_elements_partitioned_over_ranks(tmp_path, case, world, backend):
-    """Round 4: P2/P2 triangles and Q1/Q1 quadrilaterals in a partitioned run -- the NODE mesh is partitioned like a
+    """Round 4: P2/P2 triangles / tetrahedra and Q1/Q1 quadrilaterals / hexahedra in a partitioned run -- the NODE mesh is partitioned like a
     vertex mesh (owned nodes, every cell touching one, ghost nodes; cfdh_create_elem_part), halo exchange and reductions as for P1,
     the replicated global pressure space assembled from the element's own stiffness.  Solution equal to one rank's to 1e-9 / 1e-8,
     both transports (host-staged, RCCL code path through the shared-memory stand-in)."""
@@ -256,6 +257,10 @@ def test_generic_elements_partitioned_over_ranks(tmp_path, case, world, backend)
     if case == "q1_pipe":
         from cfd_hemodynamic_amd.scenarios.unit_square_pipe import UnitSquarePipeSimulation
         ref = UnitSquarePipeSimulation("stabilized_schur", 0.01, 0.035, p_inlet=7.47, p_outlet=0.0, nx=96, ny=10, L=14.0, quiet=True, options=tight)
+    elif case in ("q1_hex", "p2_tet"):
+        from cfd_hemodynamic_amd.scenarios.unit_cube_pipe import UnitCubePipeSimulation
+        kw = dict(nx=24, ny=4, nz=4, L=9.0) if case == "q1_hex" else dict(nx=10, ny=2, nz=2, L=7.5, cell_type="tetrahedron", p_grade=2)
+        ref = UnitCubePipeSimulation("stabilized_schur", 0.01, 0.035, p_inlet=4.0, p_outlet=0.0, quiet=True, options=tight, **kw)
     else:
         from cfd_hemodynamic_amd.scenarios.dfg_1 import DFG1Benchmark
         ref = DFG1Benchmark("stabilized_schur_backflow", 0.01, 0.035, m=10, quiet=True, v_max=0.3, p_grade=2, beta_backflow=0.2, options=tight)
