@@ -1290,6 +1290,154 @@ bool cfdh_amg_dev_enabled(const cfdh_ctx *c) {
 
 int cfdh_proxy_dev(cfdh_ctx *c, CsrDev &out) { return vg_build(c, ProxyF{c->A00.p, c->dim, c->nvo}, out); }
 
+// ---- the proxy on owned + ghost vertices (restricted additive Schwarz with one layer of overlap).  Ghost
+// rows live on their owners: entry k of every owned vertex-graph row travels in slot (k mod W) of the vertex record of halo
+// exchange (k div W), W = dim + 1.  Once per halo plan the records carry the GLOBAL column ids, from which the host derives the
+// pattern of the ghost rows in local numbering (columns ascending); at every rebuild they carry the values, and two kernels
+// write the CSR matrix -- nothing is downloaded, no host loop over rows.
+namespace {
+__global__ __launch_bounds__(TPB) void ras_pack_kernel(int nvo, int dim, int k0, const int *__restrict__ vptr, const int *__restrict__ vcol,
+                                                       const double *__restrict__ A00, const int *__restrict__ gid, double *__restrict__ rec) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= nvo) return;
+  for (int t = 0; t <= dim; t++) {
+    const int k = vptr[i] + k0 + t;
+    double v = gid ? -1.0 : 0.0;
+    if (k < vptr[i + 1]) {
+      if (gid) v = (double)gid[vcol[k]];
+      else {
+        v = 0.0;
+        for (int q = 0; q < dim; q++) v += A00[(size_t)dim * dim * k + (size_t)q * (dim + 1)];
+        v /= dim;
+      }
+    }
+    rec[t < dim ? (size_t)dim * i + t : (size_t)dim * nvo + i] = v;
+  }
+}
+__global__ __launch_bounds__(TPB) void ras_unpack_kernel(int ng, int nvo, int dim, int k0, int maxlen, const double *__restrict__ rec,
+                                                         double *__restrict__ gval) {
+  const int g = blockIdx.x * TPB + threadIdx.x;
+  if (g >= ng) return;
+  const size_t W = (size_t)dim + 1;
+  for (int t = 0; t <= dim; t++)
+    if (k0 + t < maxlen) gval[(size_t)g * maxlen + k0 + t] = rec[W * (size_t)nvo + W * (size_t)g + t];
+}
+// rows [0, nvo): the vertex graph with the proxy values, columns < nv; rows [nvo, nv): the received entries whose column is local.
+// Exact zeros off the diagonal are dropped in both (rows / columns of Dirichlet dofs), as the host build does.
+__device__ __forceinline__ double ras_proxy_value(const double *A00, int dim, int k) {
+  double v = 0.0;
+  for (int q = 0; q < dim; q++) v += A00[(size_t)dim * dim * k + (size_t)q * (dim + 1)];
+  return v / dim;
+}
+template <bool FILL>
+__global__ __launch_bounds__(TPB) void ras_rows_kernel(int nv, int nvo, int dim, int maxlen, const int *__restrict__ vptr, const int *__restrict__ vcol,
+                                                       const double *__restrict__ A00, const int *__restrict__ gptr, const int *__restrict__ gcol,
+                                                       const int *__restrict__ gsrc, const double *__restrict__ gval, int *__restrict__ rp,
+                                                       int *__restrict__ col, double *__restrict__ val) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= nv) return;
+  int p = FILL ? rp[i] : 0;
+  if (i < nvo) {
+    for (int k = vptr[i], e = vptr[i + 1]; k < e; k++) {
+      const int w = vcol[k];
+      if (w >= nv) continue;
+      const double v = ras_proxy_value(A00, dim, k);
+      if (v == 0.0 && w != i) continue;
+      if (FILL) { col[p] = w; val[p] = v; }
+      p++;
+    }
+  } else {
+    const int g = i - nvo;
+    for (int j = gptr[g], e = gptr[g + 1]; j < e; j++) {
+      const int w = gcol[j];
+      const double v = gval[(size_t)g * maxlen + gsrc[j]];
+      if (v == 0.0 && w != i) continue;
+      if (FILL) { col[p] = w; val[p] = v; }
+      p++;
+    }
+  }
+  if (!FILL) rp[i + 1] = p;
+}
+}  // namespace
+
+static int ras_exchange_rows(cfdh_ctx *c, const int *gid_dev) {
+  cfdh_ctx::RasPlan &R = c->rasp;
+  hipStream_t s = c->stream;
+  const int W = c->dim + 1;
+  if (!c->pcw.p) { HIPCHK(c, c->pcw.alloc(c->NL)); }
+  for (int k0 = 0; k0 < R.maxlen; k0 += W) {
+    hipLaunchKernelGGL(ras_pack_kernel, dim3((c->nvo + TPB - 1) / TPB), dim3(TPB), 0, s, c->nvo, c->dim, k0, c->vptr.p, c->vcol.p, c->A00.p, gid_dev, c->pcw.p);
+    HIPCHK(c, hipGetLastError());
+    CHK(comm_halo(c, c->pcw.p));
+    if (c->ng) hipLaunchKernelGGL(ras_unpack_kernel, dim3((c->ng + TPB - 1) / TPB), dim3(TPB), 0, s, c->ng, c->nvo, c->dim, k0, R.maxlen, c->pcw.p, R.gval.p);
+    HIPCHK(c, hipGetLastError());
+  }
+  HIPCHK(c, c->pcw.zero(s));
+  return 0;
+}
+
+int cfdh_proxy_ras_dev(cfdh_ctx *c, CsrDev &out) {
+  cfdh_ctx::RasPlan &R = c->rasp;
+  hipStream_t s = c->stream;
+  Dev dv(c);
+  const int nv = c->nv, nvo = c->nvo, ng = c->ng;
+  if ((int)c->h_gid.size() != nv || ng <= 0) return cfdh_fail(c, CFDH_E_STATE, "overlapping velocity cycle without the global vertex numbering");
+  if (!R.ready) {
+    // longest vertex-graph row over all ranks = number of entries every rank sends per vertex
+    int ml = 0;
+    for (int i = 0; i < nvo; i++) ml = std::max(ml, c->h_vptr[i + 1] - c->h_vptr[i]);
+    double mld = (double)ml;
+    HIPCHK(c, hipMemcpyAsync(c->red_out.p + 20, &mld, sizeof(double), hipMemcpyHostToDevice, s));
+    CHK(comm_allreduce_dev(c, c->red_out.p + 20, 1, 1));
+    HIPCHK(c, hipMemcpyAsync(&mld, c->red_out.p + 20, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    R.maxlen = (int)mld;
+    HIPCHK(c, R.gval.alloc((size_t)ng * R.maxlen + 1));
+    dbuf<int> gid;
+    HIPCHK(c, gid.upload(c->h_gid, s));
+    CHK(ras_exchange_rows(c, gid.p));
+    std::vector<double> hv((size_t)ng * R.maxlen);
+    HIPCHK(c, hipMemcpyAsync(hv.data(), R.gval.p, sizeof(double) * hv.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    std::vector<int> gptr(ng + 1, 0), gcol, gsrc;
+    std::vector<std::pair<int, int>> row;
+    for (int g = 0; g < ng; g++) {
+      row.clear();
+      for (int k = 0; k < R.maxlen; k++) {
+        const double gd = hv[(size_t)g * R.maxlen + k];
+        if (!(gd >= 0)) continue;
+        const int loc = c->h_g2l[(int)gd];
+        if (loc >= 0) row.push_back({loc, k});
+      }
+      std::sort(row.begin(), row.end());
+      bool diag = false;
+      for (auto &e : row) { gcol.push_back(e.first); gsrc.push_back(e.second); diag |= e.first == nvo + g; }
+      if (!diag) return cfdh_fail(c, CFDH_E_COMM, "ghost row %d arrived without its diagonal", g);
+      gptr[g + 1] = (int)gcol.size();
+    }
+    R.nent = (int)gcol.size();
+    HIPCHK(c, R.gptr.upload(gptr, s)); HIPCHK(c, R.gcol.upload(gcol, s)); HIPCHK(c, R.gsrc.upload(gsrc, s));
+    HIPCHK(c, hipStreamSynchronize(s));  // gid goes out of scope
+    R.ready = true;
+  }
+  CHK(ras_exchange_rows(c, nullptr));
+  out.n = out.m = nv;
+  HIPCHK(c, out.rowptr.alloc((size_t)nv + 1));
+  HIPCHK(c, hipMemsetAsync(out.rowptr.p, 0, sizeof(int), s));
+  hipLaunchKernelGGL((ras_rows_kernel<false>), dim3((nv + TPB - 1) / TPB), dim3(TPB), 0, s, nv, nvo, c->dim, R.maxlen, c->vptr.p, c->vcol.p, c->A00.p, R.gptr.p,
+                     R.gcol.p, R.gsrc.p, R.gval.p, out.rowptr.p, (int *)nullptr, (double *)nullptr);
+  CHK(dv.scan(out.rowptr.p + 1, nv));
+  int nnz = 0;
+  CHK(dv.read_int(out.rowptr.p + nv, &nnz));
+  out.nnz = nnz;
+  HIPCHK(c, out.col.alloc((size_t)std::max(nnz, 1)));
+  HIPCHK(c, out.val.alloc((size_t)std::max(nnz, 1)));
+  hipLaunchKernelGGL((ras_rows_kernel<true>), dim3((nv + TPB - 1) / TPB), dim3(TPB), 0, s, nv, nvo, c->dim, R.maxlen, c->vptr.p, c->vcol.p, c->A00.p, R.gptr.p,
+                     R.gcol.p, R.gsrc.p, R.gval.p, out.rowptr.p, out.col.p, out.val.p);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int cfdh_cc_h_dev(cfdh_ctx *c, double alpha, double beta, CsrDev &out) {
   if (c->d_Lval.n != c->h_Lval.size() || c->d_Ml.n != c->h_Ml.size()) {
     HIPCHK(c, c->d_Lval.upload(c->h_Lval, c->stream));

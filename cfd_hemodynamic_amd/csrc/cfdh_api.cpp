@@ -574,6 +574,7 @@ int cfdh_set_global_pressure_space(cfdh_ctx *c, int64_t nvg, int64_t ncg, const 
   // global ids of all local vertices (ghost ids through one halo exchange) and the inverse map: the overlapping
   // velocity preconditioner matches the matrix rows it receives from the owners of its ghosts by global id
   c->h_gid.clear(); c->h_g2l.clear();
+  c->rasp.ready = false;
   if (c->nranks > 1 && c->ng > 0 && c->nnbr > 0) {
     std::vector<double> hv((size_t)c->NL, -1.0);
     for (int k = 0; k < c->nvo; k++) hv[(size_t)D * k] = (double)l2g[k];  // first velocity slot of the vertex record

@@ -187,6 +187,7 @@ extern "C" int cfdh_set_halo(cfdh_ctx *c, int nnbr, const int32_t *nbr_rank, con
                              const int64_t *recv_ptr, const int32_t *recv_idx) {
   if (!c || nnbr < 0) return cfdh_fail(c, CFDH_E_ARG, "bad halo arguments");
   c->nnbr = nnbr;
+  c->rasp.ready = false;  // the ghost-row pattern follows the halo plan
   c->nbr_rank.assign(nbr_rank, nbr_rank + nnbr);
   c->send_ptr.assign(send_ptr, send_ptr + nnbr + 1);
   c->recv_ptr.assign(recv_ptr, recv_ptr + nnbr + 1);

@@ -320,6 +320,15 @@ struct cfdh_ctx {
   std::vector<int> h_gid;              // [nv] global id of every local vertex (internal numbering)
   std::vector<int> h_g2l;              // [gp_n] local internal index of a global vertex, -1 if not local
   dbuf<double> ras_b, ras_x;           // [2 nv] extended right-hand side / solution of the velocity cycle
+  // ghost rows of the velocity proxy fetched from their owners on the device (cfdh_proxy_ras_dev): the pattern is exchanged once
+  // per halo plan, the values at every rebuild in ceil(maxlen / (dim + 1)) halo exchanges
+  struct RasPlan {
+    bool ready = false;
+    int maxlen = 0;              // longest row of the vertex graph over all ranks
+    int nent = 0;
+    dbuf<int> gptr, gcol, gsrc;  // ghost rows: [ng + 1]; per entry the local column (ascending) and its position in the staging row
+    dbuf<double> gval;           // [ng][maxlen] entry k of the owner's vertex-graph row, as received
+  } rasp;
   // distributed finest level of the replicated pressure hierarchy: every rank smooths its own rows (owned rows,
   // owned + ghost columns), the coarse right-hand side is all-reduced and levels >= 1 stay replicated
   struct DistL0 {
@@ -402,6 +411,7 @@ bool cfdh_amg_dev_enabled(const cfdh_ctx *c);  // fused Jacobi cycle requested a
 int cfdh_amg_setup_dev(cfdh_ctx *c, AmgHier &H, CsrDev &A0, bool singular, int ncol);   // A0 (device CSR) is consumed
 int cfdh_level_setup_dev(cfdh_ctx *c, AmgLevel &L, CsrDev &A, double ratio, int ncol);  // A is consumed
 int cfdh_proxy_dev(cfdh_ctx *c, CsrDev &out);                       // scalar proxy of A00 on the owned vertices
+int cfdh_proxy_ras_dev(cfdh_ctx *c, CsrDev &out);                   // the same on owned + ghost vertices (collective: halo exchanges)
 int cfdh_cc_h_dev(cfdh_ctx *c, double alpha, double beta, CsrDev &out);  // H = (I + a'T) M_l + b' A11 (rows of ccPbc & 1: identity)
 
 // ---- tetrahedra (cfdh3_setup.cpp, cfdh3_kernels.hip) -------------------------------

@@ -132,6 +132,78 @@ static int amg_setup_from_host(cfdh_ctx *c, AmgHier &H, const CsrHost &A, bool s
   return cfdh_amg_setup(c, H, A, singular, ncol);
 }
 
+// Replicated pressure space of a partitioned run (cfdh_set_global_pressure_space): geometry only, built once per Dirichlet set.
+static int build_global_pressure(cfdh_ctx *c) {
+  const int nvo = c->nvo;
+  if (c->gp_n > 0 && (c->gp_dirty || !c->hLg.valid)) {
+    const bool dist = c->nranks > 1 && (int)c->h_gid.size() == c->nv && c->ng > 0;
+    c->hLg.keep_host0 = dist;
+    CHK(amg_setup_from_host(c, c->hLg, c->gp_L, c->gp_singular, 1));
+    c->gp_dirty = false;
+    // Distributed finest level: this rank's rows of the global level-0 operator / prolongator (the hierarchy is
+    // geometry-only and identical on all ranks, so no exchange is needed to build them).  The cycle is then the
+    // SAME arithmetic as the replicated one -- Jacobi sweeps are row-local once the ghost values are there.
+    cfdh_ctx::DistL0 &d = c->dl0;
+    d.on = false;
+    if (dist && c->hLg.lev.size() >= 2) {
+      const CsrHost &A0 = c->hLg.h_A0, &P0 = c->hLg.h_P0;
+      const std::vector<double> &w0 = c->hLg.h_wdinv0;
+      const int nv = c->nv, n1 = c->hLg.lev[1]->n;
+      bool ok = (int)w0.size() == c->gp_n && A0.n == c->gp_n && P0.n == c->gp_n && P0.m == n1;
+      CsrHost Al, Pl, Pt;
+      Al.n = nvo; Al.m = nv; Al.rowptr.assign(nvo + 1, 0);
+      for (int i = 0; i < nvo && ok; i++) {
+        const int g = c->h_gid[i];
+        for (int k = A0.rowptr[g]; k < A0.rowptr[g + 1]; k++) {
+          const int loc = c->h_g2l[A0.col[k]];
+          if (loc < 0) { ok = false; break; }  // a neighbour of an owned vertex is always local (one-cell overlap)
+          Al.col.push_back(loc); Al.val.push_back(A0.val[k]);
+        }
+        Al.rowptr[i + 1] = (int)Al.col.size();
+      }
+      Pl.n = nv; Pl.m = n1; Pl.rowptr.assign(nv + 1, 0);
+      std::vector<int> cnt(n1 + 1, 0);
+      for (int i = 0; i < nv && ok; i++) {
+        const int g = c->h_gid[i];
+        for (int k = P0.rowptr[g]; k < P0.rowptr[g + 1]; k++) {
+          Pl.col.push_back(P0.col[k]); Pl.val.push_back(P0.val[k]);
+          if (i < nvo) cnt[P0.col[k] + 1]++;
+        }
+        Pl.rowptr[i + 1] = (int)Pl.col.size();
+      }
+      if (ok) {
+        Pt.n = n1; Pt.m = nvo; Pt.rowptr.assign(n1 + 1, 0);
+        for (int I = 0; I < n1; I++) Pt.rowptr[I + 1] = Pt.rowptr[I] + cnt[I + 1];
+        Pt.col.resize(Pt.rowptr[n1]); Pt.val.resize(Pt.rowptr[n1]);
+        std::vector<int> fill(Pt.rowptr.begin(), Pt.rowptr.end() - 1);
+        for (int i = 0; i < nvo; i++)  // ascending owned index within every coarse row: fixed summation order
+          for (int k = Pl.rowptr[i]; k < Pl.rowptr[i + 1]; k++) { const int q = fill[Pl.col[k]]++; Pt.col[q] = i; Pt.val[q] = Pl.val[k]; }
+        std::vector<double> wl(nv);
+        for (int i = 0; i < nv; i++) wl[i] = w0[c->h_gid[i]];
+        CHK(cfdh_upload_csr(c, Al, d.A, &wl)); CHK(cfdh_upload_csr(c, Pl, d.P)); CHK(cfdh_upload_csr(c, Pt, d.PT));
+        HIPCHK(c, d.wdinv.upload(wl, c->stream));
+        HIPCHK(c, d.b.alloc(nv)); HIPCHK(c, d.xa.alloc(nv)); HIPCHK(c, d.r.alloc(nvo)); HIPCHK(c, d.x1.alloc(nv));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        d.n1 = n1;
+        d.on = true;
+        // Round 4: the ghost layer of the cycle's right-hand side is NOT exchanged any more -- the pre-smoothed iterate W b is taken
+        // as zero on the ghost vertices.  That perturbs the pre-smoothing on the interface rows only; measured with 4 ranks
+        // (gpurun_out/r4_d.log, r4_e.log): dfg_1 22.6 / 22.6 iterations per step with / without the exchange, stenosis 87.5 / 87.5,
+        // tetrahedra 70.2 / 70.5, cavity 26.7 / 26.7 -- one halo exchange per FGMRES iteration less.  CFDH_DL0_GHOST_RHS=1 restores it.
+        { const char *e = getenv("CFDH_DL0_GHOST_RHS"); d.ghost_rhs = e && e[0] == '1'; }
+      }
+      double bad = d.on ? 0.0 : 1.0;  // all ranks or none
+      HIPCHK(c, hipMemcpyAsync(c->red_out.p + 21, &bad, sizeof(double), hipMemcpyHostToDevice, c->stream));
+      CHK(comm_allreduce_dev(c, c->red_out.p + 21, 1, 1));
+      HIPCHK(c, hipMemcpyAsync(&bad, c->red_out.p + 21, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      d.on = bad == 0.0;
+      c->hLg.h_A0 = CsrHost(); c->hLg.h_P0 = CsrHost(); c->hLg.h_wdinv0.clear();
+    }
+  }
+  return 0;
+}
+
 static int build_cc_host(cfdh_ctx *c) {
   std::vector<double> a00, a01, a10, a11;
   CHK(cfdh_download_blocks(c, a00, a01, a10, a11));
@@ -241,72 +313,7 @@ static int build_cc_host(cfdh_ctx *c) {
     HIPCHK(c, c->ccMl.upload(ml, c->stream));
     HIPCHK(c, c->ccPbc.upload(pbc, c->stream));
   }
-  if (c->gp_n > 0 && (c->gp_dirty || !c->hLg.valid)) {
-    const bool dist = c->nranks > 1 && (int)c->h_gid.size() == c->nv && c->ng > 0;
-    c->hLg.keep_host0 = dist;
-    CHK(amg_setup_from_host(c, c->hLg, c->gp_L, c->gp_singular, 1));
-    c->gp_dirty = false;
-    // Distributed finest level: this rank's rows of the global level-0 operator / prolongator (the hierarchy is
-    // geometry-only and identical on all ranks, so no exchange is needed to build them).  The cycle is then the
-    // SAME arithmetic as the replicated one -- Jacobi sweeps are row-local once the ghost values are there.
-    cfdh_ctx::DistL0 &d = c->dl0;
-    d.on = false;
-    if (dist && c->hLg.lev.size() >= 2) {
-      const CsrHost &A0 = c->hLg.h_A0, &P0 = c->hLg.h_P0;
-      const std::vector<double> &w0 = c->hLg.h_wdinv0;
-      const int nv = c->nv, n1 = c->hLg.lev[1]->n;
-      bool ok = (int)w0.size() == c->gp_n && A0.n == c->gp_n && P0.n == c->gp_n && P0.m == n1;
-      CsrHost Al, Pl, Pt;
-      Al.n = nvo; Al.m = nv; Al.rowptr.assign(nvo + 1, 0);
-      for (int i = 0; i < nvo && ok; i++) {
-        const int g = c->h_gid[i];
-        for (int k = A0.rowptr[g]; k < A0.rowptr[g + 1]; k++) {
-          const int loc = c->h_g2l[A0.col[k]];
-          if (loc < 0) { ok = false; break; }  // a neighbour of an owned vertex is always local (one-cell overlap)
-          Al.col.push_back(loc); Al.val.push_back(A0.val[k]);
-        }
-        Al.rowptr[i + 1] = (int)Al.col.size();
-      }
-      Pl.n = nv; Pl.m = n1; Pl.rowptr.assign(nv + 1, 0);
-      std::vector<int> cnt(n1 + 1, 0);
-      for (int i = 0; i < nv && ok; i++) {
-        const int g = c->h_gid[i];
-        for (int k = P0.rowptr[g]; k < P0.rowptr[g + 1]; k++) {
-          Pl.col.push_back(P0.col[k]); Pl.val.push_back(P0.val[k]);
-          if (i < nvo) cnt[P0.col[k] + 1]++;
-        }
-        Pl.rowptr[i + 1] = (int)Pl.col.size();
-      }
-      if (ok) {
-        Pt.n = n1; Pt.m = nvo; Pt.rowptr.assign(n1 + 1, 0);
-        for (int I = 0; I < n1; I++) Pt.rowptr[I + 1] = Pt.rowptr[I] + cnt[I + 1];
-        Pt.col.resize(Pt.rowptr[n1]); Pt.val.resize(Pt.rowptr[n1]);
-        std::vector<int> fill(Pt.rowptr.begin(), Pt.rowptr.end() - 1);
-        for (int i = 0; i < nvo; i++)  // ascending owned index within every coarse row: fixed summation order
-          for (int k = Pl.rowptr[i]; k < Pl.rowptr[i + 1]; k++) { const int q = fill[Pl.col[k]]++; Pt.col[q] = i; Pt.val[q] = Pl.val[k]; }
-        std::vector<double> wl(nv);
-        for (int i = 0; i < nv; i++) wl[i] = w0[c->h_gid[i]];
-        CHK(cfdh_upload_csr(c, Al, d.A, &wl)); CHK(cfdh_upload_csr(c, Pl, d.P)); CHK(cfdh_upload_csr(c, Pt, d.PT));
-        HIPCHK(c, d.wdinv.upload(wl, c->stream));
-        HIPCHK(c, d.b.alloc(nv)); HIPCHK(c, d.xa.alloc(nv)); HIPCHK(c, d.r.alloc(nvo)); HIPCHK(c, d.x1.alloc(nv));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        d.n1 = n1;
-        d.on = true;
-        // Round 4: the ghost layer of the cycle's right-hand side is NOT exchanged any more -- the pre-smoothed iterate W b is taken
-        // as zero on the ghost vertices.  That perturbs the pre-smoothing on the interface rows only; measured with 4 ranks
-        // (gpurun_out/r4_d.log, r4_e.log): dfg_1 22.6 / 22.6 iterations per step with / without the exchange, stenosis 87.5 / 87.5,
-        // tetrahedra 70.2 / 70.5, cavity 26.7 / 26.7 -- one halo exchange per FGMRES iteration less.  CFDH_DL0_GHOST_RHS=1 restores it.
-        { const char *e = getenv("CFDH_DL0_GHOST_RHS"); d.ghost_rhs = e && e[0] == '1'; }
-      }
-      double bad = d.on ? 0.0 : 1.0;  // all ranks or none
-      HIPCHK(c, hipMemcpyAsync(c->red_out.p + 21, &bad, sizeof(double), hipMemcpyHostToDevice, c->stream));
-      CHK(comm_allreduce_dev(c, c->red_out.p + 21, 1, 1));
-      HIPCHK(c, hipMemcpyAsync(&bad, c->red_out.p + 21, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      d.on = bad == 0.0;
-      c->hLg.h_A0 = CsrHost(); c->hLg.h_P0 = CsrHost(); c->hLg.h_wdinv0.clear();
-    }
-  }
+  CHK(build_global_pressure(c));
   // --- H
   c->cc_alpha = c->rho * c->ts_a[0] / (c->ts_theta * c->dt);  // = 2 rho/dt for the midpoint scheme
   c->cc_beta = c->mu;
@@ -338,8 +345,7 @@ static int build_cc_host(cfdh_ctx *c) {
 }
 
 // The same preconditioner data built where the Jacobian lives (cfdh_amg_dev.hip): no download of the blocks, sparse
-// products / aggregation / formats by kernels.  Single-rank contexts; a partitioned run assembles its level-0 operators on the
-// host (ghost rows, replicated pressure space: build_cc_host) and hands them to the same device builder (amg_setup_from_host).
+// products / aggregation / formats by kernels.
 static int upload_csr_plain(cfdh_ctx *c, const CsrHost &H, CsrDev &D) {
   D.n = H.n; D.m = H.m; D.nnz = H.nnz();
   HIPCHK(c, D.rowptr.upload(H.rowptr, c->stream));
@@ -348,15 +354,51 @@ static int upload_csr_plain(cfdh_ctx *c, const CsrHost &H, CsrDev &D) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
+static int download_csr_plain(cfdh_ctx *c, const CsrDev &D, CsrHost &H) {
+  H.n = D.n; H.m = D.m;
+  H.rowptr.resize((size_t)D.n + 1); H.col.resize(D.nnz); H.val.resize(D.nnz);
+  HIPCHK(c, hipMemcpyAsync(H.rowptr.data(), D.rowptr.p, sizeof(int) * ((size_t)D.n + 1), hipMemcpyDeviceToHost, c->stream));
+  if (D.nnz) {
+    HIPCHK(c, hipMemcpyAsync(H.col.data(), D.col.p, sizeof(int) * (size_t)D.nnz, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(H.val.data(), D.val.p, sizeof(double) * (size_t)D.nnz, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+// Round 4: partitioned runs build here too.  The ghost rows of the overlapping velocity proxy are fetched from their owners by
+// halo exchanges of device buffers (cfdh_proxy_ras_dev), H drops the ghost columns in its kernel, and nothing of the Jacobian is
+// downloaded.  What is collective (the ghost-row exchange) succeeds or fails on all ranks alike; the hierarchy set-up behind it is
+// rank-local, so a rank whose device set-up gives up finishes on the host from a copy of its operator without the others noticing.
 static int build_cc_dev(cfdh_ctx *c) {
   const int nvo = c->nvo;
   const std::vector<int> &vp = c->h_vptr, &vc = c->h_vcol;
   const double t0 = wall_ms();
+  const bool multi = c->nranks > 1;
+  const bool ras = multi && c->gp_n > 0 && c->opt.schur_full == 2 && (int)c->h_gid.size() == c->nv && c->ng > 0;
   c->ras = false;
   {
-    CsrDev Ah;
-    CHK(cfdh_proxy_dev(c, Ah));
-    CHK(cfdh_amg_setup_dev(c, c->hA, Ah, false, c->dim));
+    CsrDev Ah, keep;
+    if (ras) {
+      CHK(cfdh_proxy_ras_dev(c, Ah));
+      if (!c->ras_b.p) { HIPCHK(c, c->ras_b.alloc((size_t)c->dim * c->nv)); HIPCHK(c, c->ras_x.alloc((size_t)c->dim * c->nv)); }
+    } else CHK(cfdh_proxy_dev(c, Ah));
+    c->ras = ras;
+    if (multi) {  // the set-up consumes its operator
+      keep.n = Ah.n; keep.m = Ah.m; keep.nnz = Ah.nnz;
+      HIPCHK(c, keep.rowptr.alloc((size_t)Ah.n + 1)); HIPCHK(c, keep.col.alloc((size_t)std::max(Ah.nnz, 1))); HIPCHK(c, keep.val.alloc((size_t)std::max(Ah.nnz, 1)));
+      HIPCHK(c, hipMemcpyAsync(keep.rowptr.p, Ah.rowptr.p, sizeof(int) * ((size_t)Ah.n + 1), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(keep.col.p, Ah.col.p, sizeof(int) * (size_t)Ah.nnz, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(keep.val.p, Ah.val.p, sizeof(double) * (size_t)Ah.nnz, hipMemcpyDeviceToDevice, c->stream));
+    }
+    const int rc = cfdh_amg_setup_dev(c, c->hA, Ah, false, c->dim);
+    if (rc != 0) {
+      if (!multi) return rc;
+      if (c->opt.verbose) fprintf(stderr, "[cfdh] device-side AMG set-up gave up (%s): building the velocity hierarchy on the host\n", c->err.c_str());
+      c->err.clear(); c->hA.clear();
+      CsrHost Ahh;
+      CHK(download_csr_plain(c, keep, Ahh));
+      CHK(cfdh_amg_setup(c, c->hA, Ahh, false, c->dim));
+    }
   }
   const double t1 = wall_ms();
   // pressure Laplacian hierarchy: geometry and Dirichlet set only (see build_cc_host for the pbc bits)
@@ -381,9 +423,12 @@ static int build_cc_dev(cfdh_ctx *c) {
         }
       Lh.rowptr[i + 1] = (int)Lh.col.size();
     }
-    CsrDev Ld;
-    CHK(upload_csr_plain(c, Lh, Ld));
-    CHK(cfdh_amg_setup_dev(c, c->hL, Ld, c->singular != 0 || !any_pbc, 1));
+    if (multi) CHK(amg_setup_from_host(c, c->hL, Lh, c->singular != 0 || !any_pbc, 1));
+    else {
+      CsrDev Ld;
+      CHK(upload_csr_plain(c, Lh, Ld));
+      CHK(cfdh_amg_setup_dev(c, c->hL, Ld, c->singular != 0 || !any_pbc, 1));
+    }
     c->hL_pbc = pbc;
     c->hL_singular = c->singular;
     std::vector<double> ml(nvo);
@@ -392,6 +437,7 @@ static int build_cc_dev(cfdh_ctx *c) {
     HIPCHK(c, c->ccPbc.upload(pbc, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  if (multi) CHK(build_global_pressure(c));
   const double t2 = wall_ms();
   c->cc_alpha = c->rho * c->ts_a[0] / (c->ts_theta * c->dt);
   c->cc_beta = c->mu;
@@ -408,6 +454,10 @@ static int build_cc_dev(cfdh_ctx *c) {
   return 0;
 }
 static int build_cc(cfdh_ctx *c) {
+  // CFDH_PC_HOST_ASSEMBLY=1: level-0 operators of a partitioned run assembled on the host as in rounds 2-3 (comparison, tests)
+  static const bool host_multi = (getenv("CFDH_AMG_HOST_MULTI") && getenv("CFDH_AMG_HOST_MULTI")[0] == '1') ||
+                                 (getenv("CFDH_PC_HOST_ASSEMBLY") && getenv("CFDH_PC_HOST_ASSEMBLY")[0] == '1');
+  if (c->nranks > 1 && cfdh_amg_dev_enabled(c) && !host_multi) return build_cc_dev(c);  // no per-rank fall-back across a collective
   if (c->nranks == 1 && cfdh_amg_dev_enabled(c)) {
     const int rc = build_cc_dev(c);
     if (rc == 0) return 0;

@@ -281,6 +281,21 @@ def test_generic_elements_partitioned_over_ranks(tmp_path, case, world, backend)
     assert int(r["krylov"]) <= 1.6 * ref_krylov, (int(r["krylov"]), ref_krylov)
 
 
+@pytest.mark.parametrize("case", ["", "bif3d"])
+def test_partitioned_preconditioner_built_on_the_device_equals_the_host_assembled_one(tmp_path, case):
+    """Round 4: in a partitioned run the level-0 operators of the preconditioner are built where the Jacobian lives -- the ghost rows
+    of the overlapping velocity proxy arrive by halo exchanges of device buffers (cfdh_proxy_ras_dev), H drops its ghost columns in
+    the kernel, nothing is downloaded.  Same operators as the host assembly of rounds 2-3 (CFDH_PC_HOST_ASSEMBLY=1): same FGMRES
+    iteration count, same solution."""
+    env = dict(CFDH_TEST_CASE=case) if case else {}
+    a = _run(3, str(tmp_path / "dev.npz"), **env)
+    b = _run(3, str(tmp_path / "host.npz"), CFDH_PC_HOST_ASSEMBLY="1", **env)
+    assert int(a["ras"]) == 1 and int(b["ras"]) == 1
+    assert int(a["krylov"]) == int(b["krylov"])
+    assert np.linalg.norm(a["u"] - b["u"]) <= 1e-12 * np.linalg.norm(b["u"])
+    assert np.linalg.norm(a["p"] - b["p"]) <= 1e-11 * np.linalg.norm(b["p"])
+
+
 def test_communication_per_iteration_at_the_reference_tolerances(tmp_path):
     """The same 4-rank run at PETSc-default tolerances (what the timed loops run): iterations are launched ahead of the host's
     bookkeeping and nothing takes the second Gram-Schmidt pass, so one FGMRES iteration costs 3 halo exchanges, 2 all-reduces
