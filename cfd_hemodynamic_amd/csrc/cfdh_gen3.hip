@@ -34,7 +34,10 @@ namespace {
 
 // ET: 0 P1 tetrahedron (through the generic kernels: cross-check of the closed-form path), 1 P2 tetrahedron, 2 Q1 hexahedron
 __host__ __device__ constexpr int g3_nloc(int et) { return et == 0 ? 4 : (et == 1 ? 10 : 8); }
-__host__ __device__ constexpr int g3_wgs(int et) { return et == 1 ? 128 : 64; }
+// The assembly workgroup: 256 lanes = NG point groups of GS lanes; lane (g, a, b) sums block (a, b) of the element matrix over the
+// points s = g, g + NG, ... of every 64-point chunk, and the groups are added in a fixed order at the end.
+__host__ __device__ constexpr int g3_wgs(int) { return 256; }
+__host__ __device__ constexpr int g3_gs(int et) { return et == 0 ? 16 : (et == 1 ? 128 : 64); }  // >= nloc^2
 
 __constant__ double d3_pts[2][G3_NQ][4];  // [0] tetrahedron, [1] hexahedron: reference point (x, y, z), weight times reference measure
 __constant__ double d3_tri[CFDH_NQ][4];   // triangle rule: barycentric point, weight (sum 1)
@@ -210,9 +213,9 @@ struct Cell3 {
 #define FLD 23  // per-point record: uq 0-2 | G 3-11 (G[i][j] = d_i ubar_j) | R 12-14 | rho (w + C - f) 15-17 | pq 18 | tau 19 | tauL 20 | dv 21
 
 template <int ET, bool JAC>
-__global__ __launch_bounds__(g3_wgs(ET)) void gen3_asm_kernel(Gen3Args P) {
-  constexpr int NL = g3_nloc(ET), WGS = g3_wgs(ET), NF = ET == 2 ? 6 : 4;
-  constexpr int CH = 64;                             // points per chunk: lanes 0..63 evaluate one point each
+__global__ __launch_bounds__(g3_wgs(ET), 2) void gen3_asm_kernel(Gen3Args P) {
+  constexpr int NL = g3_nloc(ET), WGS = g3_wgs(ET), GS = g3_gs(ET), NG = WGS / GS, NF = ET == 2 ? 6 : 4;
+  constexpr int CH = ET == 2 ? 32 : 64;              // points per chunk (32 on hexahedra: their per-point Hessians would cost a third workgroup per CU)
   constexpr int NCH = (G3_NQ + CH - 1) / CH;
   __shared__ Cell3<NL> D;
   __shared__ double fld[CH][FLD];
@@ -220,8 +223,9 @@ __global__ __launch_bounds__(g3_wgs(ET)) void gen3_asm_kernel(Gen3Args P) {
   __shared__ double hes[ET == 2 ? CH : 1][NL][6];    // physical second derivatives: per point on hexahedra, cell constants on P2 tetrahedra
   __shared__ double geo[12];                         // Ji (9), |det|, h, needj
   const int cell = blockIdx.x, t = threadIdx.x;
-  const int a = t / NL, b = t % NL;
-  const bool live = t < NL * NL;
+  const int grp = t / GS, blk = t % GS;
+  const int a = blk / NL, b = blk % NL;
+  const bool live = blk < NL * NL;
   const int nvo = P.nvo;
   if (t < NL) {
     const int v = P.cells[(size_t)cell * NL + t];
@@ -267,6 +271,23 @@ __global__ __launch_bounds__(g3_wgs(ET)) void gen3_asm_kernel(Gen3Args P) {
   // this lane's block of the element matrix and (b == 0) the residual rows of node a
   double Juu[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Jup[3] = {0, 0, 0}, Jpu[3] = {0, 0, 0}, Jpp = 0.0, Fa[4] = {0, 0, 0, 0};
   for (int ch = 0; ch < NCH; ch++) {
+    // ---- basis functions of the chunk's points: one (point, node) pair per lane and pass; the node is uniform in a wavefront
+    for (int item = t; item < CH * NL; item += WGS) {
+      const int sp = item % CH, c = item / CH, q = ch * CH + sp;
+      if (q >= G3_NQ) continue;
+      const double *pt = d3_pts[ET == 2 ? 1 : 0][q];
+      double ph, dr[3];
+      basis3<ET>(c, pt, ph, dr);
+      bas[sp][c][0] = ph;
+      for (int i = 0; i < 3; i++) bas[sp][c][1 + i] = dr[0] * Ji[0][i] + dr[1] * Ji[1][i] + dr[2] * Ji[2][i];
+      if (ET == 2) {
+        double Hr[6], Hs[6];
+        hess3<ET>(c, pt, Hr);
+        hess_phys(Hr, Ji, Hs);
+        for (int k = 0; k < 6; k++) hes[sp][c][k] = Hs[k];
+      }
+    }
+    __syncthreads();
     const int q = ch * CH + t;
     if (t < CH && q < G3_NQ) {
       // ---- everything that belongs to the point, once
@@ -275,19 +296,9 @@ __global__ __launch_bounds__(g3_wgs(ET)) void gen3_asm_kernel(Gen3Args P) {
       double visc[3] = {0, 0, 0};
 #pragma unroll
       for (int c = 0; c < NL; c++) {
-        double ph, dr[3], g[3];
-        basis3<ET>(c, pt, ph, dr);
-        for (int i = 0; i < 3; i++) g[i] = dr[0] * Ji[0][i] + dr[1] * Ji[1][i] + dr[2] * Ji[2][i];
-        bas[t][c][0] = ph; bas[t][c][1] = g[0]; bas[t][c][2] = g[1]; bas[t][c][3] = g[2];
+        const double ph = bas[t][c][0], g[3] = {bas[t][c][1], bas[t][c][2], bas[t][c][3]};
         double Hs[6];
-        if (ET == 2) {
-          double Hr[6];
-          hess3<ET>(c, pt, Hr);
-          hess_phys(Hr, Ji, Hs);
-          for (int k = 0; k < 6; k++) hes[t][c][k] = Hs[k];
-        } else {
-          for (int k = 0; k < 6; k++) Hs[k] = hes[0][c][k];
-        }
+        for (int k = 0; k < 6; k++) Hs[k] = hes[ET == 2 ? t : 0][c][k];
         const double lapc = Hs[0] + Hs[3] + Hs[5];
         for (int i = 0; i < 3; i++) {
           uq[i] += ph * D.ub[c][i]; wv[i] += ph * D.wn[c][i]; unq[i] += ph * D.un[c][i];
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(g3_wgs(ET)) void gen3_asm_kernel(Gen3Args P) {
     __syncthreads();
     const int npt = min(CH, G3_NQ - ch * CH);
     if (live && (needj || b == 0)) {
-      for (int s = 0; s < npt; s++) {
+      for (int s = grp; s < npt; s += NG) {
         const double *fr = fld[s];
         const double pha = bas[s][a][0], ga[3] = {bas[s][a][1], bas[s][a][2], bas[s][a][3]};
         const double uq[3] = {fr[0], fr[1], fr[2]}, R[3] = {fr[12], fr[13], fr[14]};
@@ -360,8 +371,98 @@ __global__ __launch_bounds__(g3_wgs(ET)) void gen3_asm_kernel(Gen3Args P) {
     }
     __syncthreads();
   }
+  // ---- the point groups are added in the order 0, 1, ..., NG - 1 (fixed: bitwise reproducible); VB values per lane and pass fit the
+  //      basis table, which is free now
+  {
+    constexpr int VB = CH * NL * 4 / WGS;
+    static_assert(VB >= 1 && VB * WGS <= CH * NL * 4, "the reduction buffer is the basis table");
+    double *red = &bas[0][0][0];
+    double acc[20];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) acc[3 * i + j] = Juu[i][j]; acc[9 + i] = Jup[i]; acc[12 + i] = Jpu[i]; }
+    acc[15] = Jpp;
+    for (int i = 0; i < 4; i++) acc[16 + i] = Fa[i];
+#pragma unroll
+    for (int k0 = 0; k0 < 20; k0 += VB) {
+      if (grp > 0) {
+#pragma unroll
+        for (int k = 0; k < VB; k++) if (k0 + k < 20) red[(size_t)k * WGS + t] = acc[k0 + k];
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int k = 0; k < VB; k++)
+          if (k0 + k < 20)
+            for (int g = 1; g < NG; g++) acc[k0 + k] += red[(size_t)k * WGS + g * GS + blk];
+      }
+      __syncthreads();
+    }
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Juu[i][j] = acc[3 * i + j]; Jup[i] = acc[9 + i]; Jpu[i] = acc[12 + i]; }
+    Jpp = acc[15];
+    for (int i = 0; i < 4; i++) Fa[i] = acc[16 + i];
+  }
+  if (!live || grp != 0) return;
+  // ---- Dirichlet handling on the element level: lifting with the FULL block, then constrained rows and columns dropped
+  const unsigned bca = D.bc[a], bcb = D.bc[b];
+  const double l0 = D.lift[b][0], l1 = D.lift[b][1], l2 = D.lift[b][2], l3 = D.lift[b][3];
+  double Fl[4];
+  for (int i = 0; i < 3; i++) Fl[i] = (b == 0 ? Fa[i] : 0.0) + Juu[i][0] * l0 + Juu[i][1] * l1 + Juu[i][2] * l2 + Jup[i] * l3;
+  Fl[3] = (b == 0 ? Fa[3] : 0.0) + Jpu[0] * l0 + Jpu[1] * l1 + Jpu[2] * l2 + Jpp * l3;
+  const int fd = P.fdst[(size_t)cell * NL * NL + blk];
+  if (fd < 0) return;  // row of a ghost node: assembled by its owner (one-cell overlap of the partition)
+  double *ef = P.EF + 4 * (size_t)fd;
+  for (int i = 0; i < 4; i++) ef[i] = ((bca >> i) & 1u) ? 0.0 : Fl[i];
+  if (P.mode != 1) return;
+  double *eb = P.E + 16 * (size_t)P.slot[(size_t)cell * NL * NL + blk];
+  for (int i = 0; i < 3; i++) {
+    const bool ri = (bca >> i) & 1u;
+    for (int j = 0; j < 3; j++) eb[3 * i + j] = (ri || ((bcb >> j) & 1u)) ? 0.0 : Juu[i][j];
+    eb[9 + i] = (ri || (bcb & 8u)) ? 0.0 : Jup[i];
+  }
+  const bool rp = bca & 8u;
+  for (int j = 0; j < 3; j++) eb[12 + j] = (rp || ((bcb >> j) & 1u)) ? 0.0 : Jpu[j];
+  eb[15] = (rp || (bcb & 8u)) ? 0.0 : Jpp;
+}
+
+// Exterior-facet terms (the ds pair of the do-nothing outlet, the backflow term) of the flagged cells, ADDED to what the volume kernel
+// staged: every (cell, a, b) entry of E / EF belongs to one lane, so the update needs no atomics and keeps the fixed summation order.
+// The Dirichlet handling is linear in the block, so lifting and masks apply to the facet part on its own.  A kernel of its own
+// because inlined into the volume kernel it cost that kernel a third of its registers (314 instead of 218) on every cell.
+template <int ET>
+__global__ __launch_bounds__(128) void gen3_facet_kernel(Gen3Args P, const int *__restrict__ fcells) {
+  constexpr int NL = g3_nloc(ET), NF = ET == 2 ? 6 : 4;
+  __shared__ Cell3<NL> D;
+  __shared__ double geo[9];
+  const int cell = fcells[blockIdx.x], t = threadIdx.x;
+  const int blk = t, a = blk / NL, b = blk % NL;
+  const bool live = blk < NL * NL;
+  const int nvo = P.nvo;
+  if (t < NL) {
+    const int v = P.cells[(size_t)cell * NL + t];
+    const unsigned char bf = P.bcflag[v];
+    D.bc[t] = bf;
+    for (int i = 0; i < 3; i++) {
+      D.X[t][i] = P.coords[3 * (size_t)v + i];
+      const double u = P.x[g3uo(v, nvo) + i], un = P.xprev[g3uo(v, nvo) + i];
+      D.un[t][i] = un;
+      D.ub[t][i] = P.theta * u + (1.0 - P.theta) * un;
+      D.lift[t][i] = (bf >> i) & 1 ? P.bcval[4 * (size_t)v + i] - u : 0.0;
+    }
+    const double pv = P.x[g3po(v, nvo)];
+    D.p[t] = pv;
+    D.lift[t][3] = (bf >> 3) & 1 ? P.bcval[4 * (size_t)v + 3] - pv : 0.0;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double Ji0[3][3], ad, hh;
+    geom3<ET>(D.X, Ji0, ad, hh);
+    for (int k = 0; k < 9; k++) geo[k] = Ji0[k / 3][k % 3];
+  }
+  __syncthreads();
   if (!live) return;
-  // ---- exterior-facet terms of this cell for the lane's block / residual rows
+  double Ji[3][3];
+  for (int k = 0; k < 9; k++) Ji[k / 3][k % 3] = geo[k];
+  const double rho = P.rho, th = P.theta;
+  double Juu[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Jup[3] = {0, 0, 0}, Fa[4] = {0, 0, 0, 0};
   const unsigned fl = P.flag[cell];
   if (fl) {
     for (int f = 0; f < NF; f++) {
@@ -408,26 +509,22 @@ __global__ __launch_bounds__(g3_wgs(ET)) void gen3_asm_kernel(Gen3Args P) {
       }
     }
   }
-  // ---- Dirichlet handling on the element level: lifting with the FULL block, then constrained rows and columns dropped
   const unsigned bca = D.bc[a], bcb = D.bc[b];
   const double l0 = D.lift[b][0], l1 = D.lift[b][1], l2 = D.lift[b][2], l3 = D.lift[b][3];
-  double Fl[4];
-  for (int i = 0; i < 3; i++) Fl[i] = (b == 0 ? Fa[i] : 0.0) + Juu[i][0] * l0 + Juu[i][1] * l1 + Juu[i][2] * l2 + Jup[i] * l3;
-  Fl[3] = (b == 0 ? Fa[3] : 0.0) + Jpu[0] * l0 + Jpu[1] * l1 + Jpu[2] * l2 + Jpp * l3;
-  const int fd = P.fdst[(size_t)cell * NL * NL + t];
-  if (fd < 0) return;  // row of a ghost node: assembled by its owner (one-cell overlap of the partition)
+  const int fd = P.fdst[(size_t)cell * NL * NL + blk];
+  if (fd < 0) return;
   double *ef = P.EF + 4 * (size_t)fd;
-  for (int i = 0; i < 4; i++) ef[i] = ((bca >> i) & 1u) ? 0.0 : Fl[i];
+  for (int i = 0; i < 3; i++) {
+    const double Fl = (b == 0 ? Fa[i] : 0.0) + Juu[i][0] * l0 + Juu[i][1] * l1 + Juu[i][2] * l2 + Jup[i] * l3;
+    if (!((bca >> i) & 1u)) ef[i] += Fl;
+  }
   if (P.mode != 1) return;
-  double *eb = P.E + 16 * (size_t)P.slot[(size_t)cell * NL * NL + t];
+  double *eb = P.E + 16 * (size_t)P.slot[(size_t)cell * NL * NL + blk];
   for (int i = 0; i < 3; i++) {
     const bool ri = (bca >> i) & 1u;
-    for (int j = 0; j < 3; j++) eb[3 * i + j] = (ri || ((bcb >> j) & 1u)) ? 0.0 : Juu[i][j];
-    eb[9 + i] = (ri || (bcb & 8u)) ? 0.0 : Jup[i];
+    for (int j = 0; j < 3; j++) if (!(ri || ((bcb >> j) & 1u))) eb[3 * i + j] += Juu[i][j];
+    if (!(ri || (bcb & 8u))) eb[9 + i] += Jup[i];
   }
-  const bool rp = bca & 8u;
-  for (int j = 0; j < 3; j++) eb[12 + j] = (rp || ((bcb >> j) & 1u)) ? 0.0 : Jpu[j];
-  eb[15] = (rp || (bcb & 8u)) ? 0.0 : Jpp;
 }
 
 // second phase: fixed-order sums of the staged contributions, every output written once
@@ -858,6 +955,12 @@ int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv64, int64_t nvo64, in
   HIPCHK(c, c->coords.upload(c->h_coords, s));
   HIPCHK(c, c->cells.upload(c->h_cells, s));
   HIPCHK(c, c->gflag.upload(gflag, s));
+  {
+    std::vector<int> fcl;
+    for (int e = 0; e < nc; e++) if (gflag[e]) fcl.push_back(e);
+    c->g3_nfcells = (int)fcl.size();
+    if (c->g3_nfcells) HIPCHK(c, c->g3_fcells.upload(fcl, s));
+  }
   HIPCHK(c, c->gslot.upload(slot, s));
   HIPCHK(c, c->g_eptr.upload(eptr, s)); HIPCHK(c, c->g_fptr.upload(fptr, s)); HIPCHK(c, c->g_fdst.upload(fdst, s));
   HIPCHK(c, c->gE.alloc(16 * (size_t)nc * NL * NL)); HIPCHK(c, c->gEF.alloc(4 * (size_t)nc * NL * NL));
@@ -953,6 +1056,12 @@ int kg3_assemble(cfdh_ctx *c, const double *xstate, int mode) {
   else if (c->etype == 2) G3_LAUNCH(2);
   else G3_LAUNCH(0);
 #undef G3_LAUNCH
+  if (c->g3_nfcells > 0 && (P.ds_terms || P.beta != 0.0)) {
+    const dim3 fg(c->g3_nfcells), fb(128);
+    if (c->etype == 1) hipLaunchKernelGGL((gen3_facet_kernel<1>), fg, fb, 0, c->stream, P, c->g3_fcells.p);
+    else if (c->etype == 2) hipLaunchKernelGGL((gen3_facet_kernel<2>), fg, fb, 0, c->stream, P, c->g3_fcells.p);
+    else hipLaunchKernelGGL((gen3_facet_kernel<0>), fg, fb, 0, c->stream, P, c->g3_fcells.p);
+  }
   const dim3 block(TPB);
   hipLaunchKernelGGL(gen3_gather_F_kernel, dim3((c->nvo + TPB - 1) / TPB), block, 0, c->stream, c->nvo, c->g_fptr.p, c->gEF.p, c->F.p);
   if (mode == 1)

@@ -160,6 +160,8 @@ struct cfdh_ctx {
   dbuf<int> g_eptr, g_fptr, g_fdst;   // [nnzv + 1], [nv + 1], [nc][nloc]
   dbuf<double> gE, gEF;               // [nc nloc^2][9], [nc nloc][3]
   dbuf<unsigned short> gflag;  // [nc] bit f: exterior facet f, bit 8 + f: backflow facet f
+  dbuf<int> g3_fcells;         // 3-D generic elements: the cells with an exterior facet (gen3_facet_kernel)
+  int g3_nfcells = 0;
   // P2: the P1 subspace as the first coarse level of both hierarchies (p-multigrid step): prolongator [nodes x vertex nodes],
   // 1 at a vertex node, 1/2 + 1/2 at an edge node (host copy; internal numbering)
   CsrHost gen_P1;
