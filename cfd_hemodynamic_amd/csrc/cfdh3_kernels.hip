@@ -1,7 +1,7 @@
 // gfx950 kernels of the tetrahedral (gdim == 3) instance of the stabilized_schur step: P1/P1 on affine tetrahedra,
 // 12 + 4 element dofs, 4x4 vertex blocks (A00 [9], A01 [3], A10 [3], A11 per graph entry).
 //
-//  * moments3_kernel : M_ab = int_K tau l_a l_b (10 values) and L = int_K tau_LSIC on the 343-point rule
+//  * moments3_kernel : M_ab = int_K tau l_a l_b (10 values) and L = int_K tau_LSIC on the 171-point degree-13 rule (include/cfdh_quad_tet.h)
 //                      (stabilized_schur.py:100-118; u_prev only -> once per time step)
 //  * asm3q_kernel    : fused element residual + Jacobian + Dirichlet rows/cols + lifting (stabilized_schur.py:67-123,
 //                      144-175,185-189).  Four lanes per (row vertex, cell) incidence, one 4x4 column block each.

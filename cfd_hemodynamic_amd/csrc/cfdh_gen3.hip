@@ -4,8 +4,8 @@
 // on the 3-D meshes of scenario_factory.py:47-49).  Every node carries (u_x, u_y, u_z, p): the linear-algebra side -- node graph
 // with 4 x 4 blocks in SoA arrays, block SpMV, FGMRES, Cahouet-Chabard + AMG -- is the tetrahedral code on the NODE graph.
 //
-// Element integration by quadrature: 343 points (7 x 7 x 7 Gauss on hexahedra, the degree-13 collapsed rule of the P1 tau-moments
-// on tetrahedra), i.e. 343 x (4 nloc)^2 Jacobian contributions per cell -- compute-bound by two orders of magnitude more than
+// Element integration by quadrature: 7 x 7 x 7 Gauss points on hexahedra, the 171-point degree-13 rule of the P1 tau-moments
+// on tetrahedra, i.e. 343 | 171 x (4 nloc)^2 Jacobian contributions per cell -- compute-bound by two orders of magnitude more than
 // the closed-form P1 path, whatever the mapping.  The mapping that keeps the redundancy out:
 //   * ONE CELL PER WORKGROUP, one lane per block (a, b) of the element matrix (64 lanes for a hexahedron, 100 of 128 for a P2
 //     tetrahedron); a lane keeps its 4 x 4 block in registers over the whole quadrature loop;
@@ -28,7 +28,9 @@
 #include "cfdh_quad_tri.h"
 
 #define TPB 256
-#define G3_NQ 343
+#define G3_NQ 343  // table size: 7 x 7 x 7 Gauss points on hexahedra; tetrahedra use the first CFDH3_NQ (171) entries
+__host__ __device__ constexpr int g3_nq(int et) { return et == 2 ? 343 : CFDH3_NQ; }
+static_assert(CFDH3_NQ <= G3_NQ, "point table");
 
 namespace {
 
@@ -216,7 +218,7 @@ template <int ET, bool JAC>
 __global__ __launch_bounds__(g3_wgs(ET), 2) void gen3_asm_kernel(Gen3Args P) {
   constexpr int NL = g3_nloc(ET), WGS = g3_wgs(ET), GS = g3_gs(ET), NG = WGS / GS, NF = ET == 2 ? 6 : 4;
   constexpr int CH = ET == 2 ? 32 : 64;              // points per chunk (32 on hexahedra: their per-point Hessians would cost a third workgroup per CU)
-  constexpr int NCH = (G3_NQ + CH - 1) / CH;
+  constexpr int NQ = g3_nq(ET), NCH = (NQ + CH - 1) / CH;
   __shared__ Cell3<NL> D;
   __shared__ double fld[CH][FLD];
   __shared__ double bas[CH][NL][4];                  // physical (phi, grad phi) of every node at the chunk's points
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(g3_wgs(ET), 2) void gen3_asm_kernel(Gen3Args P) {
     // ---- basis functions of the chunk's points: one (point, node) pair per lane and pass; the node is uniform in a wavefront
     for (int item = t; item < CH * NL; item += WGS) {
       const int sp = item % CH, c = item / CH, q = ch * CH + sp;
-      if (q >= G3_NQ) continue;
+      if (q >= NQ) continue;
       const double *pt = d3_pts[ET == 2 ? 1 : 0][q];
       double ph, dr[3];
       basis3<ET>(c, pt, ph, dr);
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(g3_wgs(ET), 2) void gen3_asm_kernel(Gen3Args P) {
     }
     __syncthreads();
     const int q = ch * CH + t;
-    if (t < CH && q < G3_NQ) {
+    if (t < CH && q < NQ) {
       // ---- everything that belongs to the point, once
       const double *pt = d3_pts[ET == 2 ? 1 : 0][q];
       double uq[3] = {0, 0, 0}, wv[3] = {0, 0, 0}, unq[3] = {0, 0, 0}, G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gp[3] = {0, 0, 0}, pq = 0.0;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(g3_wgs(ET), 2) void gen3_asm_kernel(Gen3Args P) {
       fr[18] = pq; fr[19] = tau; fr[20] = tauL; fr[21] = adet * pt[3];
     }
     __syncthreads();
-    const int npt = min(CH, G3_NQ - ch * CH);
+    const int npt = min(CH, NQ - ch * CH);
     if (live && (needj || b == 0)) {
       for (int s = grp; s < npt; s += NG) {
         const double *fr = fld[s];
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(TPB) void gen3_l2_kernel(int nc, int nvo, const int
     }
     double Ji[3][3], adet, h;
     geom3<ET>(X, Ji, adet, h);
-    for (int q = 0; q < G3_NQ; q++) {
+    for (int q = 0; q < g3_nq(ET); q++) {
       const double *pt = d3_pts[ET == 2 ? 1 : 0][q];
       double uq[3] = {0, 0, 0}, pq = 0;
       for (int a = 0; a < NL; a++) {
@@ -713,7 +715,7 @@ inline uint32_t part1by2(uint32_t x) {
 int kg3_upload_tables(cfdh_ctx *c) {
   static double pts[2][G3_NQ][4], tri[CFDH_NQ][4], g2[2][2];
   for (int q = 0; q < G3_NQ; q++) {
-    pts[0][q][0] = CFDH3_QL[q][1]; pts[0][q][1] = CFDH3_QL[q][2]; pts[0][q][2] = CFDH3_QL[q][3]; pts[0][q][3] = CFDH3_QW[q] / 6.0;
+    if (q < CFDH3_NQ) { pts[0][q][0] = CFDH3_QL[q][1]; pts[0][q][1] = CFDH3_QL[q][2]; pts[0][q][2] = CFDH3_QL[q][3]; pts[0][q][3] = CFDH3_QW[q] / 6.0; }
     const int i = q / 49, j = (q / 7) % 7, k = q % 7;
     pts[1][q][0] = CFDH_GL7_X[i]; pts[1][q][1] = CFDH_GL7_X[j]; pts[1][q][2] = CFDH_GL7_X[k]; pts[1][q][3] = CFDH_GL7_W[i] * CFDH_GL7_W[j] * CFDH_GL7_W[k];
   }
@@ -852,13 +854,14 @@ int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv64, int64_t nvo64, in
   std::vector<double> mdiag(nv, 0.0);
   static double pts[2][G3_NQ][4];
   for (int q = 0; q < G3_NQ; q++) {
-    pts[0][q][0] = CFDH3_QL[q][1]; pts[0][q][1] = CFDH3_QL[q][2]; pts[0][q][2] = CFDH3_QL[q][3]; pts[0][q][3] = CFDH3_QW[q] / 6.0;
+    if (q < CFDH3_NQ) { pts[0][q][0] = CFDH3_QL[q][1]; pts[0][q][1] = CFDH3_QL[q][2]; pts[0][q][2] = CFDH3_QL[q][3]; pts[0][q][3] = CFDH3_QW[q] / 6.0; }
     const int i = q / 49, j = (q / 7) % 7, k = q % 7;
     pts[1][q][0] = CFDH_GL7_X[i]; pts[1][q][1] = CFDH_GL7_X[j]; pts[1][q][2] = CFDH_GL7_X[k]; pts[1][q][3] = CFDH_GL7_W[i] * CFDH_GL7_W[j] * CFDH_GL7_W[k];
   }
   // reference stiffness-like integrals are cell dependent only through Ji: K_ab = |det| sum_q w_q (Ji^T dphi_a) . (Ji^T dphi_b)
+  const int nq = g3_nq(et);
   std::vector<double> rphi((size_t)G3_NQ * NL), rd((size_t)G3_NQ * NL * 3);
-  for (int q = 0; q < G3_NQ; q++)
+  for (int q = 0; q < nq; q++)
     for (int a = 0; a < NL; a++) {
       double ph, dr[3];
       const double *pt = pts[et == 2 ? 1 : 0][q];
@@ -868,7 +871,7 @@ int cfdh_build_mesh_gen3(cfdh_ctx *c, int etype, int64_t nv64, int64_t nvo64, in
     }
   // reference matrices: Mref_a = sum_q w phi_a^2 ; Dref[a][b][k][l] = sum_q w dphi_a[k] dphi_b[l]  ->  K_ab = |det| sum_kl Dref (Ji Ji^T)[k][l]
   std::vector<double> Mref(NL, 0.0), Dref((size_t)NL * NL * 9, 0.0);
-  for (int q = 0; q < G3_NQ; q++) {
+  for (int q = 0; q < nq; q++) {
     const double w = pts[et == 2 ? 1 : 0][q][3];
     for (int a = 0; a < NL; a++) {
       Mref[a] += w * rphi[(size_t)q * NL + a] * rphi[(size_t)q * NL + a];
@@ -1019,7 +1022,7 @@ int cfdh_gen3_element_stiffness(const cfdh_ctx *c, const int32_t *v, const doubl
   if (et == 2) geom3<2>(Xe, Ji, adet, h); else geom3<0>(Xe, Ji, adet, h);
   if (!(adet > 0)) return CFDH_E_ARG;
   for (int k = 0; k < NL * NL; k++) K[k] = 0.0;
-  for (int q = 0; q < G3_NQ; q++) {
+  for (int q = 0; q < g3_nq(et); q++) {
     double pt[3], w, g[10][3];
     if (et == 2) {
       const int i = q / 49, j = (q / 7) % 7, k = q % 7;

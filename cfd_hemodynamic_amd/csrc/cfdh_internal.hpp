@@ -28,7 +28,7 @@
 #if defined(__HIPCC__)
 // 1/sqrt(x) for normal positive x: hardware estimate (v_rsq_f64) + two Newton steps (error -> ~1 ulp); the compiler's
 // IEEE sequence for 1.0 / sqrt(x) (sqrt with scaling + full division) is ~3x as many instructions, and the tau-moment
-// kernels evaluate it at 49 / 343 points per cell
+// kernels evaluate it at 49 / 171 points per cell
 __device__ __forceinline__ double cfdh_rsqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);
   const double h = 0.5 * x;

@@ -108,7 +108,7 @@ int orc3_element_tensors(int nc, const double *x, const int *cells, const double
     double mab[4][4];
     for (int a = 0; a < 4; a++)
       for (int b = 0; b < 4; b++) mab[a][b] = vol * (a == b ? 2.0 : 1.0) / 20.0;
-    /* tau moments on the 343-point rule */
+    /* tau moments on the degree-13 rule of cfdh_quad_tet.h (171 points) */
     double M[4][4], Lm = 0.0;
     memset(M, 0, sizeof M);
     {

@@ -128,7 +128,7 @@ static int facet_rule(int et, int f, double (*pts)[3], double *w) {
 void orcg3_element_tensors(int et, int64_t nc, const int64_t *cells, const double *x, const double *u, const double *un, const double *un2,
                            const double *p, const orcg3_params *P, const uint16_t *flags, int want_jac, double *Fe, double *Je) {
   const int nl = nloc_of(et), nd = 4 * nl, nvert = et == 5 ? 8 : 4, nfac = et == 5 ? 6 : 4, PO = 3 * nl;
-  const int nq = 343;
+  const int nq = et == 5 ? 343 : CFDH3_NQ;
   /* tables */
   double (*phiq)[MAXL] = malloc(sizeof(double) * MAXQ * MAXL);
   double (*dphiq)[MAXL][3] = malloc(sizeof(double) * MAXQ * MAXL * 3);
@@ -316,7 +316,8 @@ void orcg3_stiff_mass(int et, int64_t nc, const int64_t *cells, const double *x,
   double (*dphiq)[MAXL][3] = malloc(sizeof(double) * MAXQ * MAXL * 3);
   double (*hq)[MAXL][3][3] = malloc(sizeof(double) * MAXL * 9);
   double *wq = malloc(sizeof(double) * MAXQ);
-  for (int q = 0; q < 343; q++) {
+  const int nq = et == 5 ? 343 : CFDH3_NQ;
+  for (int q = 0; q < nq; q++) {
     double pt[3];
     if (et == 5) {
       const int i = q / 49, j = (q / 7) % 7, k = q % 7;
@@ -342,7 +343,7 @@ void orcg3_stiff_mass(int et, int64_t nc, const int64_t *cells, const double *x,
     double *Kc = K + c * nl * nl, *Mc = Md + c * nl;
     for (int r = 0; r < nl * nl; r++) Kc[r] = 0.0;
     for (int a = 0; a < nl; a++) Mc[a] = 0.0;
-    for (int q = 0; q < 343; q++) {
+    for (int q = 0; q < nq; q++) {
       double g[MAXL][3];
       for (int a = 0; a < nl; a++)
         for (int i = 0; i < 3; i++) g[a][i] = dphiq[q][a][0] * Ji[0][i] + dphiq[q][a][1] * Ji[1][i] + dphiq[q][a][2] * Ji[2][i];

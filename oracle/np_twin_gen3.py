@@ -8,7 +8,7 @@ element integrals) to round-off; Jacobian = d(residual) by central differences; 
 
 The residual is the one of np_twin_gen.py / np_twin_nd.py (stabilized_schur.py:67-123, backflow variant :107,:158-176), evaluated
 by quadrature on an affine cell:
-  * tetrahedra: the 343-point degree-13 collapsed Gauss rule of the P1 path (np_twin_nd.quad_rule(3));
+  * tetrahedra: the 171-point degree-13 rule of the P1 path (np_twin_nd.quad_rule(3), include/cfdh_quad_tet.h);
   * hexahedra (parallelepipeds: `create_box`): 7 x 7 x 7 Gauss-Legendre.
 The strong residual keeps its viscous part div(2 mu eps(u_mid)) = mu (lap u + grad div u): constant second derivatives on P2
 tetrahedra, the mixed derivatives of the trilinear functions (linear in the third coordinate) on hexahedra -- evaluated at the

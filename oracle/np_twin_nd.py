@@ -33,7 +33,16 @@ def quad_rule(d, n=7):
         W = np.outer(0.25 * wj, 0.5 * wl) * 2.0
         x, y = U.ravel(), (V * (1.0 - U)).ravel()
         return np.stack([1.0 - x - y, x, y], axis=1), W.ravel()
-    # d = 3: x = u, y = v (1-u), z = w (1-u)(1-v); Jacobian (1-u)^2 (1-v)
+    # d = 3 (round 4): the fully symmetric 171-point degree-13 rule of include/cfdh_quad_tet.h, the table the C oracle and the kernels
+    # compile in (generators and their provenance: tools/gen_quadrature_tet.py).  n != 7 asks for the collapsed Gauss rule below,
+    # which tests/test_oracle_nd.py uses as the independent reference for the table's exactness.
+    if n == 7:
+        return tet_rule_table()
+    return collapsed_tet_rule(n)
+
+
+def collapsed_tet_rule(n):
+    """x = u, y = v (1-u), z = w (1-u)(1-v); Jacobian (1-u)^2 (1-v): n^3 points, exact to degree 2n - 1 (rounds 2-3 used n = 7)."""
     t2, w2 = roots_jacobi(n, 2.0, 0.0)
     t1, w1 = roots_jacobi(n, 1.0, 0.0)
     t0, w0 = roots_legendre(n)
@@ -44,6 +53,22 @@ def quad_rule(d, n=7):
     y = (V * (1.0 - U)).ravel()
     z = (Wc * (1.0 - U) * (1.0 - V)).ravel()
     return np.stack([1.0 - x - y - z, x, y, z], axis=1), wt.ravel()
+
+
+def tet_rule_table():
+    """Barycentric points and weights of include/cfdh_quad_tet.h (CFDH3_QL, CFDH3_QW)."""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cfdh_quad_tet.h")
+    text = open(path).read()
+    nq = int(re.search(r"#define CFDH3_NQ (\d+)", text).group(1))
+    num = r"[-+]?\d\.\d+e[-+]\d+"
+    wtxt = text[text.index("CFDH3_QW[CFDH3_NQ]"):text.index("CFDH3_QL[CFDH3_NQ]")]
+    ltxt = text[text.index("CFDH3_QL[CFDH3_NQ]"):]
+    W = np.array([float(v) for v in re.findall(num, wtxt)])
+    L = np.array([float(v) for v in re.findall(num, ltxt)]).reshape(-1, 4)
+    assert len(W) == nq and L.shape == (nq, 4)
+    return L, W
 
 
 _RULES = {}

@@ -49,13 +49,28 @@ def _cube_problem(n=2, seed=1, **kw):
 
 
 def test_reference_simplex_integrals_in_3d():
+    """The tetrahedron rule (round 4: 171 points, fully symmetric, include/cfdh_quad_tet.h): positive, interior, exact for EVERY
+    monomial of degree <= 13 -- against the closed form and against the collapsed Gauss rule the twin builds itself -- and not
+    exact at degree 14 (so it is a degree-13 rule, as the 343-point rule of rounds 2-3 was)."""
     QL, QW = TN.quad_rule(3)
-    assert abs(QW.sum() - 1.0) < 1e-14 and QL.shape == (343, 4)
+    assert abs(QW.sum() - 1.0) < 1e-14 and QL.shape == (171, 4)
+    assert QW.min() > 0 and QL.min() > 0.01 and np.allclose(QL.sum(axis=1), 1.0, atol=1e-15)
     # int l0^a l1^b l2^c l3^d = 3! a! b! c! d! / (a+b+c+d+3)!  (weights normalised to the reference volume)
     from math import factorial as f
-    for e in [(1, 0, 0, 0), (2, 0, 0, 0), (1, 1, 0, 0), (3, 2, 1, 0), (4, 4, 2, 2), (6, 3, 2, 1)]:
-        exact = 6.0 * np.prod([f(k) for k in e]) / f(sum(e) + 3)
-        assert abs((QW * np.prod(QL ** np.array(e), axis=1)).sum() - exact) <= 1e-14 * max(exact, 1e-3)
+    RL, RW = TN.collapsed_tet_rule(8)
+    worst = 0.0
+    for a in range(14):
+        for b in range(14 - a):
+            for c in range(14 - a - b):
+                for d in range(14 - a - b - c):
+                    e = np.array((a, b, c, d))
+                    exact = 6.0 * np.prod([f(k) for k in e]) / f(sum(e) + 3)
+                    got = (QW * np.prod(QL ** e, axis=1)).sum()
+                    assert abs((RW * np.prod(RL ** e, axis=1)).sum() - exact) <= 1e-12 * exact
+                    worst = max(worst, abs(got - exact) / exact)
+    assert worst <= 1e-12, worst
+    e = np.array((14, 0, 0, 0))
+    assert abs((QW * np.prod(QL ** e, axis=1)).sum() / (6.0 * f(14) / f(17)) - 1.0) > 1e-8
     m = create_unit_cube(1)
     g, vol, h = TN.geometry(m.x, m.cells.astype(np.int64))
     assert np.allclose(vol, 1.0 / 6.0) and np.allclose(h, np.sqrt(3.0))
