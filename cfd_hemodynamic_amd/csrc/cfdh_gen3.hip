@@ -324,14 +324,17 @@ __global__ __launch_bounds__(g3_wgs(ET), 2) void gen3_asm_kernel(Gen3Args P) {
     }
     __syncthreads();
     const int npt = min(CH, NQ - ch * CH);
-    if (live && (needj || b == 0)) {
-      for (int s = grp; s < npt; s += NG) {
+    // residual-only pass of a cell without lifting: no Jacobian block is needed, so the NL lanes of a row share the row's points
+    // (lane (a, b) takes the points grp + NG b, grp + NG (b + NL), ...) and the row is summed over b at the end
+    const bool fsplit = !needj;
+    if (live) {
+      for (int s = fsplit ? grp + NG * b : grp; s < npt; s += fsplit ? NG * NL : NG) {
         const double *fr = fld[s];
         const double pha = bas[s][a][0], ga[3] = {bas[s][a][1], bas[s][a][2], bas[s][a][3]};
         const double uq[3] = {fr[0], fr[1], fr[2]}, R[3] = {fr[12], fr[13], fr[14]};
         const double tau = fr[19], tauL = fr[20], dv = fr[21];
         const double bga = uq[0] * ga[0] + uq[1] * ga[1] + uq[2] * ga[2];
-        if (b == 0) {
+        if (b == 0 || fsplit) {
           const double pq = fr[18], divu = fr[3] + fr[7] + fr[11];
 #pragma unroll
           for (int i = 0; i < 3; i++) {
@@ -344,31 +347,38 @@ __global__ __launch_bounds__(g3_wgs(ET), 2) void gen3_asm_kernel(Gen3Args P) {
           Fa[3] += dv * (pha * divu + tau / rho * (R[0] * ga[0] + R[1] * ga[1] + R[2] * ga[2]));
         }
         if (!needj) continue;
+        // ---- block (a, b) of the Jacobian at this point, with everything that does not depend on (i, j) formed once:
+        //   dWC_i(j) = k1 G[j][i] + delta_ij s_d,   dR_i(j) = dWC_i(j) - mu th (delta_ij lap_b + H_b[i][j])
+        //   Juu[i][j] += A1 dWC_i(j) - A2 (delta_ij lap_b + H_b[i][j]) + ga[j] w_i + z_j ga[i] + delta_ij dv mu th (ga . gb)
         const double phb = bas[s][b][0], gb[3] = {bas[s][b][1], bas[s][b][2], bas[s][b][3]};
         const double *Hb = hes[ET == 2 ? s : 0][b];
         const double lapb = Hb[0] + Hb[3] + Hb[5];
         const double bgb = uq[0] * gb[0] + uq[1] * gb[1] + uq[2] * gb[2];
         const double gg = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+        const double ct = dv * tau, ctb = ct * bga, mt = mu * th;
+        const double A1 = dv * pha + ctb, A2 = ctb * mt;
+        const double k1 = rho * th * phb, sd = rho * (a0dt * phb + th * bgb);
+        const double B1 = A1 * k1, Dg = A1 * sd - A2 * lapb + dv * mt * gg;
+        const double c3 = ct * th * phb, c4 = dv * rho * th * tauL, dmt = dv * mt;
+        const double w[3] = {dmt * gb[0] + c3 * R[0], dmt * gb[1] + c3 * R[1], dmt * gb[2] + c3 * R[2]};
+        const double z[3] = {c4 * gb[0], c4 * gb[1], c4 * gb[2]};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+          for (int j = 0; j < 3; j++) Juu[i][j] += B1 * fr[3 + 3 * j + i] - A2 * sym6(Hb, i, j) + ga[j] * w[i] + z[j] * ga[i];
+          Juu[i][i] += Dg;
+        }
+        const double cr = ct / rho, e1 = dv * th * pha, e2 = sd - mt * lapb;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-          double dR[3], dWC[3];
-#pragma unroll
-          for (int i = 0; i < 3; i++) {
-            const double dij = i == j ? 1.0 : 0.0;
-            dWC[i] = rho * (a0dt * phb * dij + th * (phb * fr[3 + 3 * j + i] + dij * bgb));
-            dR[i] = dWC[i] - mu * th * (lapb * dij + sym6(Hb, i, j));
-          }
-#pragma unroll
-          for (int i = 0; i < 3; i++) {
-            const double dij = i == j ? 1.0 : 0.0;
-            Juu[i][j] += dv * (pha * dWC[i] + mu * th * (ga[j] * gb[i] + dij * gg) + tau * dR[i] * bga + th * tau * R[i] * phb * ga[j] +
-                               rho * th * tauL * gb[j] * ga[i]);
-          }
-          Jpu[j] += dv * (th * pha * gb[j] + tau / rho * (dR[0] * ga[0] + dR[1] * ga[1] + dR[2] * ga[2]));
+          const double Gga = fr[3 + 3 * j] * ga[0] + fr[4 + 3 * j] * ga[1] + fr[5 + 3 * j] * ga[2];
+          const double Hga = sym6(Hb, 0, j) * ga[0] + sym6(Hb, 1, j) * ga[1] + sym6(Hb, 2, j) * ga[2];
+          Jpu[j] += e1 * gb[j] + cr * (k1 * Gga + e2 * ga[j] - mt * Hga);
         }
+        const double f1 = -dv * phb;
 #pragma unroll
-        for (int i = 0; i < 3; i++) Jup[i] += dv * (-phb * ga[i] + tau * gb[i] * bga);
-        Jpp += dv * tau / rho * gg;
+        for (int i = 0; i < 3; i++) Jup[i] += f1 * ga[i] + ctb * gb[i];
+        Jpp += cr * gg;
       }
     }
     __syncthreads();
@@ -401,6 +411,16 @@ __global__ __launch_bounds__(g3_wgs(ET), 2) void gen3_asm_kernel(Gen3Args P) {
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Juu[i][j] = acc[3 * i + j]; Jup[i] = acc[9 + i]; Jpu[i] = acc[12 + i]; }
     Jpp = acc[15];
     for (int i = 0; i < 4; i++) Fa[i] = acc[16 + i];
+    if (!needj) {  // rows shared by their NL lanes: sum over b in the order 0, 1, ..., NL - 1 (uniform in the workgroup)
+      if (live && grp == 0) for (int i = 0; i < 4; i++) red[4 * blk + i] = Fa[i];
+      __syncthreads();
+      if (live && grp == 0 && b == 0)
+        for (int i = 0; i < 4; i++) {
+          double v = red[4 * blk + i];
+          for (int bb = 1; bb < NL; bb++) v += red[4 * (blk + bb) + i];
+          Fa[i] = v;
+        }
+    }
   }
   if (!live || grp != 0) return;
   // ---- Dirichlet handling on the element level: lifting with the FULL block, then constrained rows and columns dropped
