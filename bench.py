@@ -161,6 +161,12 @@ def make_scenario(args, solver_name, **kw):
         from cfd_hemodynamic_amd.scenarios.unit_cube_pipe import UnitCubePipeSimulation
         return UnitCubePipeSimulation(solver_name, args.dt, 1.0, p_inlet=8.85, p_outlet=0.0, nx=args.nx, ny=args.ny, nz=args.ny, cell_type="tetrahedron",
                                       quiet=True, **dict(kw, _degree=2, p_grade=2))
+    if cfg == "q1":
+        # unit_square_pipe on quadrilateral cells (Q1/Q1), refined to --nx x --ny cells
+        from cfd_hemodynamic_amd.scenarios.unit_square_pipe import UnitSquarePipeSimulation
+        return UnitSquarePipeSimulation(solver_name, args.dt, 1.0, p_inlet=7.47, p_outlet=0.0, nx=args.nx, ny=args.ny, quiet=True, **kw)
+    if cfg != "c5":
+        raise SystemExit("no scenario for --config %s" % cfg)
     from cfd_hemodynamic_amd.scenarios.stenosis_with_tree import StenosisWithTreeSimulation
     return StenosisWithTreeSimulation(solver_name, args.dt, 1.0, grade="moderate", res=args.res, pulse_amplitude=0.5,
                                       ramp_time=args.ramp, inlet_max_velocity=args.v_max, quiet=True, **kw)
