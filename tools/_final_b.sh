@@ -1,6 +1,9 @@
 #!/bin/bash
 # final batch B: bench lines of the other configurations (CPU legs included where bench.py has them)
 mkdir -p gpurun_out/final
+( while true; do sleep 60; date >> gpurun_out/final/heartbeat.log; done ) &
+HB=$!
+trap "kill $HB 2>/dev/null" EXIT
 run() { name=$1; shift; timeout -k 10 1100 python bench.py "$@" > gpurun_out/final/$name.json 2> gpurun_out/final/$name.err; rc=$?
   python - <<PY
 import json
@@ -18,7 +21,7 @@ case $cfg in
  c5) run c5 --config c5 ;;
  c5bdf2) run c5_bdf2_vmax0.5 --config c5 --solver stabilized_schur_bdf2 --v-max 0.5 --no-cpu-baseline ;;
  c5b) run c5b_1m --config c5b ;;
- c5b8) run c5b_8m --config c5b --res3 1e-4 ;;
+ c5b8) run c5b_8m --config c5b --res3 1e-4 --no-cpu-baseline --parity-steps 0 ;;
  q1) run q1 --config q1 ;;
  q1h) run q1h --config q1h ;;
  p2) run p2 --config p2 ;;
