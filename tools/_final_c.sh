@@ -1,6 +1,9 @@
 #!/bin/bash
 # final batch C: ranks sharing the one GPU through the RCCL stand-in (communication counts, iteration ratios), matching 1-rank windows
 mkdir -p gpurun_out/final
+( while true; do sleep 60; date >> gpurun_out/final/heartbeat.log; done ) &
+HB=$!
+trap "kill $HB 2>/dev/null" EXIT
 export CFDH_SHARE_GPU=1
 FAKE=$PWD/tests/fake_rccl/libfake_rccl.so
 [ -f $FAKE ] || make -C tests/fake_rccl -s
