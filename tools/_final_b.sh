@@ -4,7 +4,7 @@ mkdir -p gpurun_out/final
 ( while true; do sleep 60; date >> gpurun_out/final/heartbeat.log; done ) &
 HB=$!
 trap "kill $HB 2>/dev/null" EXIT
-run() { name=$1; shift; timeout -k 10 1100 python bench.py "$@" > gpurun_out/final/$name.json 2> gpurun_out/final/$name.err; rc=$?
+run() { name=$1; shift; timeout -k 10 1100 python bench.py --steps 20 --warmup 5 "$@" > gpurun_out/final/$name.json 2> gpurun_out/final/$name.err; rc=$?
   python - <<PY
 import json
 try:
