@@ -1,5 +1,6 @@
 #!/bin/bash
-# final batch B: bench lines of the other configurations (CPU legs included where bench.py has them)
+# bench lines of the named configurations at the driver's --steps 20 --warmup 5 -> gpurun_out/final/<name>.json (tools/collect_lines.py copies them
+# into profiles/r04_bench_line_*.json):  gpurun -- 'bash tools/bench_lines.sh c2 c4 c5 c5b c5b8 q1 q1h p2 p2s p2t c5bdf2'
 mkdir -p gpurun_out/final
 ( while true; do sleep 60; date >> gpurun_out/final/heartbeat.log; done ) &
 HB=$!

@@ -1,5 +1,5 @@
 #!/bin/bash
-# final batch C: ranks sharing the one GPU through the RCCL stand-in (communication counts, iteration ratios), matching 1-rank windows
+# gpurun -- bash tools/bench_ranks_shared_gpu.sh : ranks sharing the one GPU through the RCCL stand-in (communication counts, iteration ratios), matching 1-rank windows
 mkdir -p gpurun_out/final
 ( while true; do sleep 60; date >> gpurun_out/final/heartbeat.log; done ) &
 HB=$!

@@ -1,5 +1,5 @@
 #!/bin/bash
-# final batch D: by-grid kernel traces of the 8 M-DOF configurations for the scaling model
+# gpurun -- bash tools/profile_8m.sh : by-grid kernel traces of the 8 M-DOF configurations for the scaling model
 mkdir -p gpurun_out/final
 ( while true; do sleep 60; date >> gpurun_out/final/heartbeat.log; done ) &
 HB=$!
