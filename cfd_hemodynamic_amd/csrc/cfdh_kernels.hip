@@ -1605,14 +1605,16 @@ static void launch_down(cfdh_ctx *c, const CsrDev &G, const VT *val, const T *x,
 }
 
 template <typename T>
-static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof) {
+// l0 > 0: the cycle of the levels l0 .. (the replicated levels of a partitioned run below its distributed finest pressure level);
+// b / x are then level l0's vectors
+static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof, int l0 = 0) {
   const int nl = (int)H.lev.size();
   // down: right-hand sides of all coarse levels.  (Merging the coarse levels' down-sweeps into one launch through the
   // products G_2 G_1, ... was measured and dropped: the products fill in -- 1.1 M entries for a 713-row level -- and the one
   // launch costs more than the two it replaces.)
-  for (int l = 0; l + 1 < nl; l++) {
+  for (int l = l0; l + 1 < nl; l++) {
     AmgLevel *L = H.lev[l], *N = H.lev[l + 1];
-    const T *src = l == 0 ? b : (const T *)L->b.p;
+    const T *src = l == l0 ? b : (const T *)L->b.p;
     if (prof && l == 0) prof_begin(c, prof + 4);
     if (L->fine) launch_down<float, T>(c, L->G, L->G.valf.p, src, (T *)N->b.p);
     else launch_down<double, T>(c, L->G, L->G.val.p, src, (T *)N->b.p);
@@ -1622,12 +1624,12 @@ static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof) 
   int l = nl - 1;
   {
     AmgLevel *L = H.lev[l];
-    const T *bl = l == 0 ? b : (const T *)L->b.p;
-    T *xl = l == 0 ? x : (T *)L->x.p;
-    if (nl >= 2 && H.lev[nl - 2]->Dn > 0) {
+    const T *bl = l == l0 ? b : (const T *)L->b.p;
+    T *xl = l == l0 ? x : (T *)L->x.p;
+    if (nl - 2 >= l0 && H.lev[nl - 2]->Dn > 0) {
       AmgLevel *U = H.lev[nl - 2];
-      const T *bu = nl - 2 == 0 ? b : (const T *)U->b.p;
-      T *xu = nl - 2 == 0 ? x : (T *)U->x.p;
+      const T *bu = nl - 2 == l0 ? b : (const T *)U->b.p;
+      T *xu = nl - 2 == l0 ? x : (T *)U->x.p;
       hipLaunchKernelGGL((fused_up_dense_kernel<T>), dim3((unsigned)((64ll * U->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, U->n,
                          U->Sb.rowptr.p, U->Sb.col.p, U->Sb.val.p, bu, U->D.p, U->Dn, bl, xu);
       l = nl - 3;
@@ -1648,10 +1650,10 @@ static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof) 
     }
   }
   // up
-  for (; l >= 0; l--) {
+  for (; l >= l0; l--) {
     AmgLevel *L = H.lev[l], *N = H.lev[l + 1];
-    const T *bl = l == 0 ? b : (const T *)L->b.p;
-    T *xl = l == 0 ? x : (T *)L->x.p;
+    const T *bl = l == l0 ? b : (const T *)L->b.p;
+    T *xl = l == l0 ? x : (T *)L->x.p;
     // Cahouet-Chabard combination in the epilogue of the last kernel of the (single right-hand side) pressure cycle
     const bool epi = l == 0 && c->epi.on && sizeof(T) == sizeof(double);
     const double ea = epi ? c->epi.alpha : 0.0, eb = epi ? c->epi.beta : 0.0;
@@ -1734,7 +1736,10 @@ int k_dl0_up(cfdh_ctx *c, double *out) {
   cfdh_ctx::DistL0 &d = c->dl0;
   AmgLevel *N = c->hLg.lev[1];
   const int nvo = c->nvo;
-  CHK(amg_cycle_jacobi<double>(c, c->hLg, 1, (const double *)N->b.p, N->x.p, 0));
+  // the replicated levels: composite-operator cycle from level 1 (6 launches for four coarse levels instead of 13 sweeps)
+  static const bool sweeps = getenv("CFDH_DL0_COARSE_SWEEPS") && getenv("CFDH_DL0_COARSE_SWEEPS")[0] == '1';
+  if (c->hLg.fused && c->opt.amg_smooth_degree == 1 && !sweeps) CHK(amg_cycle_fused<double>(c, c->hLg, (const double *)N->b.p, N->x.p, 0, 1));
+  else CHK(amg_cycle_jacobi<double>(c, c->hLg, 1, (const double *)N->b.p, N->x.p, 0));
   if (d.P.nnz <= 12ll * c->nv && c->nv >= 16384)
     hipLaunchKernelGGL((sell_spmv_kernel<3, double>), dim3((unsigned)((c->nv + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, c->nv,
                        d.P.sptr.p, d.P.scol.p, d.P.sval.p, (const double *)N->x.p, d.x1.p, (const double *)d.xa.p);
