@@ -162,3 +162,45 @@ $EndElements
     assert {tuple(sorted(v)) for v in m3.facet_vertices[ft3.find(8)]} == {(0, 1, 2)}
     assert {tuple(sorted(v)) for v in m3.facet_vertices[ft3.find(11)]} == {(1, 2, 3)}
     assert abs(m3.cell_volumes()[0] - 1.0 / 6.0) < 1e-15
+
+
+@pytest.mark.parametrize("kind", ["P2_tri", "Q1_quad", "P2_tet", "Q1_hex"])
+@pytest.mark.parametrize("nparts", [2, 3, 5])
+def test_partition_of_node_meshes_of_the_generic_elements(kind, nparts):
+    """Round 4: P2 / Q1 contexts take part in partitioned runs (cfdh_create_elem_part) -- the NODE mesh of the function space is
+    partitioned like a vertex mesh.  Same invariants as for P1: owned rows complete, ghosts grouped by owner in receive order, every
+    cell integrated by exactly one rank (first-node rule), send lists = the neighbours' receive lists."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    if kind in ("P2_tri", "Q1_quad"):
+        from gen_util import node_mesh
+        m = node_mesh("P2" if kind == "P2_tri" else "Q1", 6)
+    else:
+        from gen3_util import node_mesh3
+        m = node_mesh3("P2" if kind == "P2_tet" else "Q1", 3)
+    assert m.cells.shape[1] == {"P2_tri": 6, "Q1_quad": 4, "P2_tet": 10, "Q1_hex": 8}[kind]
+    owner = partition_vertices_rcb(m.x, nparts)
+    parts = [LocalPart(m, owner, r) for r in range(nparts)]
+    assert sum(p.nvo for p in parts) == m.num_vertices
+    assert np.array_equal(np.sort(np.concatenate([p.owned_global for p in parts])), np.arange(m.num_vertices))
+    seen_cells = np.zeros(m.num_cells, dtype=int)
+    seen_facets = np.zeros(len(m.facet_cells), dtype=int)
+    for p in parts:
+        touch = (owner[m.cells] == p.rank).any(axis=1)
+        assert np.array_equal(np.nonzero(touch)[0], p.cell_ids)
+        assert p.cells.min() >= 0 and p.cells.max() < p.nv                      # every node of a local cell is local
+        assert np.array_equal(p.l2g[p.cells], m.cells[p.cell_ids])               # local connectivity = global, renumbered
+        own_cell = owner[m.cells[p.cell_ids, 0]] == p.rank
+        seen_cells[p.cell_ids[own_cell]] += 1
+        seen_facets[p.facet_ids[own_cell[p.facet_cells]]] += 1
+        assert np.array_equal(p.recv_idx, np.arange(p.nvo, p.nv))
+        assert np.all(np.diff(owner[p.ghost_global]) >= 0)
+        assert np.allclose(p.x, m.x[p.l2g])
+    assert np.all(seen_cells == 1) and np.all(seen_facets == 1)
+    for p in parts:
+        for k, q in enumerate(p.nbr):
+            sent = p.l2g[p.send_idx[p.send_ptr[k]:p.send_ptr[k + 1]]]
+            qk = list(parts[q].nbr).index(p.rank)
+            recv = parts[q].l2g[parts[q].recv_idx[parts[q].recv_ptr[qk]:parts[q].recv_ptr[qk + 1]]]
+            assert np.array_equal(sent, recv)
