@@ -300,6 +300,7 @@ struct cfdh_ctx {
   double cc_alpha = 0, cc_beta = 0;
   // Cahouet-Chabard combination z_p = alpha t + beta zH (r on Dirichlet rows) applied in the epilogue of the last
   // kernel of the pressure cycle instead of a kernel of its own
+  int up0_rows = 0;  // > 0: the fused cycle's finest up-sweep computes the first up0_rows rows only (owned rows of the overlapping velocity cycle)
   struct Epilogue { bool on = false, done = false; double alpha = 0, beta = 0; const double *zH = nullptr, *r = nullptr; const unsigned char *pbc = nullptr; double *out = nullptr; } epi;
   std::vector<double> h_Lval, h_Ml;  // P1 stiffness on the vertex graph, lumped mass (geometry only)
   dbuf<double> d_Lval, d_Ml;         // device copies (device-side preconditioner set-up)
@@ -479,7 +480,7 @@ int k_dl0_up(cfdh_ctx *c, double *out);               // replicated coarse cycle
 int k_ext_pack(cfdh_ctx *c, const double *vec, double *out);  // [u | p | ghost triplets] -> nv contiguous (ux,uy) pairs
 int k_scatter_global(cfdh_ctx *c, int n, const int *l2g, const double *loc, double *glob);
 int k_gather_global(cfdh_ctx *c, int n, const int *l2g, const double *glob, double *loc);
-int k_cc_combine(cfdh_ctx *c, int n, double alpha, double beta, const double *t, const double *z, const double *r, const unsigned char *pbc, double *out);
+int k_cc_combine(cfdh_ctx *c, int n, double alpha, double beta, const double *t, const double *z, const double *r, const unsigned char *pbc, double *out, double *out2 = nullptr);
 int k_nullspace_test(cfdh_ctx *c, double *nrm, double *absnrm);
 int k_bc_scatter(cfdh_ctx *c, int n, int ncomp, const int *idx, const unsigned char *flag, const double *val, const double *mult);
 

@@ -1630,7 +1630,9 @@ static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof, 
       AmgLevel *U = H.lev[nl - 2];
       const T *bu = nl - 2 == l0 ? b : (const T *)U->b.p;
       T *xu = nl - 2 == l0 ? x : (T *)U->x.p;
-      hipLaunchKernelGGL((fused_up_dense_kernel<T>), dim3((unsigned)((64ll * U->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, U->n,
+      // (a two-level hierarchy: this IS the finest up-sweep -- owned rows only where the caller keeps just those)
+      const int un = (nl - 2 == 0 && c->up0_rows > 0 && c->up0_rows < U->n) ? c->up0_rows : U->n;
+      hipLaunchKernelGGL((fused_up_dense_kernel<T>), dim3((unsigned)((64ll * un + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, un,
                          U->Sb.rowptr.p, U->Sb.col.p, U->Sb.val.p, bu, U->D.p, U->Dn, bl, xu);
       l = nl - 3;
     } else {
@@ -1660,19 +1662,21 @@ static int amg_cycle_fused(cfdh_ctx *c, AmgHier &H, const T *b, T *x, int prof, 
     const double *ezH = epi ? c->epi.zH : nullptr, *er = epi ? c->epi.r : nullptr;
     const unsigned char *epbc = epi ? c->epi.pbc : nullptr;
     if (epi) { xl = (T *)c->epi.out; c->epi.done = true; }
+    // overlapping velocity cycle of a partitioned run: only the owned rows (the first ones) of the finest level's result are kept
+    const int nrow = (l == 0 && c->up0_rows > 0 && c->up0_rows < L->n) ? c->up0_rows : L->n;
     if (prof && l == 0) prof_begin(c, prof);
     // a few longer rows (irregular vertices of a triangle mesh) go through the tail loop of the one-chunk kernel; the chunked
     // kernel is for meshes whose typical row exceeds a chunk (tetrahedra)
     if (L->sell && L->Sb.sell_maxw <= 14 && L->Sc.sell_maxw <= 14)
-      hipLaunchKernelGGL((fused_up_sell_kernel<T, false>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
+      hipLaunchKernelGGL((fused_up_sell_kernel<T, false>), dim3((unsigned)((nrow + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, nrow,
                          L->Sb.sptr.p, L->Sb.scol.p, L->Sb.sval.p, bl, L->Sc.sptr.p, L->Sc.scol.p, L->Sc.sval.p, (const T *)N->x.p, xl,
                          ea, eb, ezH, er, epbc);
     else if (L->sell)
-      hipLaunchKernelGGL((fused_up_sell_kernel<T, true>), dim3((unsigned)((L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
+      hipLaunchKernelGGL((fused_up_sell_kernel<T, true>), dim3((unsigned)((nrow + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, nrow,
                          L->Sb.sptr.p, L->Sb.scol.p, L->Sb.sval.p, bl, L->Sc.sptr.p, L->Sc.scol.p, L->Sc.sval.p, (const T *)N->x.p, xl,
                          ea, eb, ezH, er, epbc);
     else
-      hipLaunchKernelGGL((fused_up_csr_kernel<T>), dim3((unsigned)((8ll * L->n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, L->n,
+      hipLaunchKernelGGL((fused_up_csr_kernel<T>), dim3((unsigned)((8ll * nrow + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, nrow,
                          L->Sb.rowptr.p, L->Sb.col.p, L->Sb.val.p, bl, L->Sc.rowptr.p, L->Sc.col.p, L->Sc.val.p, (const T *)N->x.p, xl,
                          ea, eb, ezH, er, epbc);
     if (prof && l == 0) prof_end(c, prof);
@@ -1720,7 +1724,9 @@ int k_dl0_down(cfdh_ctx *c, const double *halo_vec) {
   cfdh_ctx::DistL0 &d = c->dl0;
   AmgLevel *N = c->hLg.lev[1];
   const int nvo = c->nvo, nv = c->nv;
-  hipLaunchKernelGGL(dl0_pack_kernel, dim3((nv + TPB - 1) / TPB), dim3(TPB), 0, c->stream, nvo, nv, c->dim, halo_vec, d.wdinv.p, d.b.p, d.xa.p, d.ghost_rhs ? 1 : 0);
+  // without the exchange of the right-hand side's ghost layer the producer (the H solve) has written the owned part of d.b itself;
+  // the ghost parts of d.b and d.xa stay zero
+  if (d.ghost_rhs) hipLaunchKernelGGL(dl0_pack_kernel, dim3((nv + TPB - 1) / TPB), dim3(TPB), 0, c->stream, nvo, nv, c->dim, halo_vec, d.wdinv.p, d.b.p, d.xa.p, 1);
   dim3 block(TPB), grid((unsigned)((8ll * nvo + TPB - 1) / TPB)), gridS((unsigned)((nvo + TPB - 1) / TPB));
   if (d.A.nnz <= 12ll * nvo && nvo >= 16384)  // short regular rows: SELL-64 (as the replicated level 0 would use)
     hipLaunchKernelGGL((sell_jacobi_pre_kernel<double>), gridS, block, 0, c->stream, nvo, d.A.sptr.p, d.A.scol.p, d.A.svalw.p,
@@ -1780,9 +1786,13 @@ __global__ __launch_bounds__(TPB) void cc_scale_kernel(int n, const double *__re
 }
 __global__ __launch_bounds__(TPB) void cc_combine_kernel(int n, double alpha, double beta, const double *__restrict__ t,
                                                          const double *__restrict__ z, const double *__restrict__ r,
-                                                         const unsigned char *__restrict__ pbc, double *__restrict__ out) {
+                                                         const unsigned char *__restrict__ pbc, double *__restrict__ out, double *__restrict__ out2) {
   const int i = blockIdx.x * TPB + threadIdx.x;
-  if (i < n) out[i] = (pbc[i] & 1) ? r[i] : alpha * t[i] + beta * z[i];
+  if (i < n) {
+    const double v = (pbc[i] & 1) ? r[i] : alpha * t[i] + beta * z[i];
+    out[i] = v;
+    if (out2) out2[i] = v;  // partitioned run: z_p also into the pressure slot of the halo scratch vector
+  }
 }
 __global__ __launch_bounds__(TPB) void scatter_global_kernel(int n, const int *__restrict__ l2g, const double *__restrict__ loc, double *__restrict__ glob) {
   const int i = blockIdx.x * TPB + threadIdx.x;
@@ -1834,8 +1844,8 @@ int k_cc_scale(cfdh_ctx *c, int n, const double *ml, const double *z, double *y)
   return 0;
 }
 int k_cc_combine(cfdh_ctx *c, int n, double alpha, double beta, const double *t, const double *z, const double *r,
-                 const unsigned char *pbc, double *out) {
-  hipLaunchKernelGGL(cc_combine_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, alpha, beta, t, z, r, pbc, out);
+                 const unsigned char *pbc, double *out, double *out2) {
+  hipLaunchKernelGGL(cc_combine_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, n, alpha, beta, t, z, r, pbc, out, out2);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

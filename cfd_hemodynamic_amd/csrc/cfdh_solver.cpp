@@ -183,6 +183,7 @@ static int build_global_pressure(cfdh_ctx *c) {
         CHK(cfdh_upload_csr(c, Al, d.A, &wl)); CHK(cfdh_upload_csr(c, Pl, d.P)); CHK(cfdh_upload_csr(c, Pt, d.PT));
         HIPCHK(c, d.wdinv.upload(wl, c->stream));
         HIPCHK(c, d.b.alloc(nv)); HIPCHK(c, d.xa.alloc(nv)); HIPCHK(c, d.r.alloc(nvo)); HIPCHK(c, d.x1.alloc(nv));
+        HIPCHK(c, d.b.zero(c->stream)); HIPCHK(c, d.xa.zero(c->stream));  // their ghost parts stay zero when the rhs's ghost layer is not exchanged
         HIPCHK(c, hipStreamSynchronize(c->stream));
         d.n1 = n1;
         d.on = true;
@@ -551,12 +552,16 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
         if (upper) { /* t_p = r_p: used in place */ }
         else if (multi) CHK(k_spmv_block_ghost(c, 3, c->pcw.p, c->pp0.p, rp));   // t_p = r_p - A10 y_u (with ghosts)
         else CHK(k_spmv_block(c, 3, c->pu0.p, c->pp0.p, rp, 0));
-        if (!(c->opt.cc_smooth_degree == 2 && k_cc_cheb2_scale(c, &c->Hlev, upper ? rp : c->pp0.p, c->pp1.p, c->ccMl.p, c->pu1.p))) {
-          CHK(k_level_smooth(c, &c->Hlev, upper ? rp : c->pp0.p, c->pp1.p, c->opt.cc_smooth_degree));
-          CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, c->pu1.p));
+        {
+          // right-hand side of the pressure cycle.  Distributed finest level: straight into the level's own vector (ghost part zero);
+          // with the ghost-layer exchange switched on (CFDH_DL0_GHOST_RHS=1) into the pressure slot of the halo scratch vector
+          double *y = !dist ? c->pu1.p : (c->dl0.ghost_rhs ? c->pcw.p + nu : c->dl0.b.p);
+          if (!(c->opt.cc_smooth_degree == 2 && k_cc_cheb2_scale(c, &c->Hlev, upper ? rp : c->pp0.p, c->pp1.p, c->ccMl.p, y))) {
+            CHK(k_level_smooth(c, &c->Hlev, upper ? rp : c->pp0.p, c->pp1.p, c->opt.cc_smooth_degree));
+            CHK(k_cc_scale(c, nvo, c->ccMl.p, c->pp1.p, y));
+          }
         }
         if (dist) {
-          CHK(v_copy(c, nvo, c->pu1.p, c->pcw.p + nu));  // right-hand side into the pressure slot of the halo scratch vector
         } else if (global_p && c->gp_allgather) {
           CHK(k_gather_global(c, nvo, c->gp_send_idx.p, c->pu1.p, c->gp_sendbuf.p));  // owned values in global-id order
         } else if (global_p) {
@@ -596,16 +601,21 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
           c->epi.on = false;
           CHK(rc);
         }
-        if (c->epi.done) c->epi.done = false;
-        else CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, upper ? rp : c->pp0.p, c->ccPbc.p, zp));
-        if (multi && c->opt.schur_full) CHK(v_copy(c, nvo, zp, c->pcw.p + nu));  // z_p into the halo scratch vector
+        if (c->epi.done) {
+          c->epi.done = false;
+          if (multi && c->opt.schur_full) CHK(v_copy(c, nvo, zp, c->pcw.p + nu));  // z_p into the halo scratch vector
+        } else {
+          CHK(k_cc_combine(c, nvo, c->cc_alpha, c->cc_beta, c->pu2.p, c->pp1.p, upper ? rp : c->pp0.p, c->ccPbc.p, zp,
+                           (multi && c->opt.schur_full) ? c->pcw.p + nu : nullptr));
+        }
         return 0;
       case 3:
         if (c->opt.schur_full) {
-          if (multi) CHK(k_spmv_block_ghost(c, 2, c->pcw.p, c->pu0.p, ru));  // t_u = r_u - A01 z_p (with ghosts)
+          // t_u = r_u - A01 z_p (with ghosts); for the overlapping cycle straight into the velocity slots of the halo scratch vector
+          // (the kernel reads the pressure slots and ghost records of that vector and writes its owned velocity slots: disjoint)
+          if (multi) CHK(k_spmv_block_ghost(c, 2, c->pcw.p, c->ras ? c->pcw.p : c->pu0.p, ru));
           else CHK(k_spmv_block(c, 2, zp, c->pu0.p, ru, 0));
           if (multi && c->ras) {
-            CHK(v_copy(c, nu, c->pu0.p, c->pcw.p));       // t_u into the halo scratch vector; cycle in stage 4
             // experiment (CFDH_RAS_GHOST_RHS=0): no exchange of the overlap residual -- the right-hand side of the overlapping
             // cycle is zero on the ghost layer
             if (!ras_ghost_rhs()) CHK(v_zero(c, c->NL - c->NO, c->pcw.p + c->NO));
@@ -631,8 +641,15 @@ static int pc_stage(cfdh_ctx *c, const double *r, double *z, int stage) {
         if (multi && c->ras && c->opt.schur_full) {
           // restricted additive Schwarz: cycle on owned + ghost vertices, keep the owned part
           CHK(k_ext_pack(c, c->pcw.p, c->ras_b.p));
-          CHK(k_amg_vcycle(c, c->hA, c->ras_b.p, c->ras_x.p));
-          CHK(v_copy(c, nu, c->ras_x.p, zu));
+          if (c->hA.fused && c->opt.amg_smooth_degree == 1 && c->hA.lev.size() >= 2) {
+            c->up0_rows = nvo;  // the finest up-sweep writes the owned rows only, straight into z_u
+            const int rc = k_amg_vcycle(c, c->hA, c->ras_b.p, zu);
+            c->up0_rows = 0;
+            CHK(rc);
+          } else {
+            CHK(k_amg_vcycle(c, c->hA, c->ras_b.p, c->ras_x.p));
+            CHK(v_copy(c, nu, c->ras_x.p, zu));
+          }
         }
         return 0;
       default:
