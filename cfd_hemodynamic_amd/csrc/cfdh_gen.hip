@@ -299,7 +299,8 @@ __global__ __launch_bounds__(TPB) void gen_asm_kernel(GenArgs P) {
   }
   // exterior-facet terms of this cell that involve test node a
   const unsigned fl = P.flag[cell];
-  if (fl) {
+  // (the facet terms enter the velocity rows of node a only: nothing to do when both are Dirichlet rows, i.e. on no-slip walls)
+  if (fl && (D.bc[a] & 3u) != 3u) {
     double cen[2] = {0, 0};
     for (int q = 0; q < NV; q++) { cen[0] += D.X[q][0] * (1.0 / NV); cen[1] += D.X[q][1] * (1.0 / NV); }
     constexpr int NQF = ET == 1 ? 4 : 2;

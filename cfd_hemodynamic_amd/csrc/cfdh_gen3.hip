@@ -216,7 +216,7 @@ struct Cell3 {
 
 template <int ET, bool JAC>
 __global__ __launch_bounds__(g3_wgs(ET), 2) void gen3_asm_kernel(Gen3Args P) {
-  constexpr int NL = g3_nloc(ET), WGS = g3_wgs(ET), GS = g3_gs(ET), NG = WGS / GS, NF = ET == 2 ? 6 : 4;
+  constexpr int NL = g3_nloc(ET), WGS = g3_wgs(ET), GS = g3_gs(ET), NG = WGS / GS;
   constexpr int CH = ET == 2 ? 32 : 64;              // points per chunk (32 on hexahedra: their per-point Hessians would cost a third workgroup per CU)
   constexpr int NQ = g3_nq(ET), NCH = (NQ + CH - 1) / CH;
   __shared__ Cell3<NL> D;
@@ -486,10 +486,25 @@ __global__ __launch_bounds__(128) void gen3_facet_kernel(Gen3Args P, const int *
   const double rho = P.rho, th = P.theta;
   double Juu[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Jup[3] = {0, 0, 0}, Fa[4] = {0, 0, 0, 0};
   const unsigned fl = P.flag[cell];
+  // the facet terms enter the velocity rows of node a only: when all three are Dirichlet rows (a node on a no-slip wall) they would
+  // be dropped below -- and the lanes of the nodes off the facet see a vanishing test function.  Most exterior facets are walls.
+  if ((D.bc[a] & 7u) == 7u) return;
   if (fl) {
     for (int f = 0; f < NF; f++) {
       const bool ext = P.ds_terms && ((fl >> f) & 1u), bfl = P.beta != 0.0 && ((fl >> (8 + f)) & 1u);
       if (!ext && !bfl) continue;
+      {  // a facet all of whose nodes are no-slip nodes contributes to dropped rows only (uniform in the workgroup)
+        constexpr int et = ET;
+        bool wall = true;
+        for (int k = 0; k < facet_nvert(et); k++) wall = wall && (D.bc[facet_vertex(et, f, k)] & 7u) == 7u;
+        if (ET == 1)
+          for (int e = 0; e < 6; e++) {
+            int i, j;
+            tet_edge(e, i, j);
+            if (i != f && j != f) wall = wall && (D.bc[4 + e] & 7u) == 7u;
+          }
+        if (wall) continue;
+      }
       double n[3], area;
       facet_geom3<ET>(D.X, f, n, area);
       for (int q = 0; q < facet_nq<ET>(); q++) {
