@@ -1,4 +1,5 @@
 #!/bin/bash
+# gpurun -- bash tools/final_check.sh : headline kernel trace + PMC passes + the bench line at the driver's settings + the whole GPU suite + smoke, at the current sources
 mkdir -p gpurun_out/final
 ( while true; do sleep 60; date >> gpurun_out/final/heartbeat.log; done ) &
 HB=$!
