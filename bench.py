@@ -134,7 +134,7 @@ def make_scenario(args, solver_name, **kw):
         # remove_p_mean 0: see the tolerance caveat in scenarios/simple_bifurcation.py (with the reference's mean removal the
         # steps after the first meet snes_rtol on the outlet rows alone and skip the PDE solve at this mesh scale)
         kw = dict(kw)
-        kw["options"] = dict(kw.get("options", {}), remove_p_mean=0)
+        kw["options"] = dict(kw.get("options", {}), remove_p_mean=int(args.remove_p_mean))
         return MicrovasculatureSimulation(solver_name, args.dt, 1.0, v_inlet=args.v_max, res=args.res3, quiet=True, **kw)
     if cfg == "p2":
         # `--solver stabilized_schur_backflow --p_grade 2` (P2/P2 triangles, do-nothing outlet + backflow term) on the
@@ -184,8 +184,8 @@ def workload_text(args, sc):
             "q1": "unit_square_pipe (80 x 1.5 mm channel, p_inlet 7.47 / p_outlet 0, no-slip walls) on %d x %d quadrilateral cells, Q1/Q1" % (args.nx, args.ny),
             "q1h": "unit_cube_pipe (80 x 1.5 x 1.5 mm duct, p_inlet 8.85 / p_outlet 0, no-slip walls) on %d x %d x %d hexahedral cells, Q1/Q1" % (args.nx, args.ny, args.ny),
             "p2t": "unit_cube_pipe duct (80 x 1.5 x 1.5 mm, p_inlet 8.85 / p_outlet 0, no-slip walls) split into tetrahedra, %d x %d x %d bricks x 6, P2/P2" % (args.nx, args.ny, args.ny),
-            "c5b": "simple_bifurcation (3-D, tetrahedra; Re=%s, inlet u_y = %g (1 - (r/r_in)^2), p = 0 at both outlets; remove_p_mean=0), voxel-tet mesh res=%g" % (
-                ("%.1f" % sc.Re) if args.config == "c5b" else "-", args.v_max, args.res3)}[args.config]
+            "c5b": "simple_bifurcation (3-D, tetrahedra; Re=%s, inlet u_y = %g (1 - (r/r_in)^2), p = 0 at both outlets; remove_p_mean=%d), voxel-tet mesh res=%g" % (
+                ("%.1f" % sc.Re) if args.config == "c5b" else "-", args.v_max, int(args.remove_p_mean), args.res3)}[args.config]
     return "%s: %d nodes, %d DOF (equal-order), dt=%g, steps from t=0, PETSc-default tolerances (snes_rtol 1e-8, ksp_rtol 1e-5)" % (
         head, nv, (sc.mesh.geometry.dim + 1) * nv, args.dt)
 
@@ -269,6 +269,8 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=2, help="extra steps with HIP-event kernel timing (after the timed region)")
     ap.add_argument("--host-loop-steps", type=int, default=10, help="extra steps with the reference's literal state-copy loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--remove-p-mean", type=int, default=0, choices=[0, 1],
+                    help="c5b: 1 = the reference's literal mean-pressure removal (stabilized_schur.py:319); default 0, see DESIGN.md section 9 'tolerance trap'")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "host"])
     ap.add_argument("--verbose", type=int, default=0)
     ap.add_argument("--solver", default="stabilized_schur", choices=["stabilized_schur", "stabilized_schur_bdf2"],

@@ -22,6 +22,7 @@ case $cfg in
  c5) run c5 --config c5 ;;
  c5bdf2) run c5_bdf2_vmax0.5 --config c5 --solver stabilized_schur_bdf2 --v-max 0.5 --no-cpu-baseline ;;
  c5b) run c5b_1m --config c5b ;;
+ c5bmean) run c5b_1m_remove_p_mean1 --config c5b --remove-p-mean 1 ;;
  c5b8) run c5b_8m --config c5b --res3 1e-4 --no-cpu-baseline --parity-steps 0 ;;
  q1) run q1 --config q1 ;;
  q1h) run q1h --config q1h ;;
