@@ -930,7 +930,10 @@ int cfdh_fgmres(cfdh_ctx *c, const double *b, double *x, int *its_out, int *reas
   const int fp32_env = getenv("CFDH_KRYLOV_FP32") ? atoi(getenv("CFDH_KRYLOV_FP32")) : 1;
   const int gslot = c->guess_slot;
   const bool expect_long = gslot >= 0 && gslot < cfdh_ctx::GUESS_NEWTON && c->guess_last_its[gslot] >= 20;
-  bool use32 = fp32_env > 0 && o.ksp_rtol >= 1e-6 && c->krylov_fp32_ok && (expect_long || fp32_env >= 2);
+  // In a partitioned run the copy costs one more all-reduce per iteration (the measured norm) and saves 1/nranks of the traffic it
+  // saves on one GPU: taken only where a rank still holds >= 2 M unknowns (decided from the GLOBAL count: the same on every rank).
+  const bool worth32 = c->nranks <= 1 || (c->nvo_global / c->nranks) * (c->dim + 1) >= 2.0e6;
+  bool use32 = fp32_env > 0 && o.ksp_rtol >= 1e-6 && c->krylov_fp32_ok && ((expect_long && worth32) || fp32_env >= 2);
   float *V32 = nullptr;
   const size_t ld32 = (ld + 3) & ~(size_t)3;  // columns of the copy start on 16-B boundaries (float4 loads)
   if (use32) {
