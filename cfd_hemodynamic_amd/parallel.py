@@ -220,7 +220,8 @@ class PartComm:
     def fall_back_to_host(self, ctx, why):
         """Replace the RCCL communicator by the host-staged exchange (collective: all ranks call it)."""
         if self.rank == 0:
-            print("[cfdh] WARNING: %s -- falling back to host-staged exchange over torch.distributed" % why, flush=True)
+            import sys
+            print("[cfdh] WARNING: %s -- falling back to host-staged exchange over torch.distributed" % why, file=sys.stderr, flush=True)  # stdout carries the bench line only
         self.backend = "host"
         self.fallback_reason = why
         self._attach_host(ctx)
