@@ -201,17 +201,29 @@ class PartComm:
             return
         ctx.set_halo(part.nbr, part.send_ptr, part.send_idx, part.recv_ptr, part.recv_idx)
         if self.backend == "rccl":
+            import os
+            import sys
             import torch
             import torch.distributed as dist
             from . import _lib
-            uid = _lib.rccl_unique_id() if self.rank == 0 else bytes(128)
-            t = torch.tensor(list(uid), dtype=torch.uint8)
-            dist.broadcast(t, src=0)
+            # RCCL prints a version banner on STDOUT when its first communicator is formed; the stdout of a bench run carries one
+            # JSON line and nothing else, so file descriptor 1 points at stderr while the library initialises
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
             err = None
             try:
-                ctx.comm_init_rccl(bytes(t.tolist()), self.rank, self.size)
-            except RuntimeError as e:
-                err = str(e)
+                uid = _lib.rccl_unique_id() if self.rank == 0 else bytes(128)
+                t = torch.tensor(list(uid), dtype=torch.uint8)
+                dist.broadcast(t, src=0)
+                try:
+                    ctx.comm_init_rccl(bytes(t.tolist()), self.rank, self.size)
+                except RuntimeError as e:
+                    err = str(e)
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             if self.allreduce(0.0 if err is None else 1.0, "max") > 0:  # every rank takes the same branch
                 self.fall_back_to_host(ctx, "RCCL communicator init failed: %s" % (err or "on another rank"))
         else:
