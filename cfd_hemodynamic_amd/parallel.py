@@ -48,12 +48,13 @@ def partition_vertices_rcb(x, nparts):
 class LocalPart:
     """The piece of the global mesh that rank `rank` works on, in local numbering."""
 
-    def __init__(self, mesh, owner, rank):
+    def __init__(self, mesh, owner, rank, layers=1):
         cells = mesh.cells
         nparts = int(owner.max()) + 1
         self.rank, self.nparts = int(rank), nparts
+        self.layers = int(layers)
         cown = owner[cells]  # [nc,3]
-        mine = (cown == rank).any(axis=1)
+        mine = self._cell_mask(cells, owner, rank, self.layers, mesh.num_vertices)
         self.cell_ids = np.nonzero(mine)[0]
         lc = cells[self.cell_ids]
         verts = np.unique(lc)
@@ -86,14 +87,23 @@ class LocalPart:
         need = set()
         send = {}
         nloc = cells.shape[1]  # 3: triangles, 4: tetrahedra
-        for a in range(nloc):
-            for b in range(nloc):
-                if a == b:
+        if self.layers > 1:
+            # deeper overlap: rank q's ghosts are the non-owned vertices of ITS cell set
+            for q in range(nparts):
+                if q == rank:
                     continue
-                sel = (cown[:, a] == rank) & (cown[:, b] != rank)
-                if sel.any():
-                    pairs = np.stack([cown[sel, b], cells[sel, a]], axis=1)
-                    need.update(map(tuple, np.unique(pairs, axis=0)))
+                vq = np.unique(cells[self._cell_mask(cells, owner, q, self.layers, mesh.num_vertices)])
+                for v in vq[owner[vq] == rank]:
+                    need.add((q, int(v)))
+        else:
+            for a in range(nloc):
+                for b in range(nloc):
+                    if a == b:
+                        continue
+                    sel = (cown[:, a] == rank) & (cown[:, b] != rank)
+                    if sel.any():
+                        pairs = np.stack([cown[sel, b], cells[sel, a]], axis=1)
+                        need.update(map(tuple, np.unique(pairs, axis=0)))
         for q, v in sorted(need):
             send.setdefault(int(q), []).append(int(v))
         nbrs = sorted(set(self.nbr.tolist()) | set(send.keys()))
@@ -110,6 +120,16 @@ class LocalPart:
         self.send_idx = np.asarray(si, dtype=np.int32)
         self.recv_ptr = np.asarray(rp, dtype=np.int64)
         self.recv_idx = np.asarray(ri, dtype=np.int32)
+
+    @staticmethod
+    def _cell_mask(cells, owner, rank, layers, nv):
+        """Cells of rank's part: those touching an owned vertex, then (layers - 1) times those touching a vertex of the set so far."""
+        mask = (owner[cells] == rank).any(axis=1)
+        for _ in range(layers - 1):
+            inset = np.zeros(nv, dtype=bool)
+            inset[np.unique(cells[mask])] = True
+            mask = inset[cells].any(axis=1)
+        return mask
 
     @property
     def nv(self):
@@ -143,7 +163,12 @@ class PartComm:
         if owner.shape != (mesh.num_vertices,) or owner.min() < 0 or owner.max() >= self.size:
             raise ValueError("partitioner must return one owner rank in [0, size) per vertex")
         self.owner = owner
-        self.part = LocalPart(mesh, owner, self.rank)
+        import os
+        # Two cell layers of overlap by default (round 4): the overlapping velocity cycle of the preconditioner works on owned + ghost
+        # vertices, and one layer costs 1.2 - 1.8 x the iterations of one rank on fine meshes where two cost 1.1 - 1.6 x (DESIGN.md
+        # section 7).  The library itself takes any ghost set (cfdh_create_part + cfdh_set_halo); CFDH_OVERLAP_LAYERS=1 gives the
+        # one-cell overlap of a DOLFINx ghost layer.
+        self.part = LocalPart(mesh, owner, self.rank, layers=int(os.environ.get("CFDH_OVERLAP_LAYERS", "2")))
         return self.part
 
     # -- collective helpers on the host (norms, gathers of the harness) -------------

@@ -204,3 +204,34 @@ def test_partition_of_node_meshes_of_the_generic_elements(kind, nparts):
             qk = list(parts[q].nbr).index(p.rank)
             recv = parts[q].l2g[parts[q].recv_idx[parts[q].recv_ptr[qk]:parts[q].recv_ptr[qk + 1]]]
             assert np.array_equal(sent, recv)
+
+
+@pytest.mark.parametrize("layers", [2, 3])
+@pytest.mark.parametrize("nparts", [2, 4, 5])
+def test_partition_with_more_layers_of_overlap(nparts, layers):
+    """Round 4: PartComm.make_part builds parts with TWO cell layers of overlap by default (the overlapping velocity cycle needs them on
+    fine meshes).  The owned rows stay complete, every vertex of a local cell is local, the part contains the part with one layer less,
+    ghosts are grouped by owner in receive order, and the send lists are the neighbours' receive lists."""
+    m, _ = create_dfg_channel(8)
+    owner = partition_vertices_rcb(m.x, nparts)
+    parts = [LocalPart(m, owner, r, layers=layers) for r in range(nparts)]
+    less = [LocalPart(m, owner, r, layers=layers - 1) for r in range(nparts)]
+    assert sum(p.nvo for p in parts) == m.num_vertices
+    for p, q in zip(parts, less):
+        assert np.array_equal(p.owned_global, q.owned_global)
+        assert set(q.cell_ids) <= set(p.cell_ids) and set(q.ghost_global) <= set(p.ghost_global)
+        assert (owner[m.cells[p.cell_ids]] == p.rank).any(axis=1).sum() == (owner[m.cells] == p.rank).any(axis=1).sum()  # owned rows complete
+        assert p.cells.min() >= 0 and p.cells.max() < p.nv and np.array_equal(p.l2g[p.cells], m.cells[p.cell_ids])
+        assert np.array_equal(p.recv_idx, np.arange(p.nvo, p.nv)) and np.all(np.diff(owner[p.ghost_global]) >= 0)
+        # exactly the cells within `layers` vertex-hops of an owned vertex
+        reach = owner == p.rank
+        for _ in range(layers - 1):
+            reach = reach.copy()
+            reach[np.unique(m.cells[reach[m.cells].any(axis=1)])] = True
+        assert np.array_equal(np.nonzero(reach[m.cells].any(axis=1))[0], p.cell_ids)
+    for p in parts:
+        for k, q in enumerate(p.nbr):
+            sent = p.l2g[p.send_idx[p.send_ptr[k]:p.send_ptr[k + 1]]]
+            qk = list(parts[q].nbr).index(p.rank)
+            recv = parts[q].l2g[parts[q].recv_idx[parts[q].recv_ptr[qk]:parts[q].recv_ptr[qk + 1]]]
+            assert np.array_equal(sent, recv)
